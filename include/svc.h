@@ -1,0 +1,117 @@
+/*
+ * svc.h — C ABI of the MI355X-native SmartVidCrop saliency-to-crop hot path.
+ *
+ * libsvc_hip.so (retargetvid_amd/csrc) exports exactly these entry points.  Every
+ * data pointer is a DEVICE pointer unless its name ends in _host; the caller owns
+ * all buffers, the library owns only the weights and scratch workspace inside the
+ * handle.  `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ * all work is enqueued on it and nothing synchronises unless stated.  Every call
+ * returns 0 on success or a negative SVC_E_* code; svc_last_error() then holds a
+ * message for the calling thread.  The library never exits the process and never
+ * reads stdin (the reference blocks on input() at smartVidCrop.py:544-545).
+ *
+ * Reference interfaces replaced (paths relative to the reference tree):
+ *   svc_create / svc_destroy    unisal_handler.init_unisal_for_images()
+ *                               3rd_party_libs/unisal/unisal_handler.py:68-71 and
+ *                               Trainer.model / init_unisal_weights, unisal/train.py:1449-1456, :1200-1209
+ *   svc_resize_frames_u8        cv2.resize(frame,(SAL_W,SAL_H),INTER_LINEAR), smartVidCrop.py:333-335, :633-635
+ *   svc_saliency_u8             unisal_handler.predictions_from_memory_nuint8_np(),
+ *                               3rd_party_libs/unisal/unisal_handler.py:85-86 ->
+ *                               Trainer.generate_predictions_from_image_memory_nuint8_np, unisal/train.py:1255-1279
+ *   svc_threshold_u8            sc_threshold(), smartVidCrop.py:1050-1059
+ *   svc_cluster_center          the clustering loop + centre loop of smart_vid_crop():
+ *                               sc_clustering_filt() smartVidCrop.py:1062-1161 with the cut blend :2359-2373,
+ *                               and sc_find_center_of_mass() :1163-1219 / :2402-2414
+ *   svc_iou_i32                 bb_intersection_over_union(), smartVidCrop.py:927-944
+ *                               (== retargetvid_eval.py:10-27)
+ */
+#ifndef SVC_H_
+#define SVC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVC_OK 0
+#define SVC_E_INVALID (-1)     /* bad argument / unsupported size           */
+#define SVC_E_HIP (-2)         /* a HIP runtime call failed                 */
+#define SVC_E_BLOB (-3)        /* malformed weights blob                    */
+#define SVC_E_NOMEM (-4)
+
+typedef struct SvcHandle SvcHandle;
+
+/* The crop parameters (sc_init_crop_params, smartVidCrop.py:132-209) that the
+ * device path consumes. */
+typedef struct SvcParams {
+    int32_t hdbscan_min;          /* CP['hdbscan_min']  (min_cluster_size)             */
+    int32_t hdbscan_min_samples;  /* CP['hdbscan_min_samples'], 0 = None               */
+    int32_t select_sum;           /* CP['select_sum']: 1 = cluster sum, else cluster max */
+    int32_t op_close;             /* CP['op_close']                                    */
+    int32_t clust_filt;           /* CP['clust_filt']: 0 skips filtering, centres only */
+} SvcParams;
+
+/* Per-call diagnostics written by svc_cluster_center when `stats` is non-NULL:
+ * int32[n][4] = { points after threshold/blend, clusters selected, label kept, reserved } */
+#define SVC_STATS_STRIDE 4
+
+const char *svc_last_error(void);
+
+/* weights_blob_host: the packed, BN-folded static SALICON slice of a UNISAL
+ * checkpoint (retargetvid_amd.weights.pack_blob).  The blob is copied to `device`. */
+int svc_create(const void *weights_blob_host, size_t n_bytes, int device, SvcHandle **out);
+int svc_destroy(SvcHandle *h);
+
+/* frames[n][h][w][3] u8 RGB -> out[n][sh][sw][3] u8, OpenCV INTER_LINEAR semantics. */
+int svc_resize_frames_u8(SvcHandle *h, const uint8_t *frames, int n, int height, int width,
+                         uint8_t *out, int sh, int sw, void *stream);
+
+/* frames_nhwc[n][h][w][3] u8 RGB (saliency size, e.g. 140x250) -> maps_nhw[n][h][w] u8.
+ * Frame-major output; the reference's [h][w][n] view is a transpose done by the
+ * caller only when someone asks for VD['smaps']. */
+int svc_saliency_u8(SvcHandle *h, const uint8_t *frames_nhwc, int n, int height, int width,
+                    uint8_t *maps_nhw, void *stream);
+
+/* maps[i] = maps[i] < t ? 0 : maps[i], in place. */
+int svc_threshold_u8(SvcHandle *h, uint8_t *maps, size_t n_bytes, int t, void *stream);
+
+/* Cluster filter + cut blend + centre of every map, in place on thresholded maps.
+ * blend_flags_host[n] (HOST memory, may be NULL): non-zero at i means "after filtering
+ * map i, blend it into map i+1" (smartVidCrop.py:2369-2373; the caller evaluates the
+ * cut test).  xy[n][2] receives (x, y) centres as float64 in saliency-map pixels,
+ * NaN = None (empty map).  stats may be NULL. */
+int svc_cluster_center(SvcHandle *h, uint8_t *maps_nhw, int n, int height, int width,
+                       const uint8_t *blend_flags_host, const SvcParams *params,
+                       double *xy, int32_t *stats, void *stream);
+
+/* a[n][4], b[n][4] int32 boxes (x1,y1,x2,y2) -> out[n] float64 IoU, inclusive +1 pixel convention. */
+int svc_iou_i32(const int32_t *a, const int32_t *b, size_t n, double *out, void *stream);
+
+/* Test/diagnostic door: copy internal per-frame clustering state of the LAST
+ * svc_cluster_center call to HOST buffers (any may be NULL).  Synchronises.
+ *   pts_host[cap]   packed points: row | col<<8 | value<<16, raster order
+ *   core_host[cap]  core distances (squared)
+ *   mst_host[cap][3] MST edges in Prim order: from, to, weight
+ *   labels_host[cap] final labels (-1 = noise)
+ * Returns the number of points of that frame (or a negative error). */
+int svc_debug_cluster_state(SvcHandle *h, int frame, int cap, uint32_t *pts_host, uint32_t *core_host,
+                            uint32_t *mst_host, int32_t *labels_host);
+
+/* Test/diagnostic door: copy an intermediate activation of the LAST svc_saliency_u8
+ * call (NHWC fp32, frame 0..n-1) to a HOST buffer.  `which` is one of the SVC_TAP_*
+ * ids.  Returns the number of floats per frame (or a negative error).  Synchronises. */
+#define SVC_TAP_INPUT 0     /* [256][416][3]  normalised network input          */
+#define SVC_TAP_FEAT4X 1    /* [32][52][64]   cnn.features.7 output (pre-subsample) */
+#define SVC_TAP_FEAT2X 2    /* [16][26][160]  cnn.features.14 output            */
+#define SVC_TAP_FEAT1X 3    /* [8][13][1296]  cnn.features.18 output + 16 Gaussian maps */
+#define SVC_TAP_POSTCNN 4   /* [8][13][256]                                     */
+#define SVC_TAP_DEC 5       /* [32][52][64]   post_upsampling_2 output          */
+#define SVC_TAP_PRE 6       /* [h][w]         pre-softmax map at saliency size  */
+int svc_debug_tap(SvcHandle *h, int which, int frame, float *out_host, size_t cap_floats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVC_H_ */

@@ -1,0 +1,59 @@
+"""ctypes binding of libsvc_hip.so (C ABI: include/svc.h).
+
+There is deliberately no CPU fallback: if the shared library has not been built
+(`make -C retargetvid_amd/csrc`, or `python -c "import __graft_entry__ as g; g.build()"`)
+importing any device op raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsvc_hip.so')
+
+EXPORTS = ('svc_last_error', 'svc_create', 'svc_destroy', 'svc_resize_frames_u8', 'svc_saliency_u8',
+           'svc_threshold_u8', 'svc_cluster_center', 'svc_iou_i32', 'svc_debug_cluster_state', 'svc_debug_tap')
+
+
+class SvcParams(ctypes.Structure):
+    _fields_ = [('hdbscan_min', ctypes.c_int32), ('hdbscan_min_samples', ctypes.c_int32),
+                ('select_sum', ctypes.c_int32), ('op_close', ctypes.c_int32), ('clust_filt', ctypes.c_int32)]
+
+
+class SvcError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Raises SvcError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise SvcError('HIP library %s not found: build it with `make -C %s/csrc` '
+                       '(there is no CPU fallback)' % (LIB_PATH, _HERE))
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    lib.svc_last_error.restype = ctypes.c_char_p
+    lib.svc_last_error.argtypes = []
+    lib.svc_create.argtypes = [vp, sz, i32, ctypes.POINTER(vp)]
+    lib.svc_destroy.argtypes = [vp]
+    lib.svc_resize_frames_u8.argtypes = [vp, vp, i32, i32, i32, vp, i32, i32, vp]
+    lib.svc_saliency_u8.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    lib.svc_threshold_u8.argtypes = [vp, vp, sz, i32, vp]
+    lib.svc_cluster_center.argtypes = [vp, vp, i32, i32, i32, vp, ctypes.POINTER(SvcParams), vp, vp, vp]
+    lib.svc_iou_i32.argtypes = [vp, vp, sz, vp, vp]
+    lib.svc_debug_cluster_state.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+    lib.svc_debug_tap.argtypes = [vp, i32, i32, vp, sz]
+    for name in EXPORTS:
+        if name != 'svc_last_error':
+            getattr(lib, name).restype = i32
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc < 0:
+        raise SvcError('svc call failed (%d): %s' % (rc, load().svc_last_error().decode(errors='replace')))
+    return rc

@@ -1,0 +1,252 @@
+// hdb_tree.h — HDBSCAN* hierarchy stage of the cluster filter (K10, second half).
+//
+// Input: the N-1 edges of the mutual-reachability MST in the library's Prim order,
+// stably sorted by weight.  Output: for every point the condensed cluster that
+// absorbed it, the weight at which that happened, and the excess-of-mass selection —
+// enough to label points exactly like hdbscan's generic path
+// (call site smartVidCrop.py:1099; algorithm: SURVEY.md Appendix A steps 6-10).
+//
+// The reference library builds the full single-linkage dendrogram, condenses it
+// top-down (BFS) and then sums stabilities.  This file does the same work in ONE
+// bottom-up pass over the sorted edges: a component that first reaches
+// min_cluster_size opens a condensed cluster; a smaller component merging into it is
+// a batch of points "falling out" of that cluster at lambda = 1/w; two large
+// components merging is a true split that opens their parent.  Stability is
+// accumulated as  sum(lambda*size) - birth*sum(size)  per cluster, in float64.
+// The result is identical to the library's whenever its `subtree > own` comparisons
+// are not exact floating-point ties (summation order differs).
+//
+// Cluster numbering: the library numbers condensed clusters in BFS order of the
+// dendrogram; the caller only needs that order to break ties between equally
+// weighted clusters ("first arg-max wins", smartVidCrop.py:1114), so it is
+// evaluated lazily by cluster_before() from the dendrogram parent links.
+//
+// Plain C++ (no HIP types) so the same source is unit-tested on the CPU
+// (tests/native/tree_harness.cpp) and inlined into the device kernel.
+#pragma once
+#include <stdint.h>
+
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+#define SVC_HD __host__ __device__ __forceinline__
+#else
+#define SVC_HD inline
+#endif
+
+namespace hdb {
+
+static const uint32_t NONE16 = 0xFFFFu;
+static const int32_t ROOT_NOISE = -2;
+
+struct Edge {          // 8 bytes
+    uint16_t a, b;     // a = node already in the tree (library: current_node), b = new node
+    uint32_t w;        // mutual reachability (squared distance), >= 1
+};
+
+// Per-point arrays (capacity n) and per-cluster arrays (capacity max_clusters(n, mcs)).
+struct Tree {
+    // per point
+    uint16_t *sp;      // small-component union-find parent
+    uint16_t *ssz;     // small-component size (valid at roots)
+    uint16_t *absc;    // cluster that absorbed this small component (valid at roots), NONE16 = not yet
+    uint32_t *absw;    // weight at absorption (valid at roots)
+    uint32_t *sdn;     // dendrogram node id of a live small component (valid at roots)
+    // dendrogram: parent link of every node (2n-1 entries): parent << 1 | is_right
+    uint32_t *dparent;
+    // per cluster
+    uint16_t *cup;     // union-find parent towards the current top cluster of the component
+    int32_t *ctp;      // tree parent (-1 = root so far)
+    int32_t *cleft, *cright;
+    uint32_t *cbirthw; // weight at which the cluster is born top-down (0 = root: lambda 0)
+    uint32_t *cminw;   // smallest weight among the cluster's rows (largest lambda)
+    uint32_t *csize;   // points in the component while this cluster is its top
+    uint32_t *ccnt;    // sum of row sizes
+    uint32_t *cdn;     // dendrogram node of the component while this cluster is its top
+    uint32_t *csplit;  // dendrogram node at which the cluster's children were created
+    double *cacc;      // sum of lambda * row size, later the (propagated) stability
+    uint8_t *csel;     // selected by excess of mass
+    int32_t *crep;     // nearest selected ancestor-or-self, ROOT_NOISE if none
+    int32_t nclusters;
+    int32_t n;
+};
+
+SVC_HD int max_clusters(int n, int mcs) {
+    if (mcs < 1) mcs = 1;
+    return 2 * (n / mcs) + 2;
+}
+
+SVC_HD uint32_t find_small(Tree &t, uint32_t x) {
+    while (t.sp[x] != x) {
+        uint16_t g = t.sp[t.sp[x]];
+        t.sp[x] = g;              // path halving
+        x = g;
+    }
+    return x;
+}
+
+SVC_HD uint32_t find_small_ro(const Tree &t, uint32_t x) {
+    while (t.sp[x] != x) x = t.sp[x];
+    return x;
+}
+
+SVC_HD uint32_t find_top(Tree &t, uint32_t c) {
+    while (t.cup[c] != c) {
+        uint16_t g = t.cup[t.cup[c]];
+        t.cup[c] = g;
+        c = g;
+    }
+    return c;
+}
+
+SVC_HD int32_t new_cluster(Tree &t, uint32_t w, uint32_t size, uint32_t node, int32_t l, int32_t r) {
+    int32_t c = t.nclusters++;
+    t.cup[c] = (uint16_t)c;
+    t.ctp[c] = -1;
+    t.cleft[c] = l;
+    t.cright[c] = r;
+    t.cbirthw[c] = 0;
+    t.cminw[c] = w;
+    t.csize[c] = size;
+    t.ccnt[c] = size;
+    t.cdn[c] = node;
+    t.csplit[c] = node;
+    t.cacc[c] = 0.0;
+    t.csel[c] = 0;
+    t.crep[c] = ROOT_NOISE;
+    return c;
+}
+
+SVC_HD void init_points(Tree &t, int lo, int hi) {      // callable by many threads on disjoint ranges
+    for (int i = lo; i < hi; ++i) {
+        t.sp[i] = (uint16_t)i;
+        t.ssz[i] = 1;
+        t.absc[i] = (uint16_t)NONE16;
+        t.absw[i] = 0;
+        t.sdn[i] = (uint32_t)i;
+    }
+}
+
+// The sequential pass.  edges must be sorted by w (stable w.r.t. Prim order).
+SVC_HD void build(Tree &t, const Edge *edges, int n, int mcs) {
+    t.n = n;
+    t.nclusters = 0;
+    for (int i = 0; i < n - 1; ++i) {
+        const Edge e = edges[i];
+        const uint32_t w = e.w;
+        const double lam = 1.0 / (double)w;
+        uint32_t ra = find_small(t, e.a), rb = find_small(t, e.b);
+        const bool abig = t.absc[ra] != NONE16, bbig = t.absc[rb] != NONE16;
+        uint32_t ca = 0, cb = 0, sa, sb, na, nb;
+        if (abig) { ca = find_top(t, t.absc[ra]); sa = t.csize[ca]; na = t.cdn[ca]; }
+        else      { sa = t.ssz[ra]; na = t.sdn[ra]; }
+        if (bbig) { cb = find_top(t, t.absc[rb]); sb = t.csize[cb]; nb = t.cdn[cb]; }
+        else      { sb = t.ssz[rb]; nb = t.sdn[rb]; }
+        const uint32_t node = (uint32_t)(n + i);
+        t.dparent[na] = node << 1;
+        t.dparent[nb] = (node << 1) | 1u;
+        if (!abig && !bbig) {
+            const uint32_t s = sa + sb;
+            if ((int)s < mcs) {
+                uint32_t big = ra, small = rb;
+                if (sb > sa) { big = rb; small = ra; }
+                t.sp[small] = (uint16_t)big;
+                t.ssz[big] = (uint16_t)s;
+                t.sdn[big] = node;
+            } else {                                   // a condensed cluster is born bottom-up
+                int32_t c = new_cluster(t, w, s, node, -1, -1);
+                t.cacc[c] = lam * (double)sa + lam * (double)sb;
+                t.absc[ra] = (uint16_t)c; t.absw[ra] = w;
+                t.absc[rb] = (uint16_t)c; t.absw[rb] = w;
+            }
+        } else if (abig && bbig) {                     // true split: both sides >= mcs
+            int32_t p = new_cluster(t, w, sa + sb, node, (int32_t)ca, (int32_t)cb);
+            t.cacc[p] = lam * (double)sa + lam * (double)sb;
+            t.cup[ca] = (uint16_t)p; t.cup[cb] = (uint16_t)p;
+            t.ctp[ca] = p; t.ctp[cb] = p;
+            t.cbirthw[ca] = w; t.cbirthw[cb] = w;
+        } else {                                       // small side falls out of the big side's cluster
+            uint32_t c = abig ? ca : cb, r = abig ? rb : ra, s = abig ? sb : sa;
+            t.absc[r] = (uint16_t)c; t.absw[r] = w;
+            t.cacc[c] += lam * (double)s;
+            t.ccnt[c] += s;
+            t.csize[c] += s;
+            t.cdn[c] = node;
+        }
+    }
+    t.dparent[2 * n - 2] = 0xFFFFFFFFu;               // root of the dendrogram
+}
+
+// Stability, excess-of-mass selection (root allowed) and nearest-selected-ancestor map.
+// Returns the number of selected clusters.
+SVC_HD int select(Tree &t) {
+    const int nc = t.nclusters;
+    for (int c = 0; c < nc; ++c) {                      // creation order: children before parents
+        const double birth = t.cbirthw[c] ? 1.0 / (double)t.cbirthw[c] : 0.0;
+        double stab = t.cacc[c] - birth * (double)t.ccnt[c];
+        double sub = 0.0;
+        if (t.cleft[c] >= 0) sub = t.cacc[t.cleft[c]] + t.cacc[t.cright[c]];
+        if (sub > stab) {
+            t.csel[c] = 0;
+            stab = sub;
+        } else {
+            t.csel[c] = 1;
+        }
+        t.cacc[c] = stab;
+    }
+    int nsel = 0;
+    for (int c = nc - 1; c >= 0; --c) {                 // parents before children
+        const int32_t p = t.ctp[c];
+        if (p >= 0 && t.crep[p] >= 0) {                 // an ancestor is selected: it wins
+            t.csel[c] = 0;
+            t.crep[c] = t.crep[p];
+        } else if (t.csel[c]) {
+            t.crep[c] = c;
+            ++nsel;
+        } else {
+            t.crep[c] = ROOT_NOISE;
+        }
+    }
+    return nsel;
+}
+
+// Label of point p as a cluster index (creation order), -1 = noise.
+SVC_HD int32_t point_cluster(const Tree &t, uint32_t p, int nsel) {
+    const uint32_t r = find_small_ro(t, p);
+    const uint16_t c0 = t.absc[r];
+    if (c0 == NONE16) return -1;
+    const int32_t rep = t.crep[c0];
+    if (rep == ROOT_NOISE) return -1;
+    const int root = t.nclusters - 1;
+    if (rep == root && nsel == 1) {
+        // a lone selected root keeps only the points whose lambda >= the root's max lambda
+        return t.absw[r] <= t.cminw[root] ? rep : -1;
+    }
+    return rep;
+}
+
+SVC_HD int dendro_depth(const Tree &t, uint32_t node) {
+    int d = 0;
+    while (t.dparent[node] != 0xFFFFFFFFu) { node = t.dparent[node] >> 1; ++d; }
+    return d;
+}
+
+// True if condensed cluster c1 gets a smaller id than c2 in the library's numbering
+// (BFS order of the dendrogram; children of one split: left first).
+SVC_HD bool cluster_before(const Tree &t, int c1, int c2) {
+    if (c1 == c2) return false;
+    const int p1 = t.ctp[c1], p2 = t.ctp[c2];
+    if (p1 < 0) return true;                            // root has the smallest id
+    if (p2 < 0) return false;
+    if (p1 == p2) return t.cleft[p1] == c1;
+    uint32_t s1 = t.csplit[p1], s2 = t.csplit[p2];
+    int d1 = dendro_depth(t, s1), d2 = dendro_depth(t, s2);
+    if (d1 != d2) return d1 < d2;
+    uint32_t side1 = 0, side2 = 0;
+    while (s1 != s2) {
+        side1 = t.dparent[s1] & 1u; side2 = t.dparent[s2] & 1u;
+        s1 = t.dparent[s1] >> 1; s2 = t.dparent[s2] >> 1;
+    }
+    return side1 < side2;
+}
+
+}  // namespace hdb

@@ -1,0 +1,86 @@
+// svc_internal.h — handle layout and helpers shared by svc_net.hip / svc_tail.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/svc.h"
+
+void svc_set_error(const char *fmt, ...);
+
+#define SVC_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            svc_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return SVC_E_HIP;                                                                  \
+        }                                                                                      \
+    } while (0)
+
+#define SVC_CHECK_LAUNCH()  SVC_HIP(hipGetLastError())
+
+struct SvcTensor {
+    const float *dev;     // device pointer into the blob
+    size_t n;             // floats
+};
+
+// One folded layer of the static SALICON graph, in execution order (weights.fold_state_dict).
+struct SvcLayer {
+    enum Kind { STEM, PW, DW, GAUSS, ADAPT, SMOOTH } kind;
+    int cin, cout, stride, relu6;
+    SvcTensor w, b;
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return SVC_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) { svc_set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(e)); return SVC_E_NOMEM; }
+        bytes = need;
+        return SVC_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+// Fixed-point resampling tables for one (in, out) size pair, device resident.
+struct ResampleTab {
+    int ksize = 0;
+    DevBuf bounds;    // int32[out][2]  (first, count)
+    DevBuf coeff;     // int32[out][ksize]
+    int max_span = 0; // max over blocks of rows spanned (host-computed helper)
+    std::vector<int> bounds_host;
+};
+
+struct NetPlan;     // svc_net.hip
+
+struct SvcHandle {
+    int device = 0;
+    DevBuf blob;
+    std::vector<SvcTensor> tensors;
+    std::vector<SvcLayer> layers;
+    std::vector<float> gauss_params;      // coarse_gaussians_salicon [16][2][2]
+    // network workspace + plan (svc_net.hip)
+    NetPlan *plan = nullptr;
+    // ingest resize tables keyed by (in_h, in_w, out_h, out_w)
+    std::map<std::tuple<int, int, int, int>, DevBuf> cvtabs;
+    // tail workspace (svc_tail.hip)
+    DevBuf tail_ws;
+    DevBuf tail_offsets;     // ring-walk offset table
+    int tail_n_offsets = 0;
+    int tail_frames = 0, tail_h = 0, tail_w = 0;
+    size_t tail_frame_stride = 0;      // bytes of per-frame tail workspace
+    int chunk = 32;                    // frames per network pass
+};
+
+int svc_net_release(SvcHandle *h);

@@ -1,0 +1,947 @@
+// svc_net.hip — UNISAL static (SALICON) saliency forward for gfx950, plus the ingest
+// down-scale.  Hand-written HIP: NHWC fp32 activations, BN folded into the weights,
+// 1x1 convolutions on the f32-input MFMA (v_mfma_f32_32x32x2_f32, exact fp32),
+// depthwise / resampling / softmax-quantise stages as coalesced float4 kernels.
+//
+// Reference semantics restated per kernel (paths relative to the reference tree):
+//   k_cv_resize      cv2.resize(INTER_LINEAR)         smartVidCrop.py:333-335, :633-635
+//   k_lanczos_norm   PIL LANCZOS + ToTensor + Normalize 3rd_party_libs/unisal/unisal/data.py:1281-1294
+//   k_stem           conv_bn(3,32,stride 2)+ReLU6      unisal/models/MobileNetV2.py:10-15,124
+//   k_pw<TN>         1x1 conv (+BN)(+ReLU6)(+residual) MobileNetV2.py:18-23,26-83; unisal/model.py:388-409
+//   k_dw<S>          3x3 depthwise (+BN+ReLU6)         MobileNetV2.py:48-51,66-69
+//   k_subsample      x[..., ::2, ::2] (omit-stride)    MobileNetV2.py:170-171
+//   k_gauss_fill     Gaussian prior maps + concat      unisal/model.py:348-385,446-448
+//   k_upsample2x     bilinear x2, align_corners=False  unisal/model.py:304-309,475-478
+//   k_adapt          adaptation 1x1 64->1 (+bias)      unisal/model.py:481-483
+//   k_smooth_down    nearest x8 + replicate pad 20 + 41x41 smoothing + bilinear to (h,w)
+//                                                      unisal/model.py:485-495
+//   k_quantise       log-softmax/exp/max/x255/u8 cast  unisal/utils.py:132-136, unisal/train.py:1267-1274
+#include <math.h>
+
+#include <algorithm>
+
+#include "svc_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// --------------------------------------------------------------------------------------
+// error string
+// --------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void svc_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *svc_last_error(void) { return g_err; }
+
+// --------------------------------------------------------------------------------------
+// ingest down-scale: OpenCV INTER_LINEAR on u8 (11-bit fixed-point weights)
+// tab layout (int32): xofs[ow] | xa[ow][2] | yofs[oh] | ya[oh][2] | xmax
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cv_resize(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                   const int *__restrict__ tab, int n, int h, int w, int oh, int ow) {
+    const int *xofs = tab, *xa = tab + ow, *yofs = tab + 3 * ow, *ya = tab + 3 * ow + oh;
+    const int xmax = tab[3 * ow + 3 * oh];
+    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t total = (size_t)n * oh * ow;
+    if (gid >= total) return;
+    int ox = gid % ow;
+    int oy = (gid / ow) % oh;
+    int f = gid / ((size_t)ow * oh);
+    int sy = yofs[oy];
+    int y0 = min(max(sy, 0), h - 1), y1 = min(max(sy + 1, 0), h - 1);
+    int b0 = ya[2 * oy], b1 = ya[2 * oy + 1];
+    int sx = xofs[ox];
+    int sx1 = min(sx + 1, w - 1);
+    int a0 = xa[2 * ox], a1 = xa[2 * ox + 1];
+    const uint8_t *r0 = in + ((size_t)f * h + y0) * w * 3;
+    const uint8_t *r1 = in + ((size_t)f * h + y1) * w * 3;
+    uint8_t *o = out + gid * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int h0, h1;
+        if (ox < xmax) {
+            h0 = r0[sx * 3 + c] * a0 + r0[sx1 * 3 + c] * a1;
+            h1 = r1[sx * 3 + c] * a0 + r1[sx1 * 3 + c] * a1;
+        } else {
+            h0 = r0[sx * 3 + c] * 2048;
+            h1 = r1[sx * 3 + c] * 2048;
+        }
+        int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        o[c] = (uint8_t)min(max(v, 0), 255);
+    }
+}
+
+static void cv_linear_tab(int src, int dst, bool horizontal, int *ofs, int *a, int *xmax_out) {
+    double scale = (double)src / dst;
+    int xmax = dst;
+    for (int d = 0; d < dst; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        if (horizontal) {
+            if (s < 0) { f = 0.f; s = 0; }
+            if (s + 1 >= src) {
+                xmax = std::min(xmax, d);
+                if (s >= src - 1) { f = 0.f; s = src - 1; }
+            }
+        }
+        ofs[d] = s;
+        long w0 = lrintf((1.f - f) * 2048.f), w1 = lrintf(f * 2048.f);
+        a[2 * d] = (int)std::min(std::max(w0, -32768L), 32767L);
+        a[2 * d + 1] = (int)std::min(std::max(w1, -32768L), 32767L);
+    }
+    if (xmax_out) *xmax_out = xmax;
+}
+
+extern "C" int svc_resize_frames_u8(SvcHandle *h, const uint8_t *frames, int n, int height, int width,
+                                    uint8_t *out, int sh, int sw, void *stream) {
+    if (!h || !frames || !out || n < 0 || height < 1 || width < 1 || sh < 1 || sw < 1) {
+        svc_set_error("svc_resize_frames_u8: invalid argument");
+        return SVC_E_INVALID;
+    }
+    if (n == 0) return SVC_OK;
+    SVC_HIP(hipSetDevice(h->device));
+    auto key = std::make_tuple(height, width, sh, sw);
+    auto it = h->cvtabs.find(key);
+    if (it == h->cvtabs.end()) {
+        std::vector<int> tab(3 * sw + 3 * sh + 1);
+        int xmax = sw;
+        cv_linear_tab(width, sw, true, tab.data(), tab.data() + sw, &xmax);
+        cv_linear_tab(height, sh, false, tab.data() + 3 * sw, tab.data() + 3 * sw + sh, nullptr);
+        tab[3 * sw + 3 * sh] = xmax;
+        DevBuf buf;
+        int rc = buf.ensure(tab.size() * 4);
+        if (rc) return rc;
+        SVC_HIP(hipMemcpy(buf.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+        it = h->cvtabs.emplace(key, buf).first;
+    }
+    size_t total = (size_t)n * sh * sw;
+    k_cv_resize<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        frames, out, (const int *)it->second.p, n, height, width, sh, sw);
+    SVC_CHECK_LAUNCH();
+    return SVC_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// K0: Pillow LANCZOS (two 8-bit fixed-point passes) + /255 + normalise (via LUT) -> NHWC fp32
+// --------------------------------------------------------------------------------------
+#define LZ_PREC 22
+__global__ __launch_bounds__(256) void k_lanczos_norm(
+    const uint8_t *__restrict__ in, float *__restrict__ out, int h, int w, int NH, int NW,
+    const int *__restrict__ hb, const int *__restrict__ hk, int hks, const int *__restrict__ vb,
+    const int *__restrict__ vk, int vks, const float *__restrict__ lut, int rows_per_block, int tile_cap) {
+    extern __shared__ uint8_t tile[];          // [tile_cap][NW][3] horizontal-pass rows
+    const int f = blockIdx.y;
+    const int y0 = blockIdx.x * rows_per_block;
+    const int y1 = min(NH, y0 + rows_per_block);
+    const int r_lo = vb[2 * y0];
+    const int r_hi = vb[2 * (y1 - 1)] + vb[2 * (y1 - 1) + 1];
+    const int nr = min(r_hi - r_lo, tile_cap);
+    const uint8_t *src = in + (size_t)f * h * w * 3;
+    for (int idx = threadIdx.x; idx < nr * NW * 3; idx += 256) {
+        int c = idx % 3, x = (idx / 3) % NW, r = idx / (3 * NW);
+        int xmin = hb[2 * x], cnt = hb[2 * x + 1];
+        const uint8_t *p = src + ((size_t)(r_lo + r) * w + xmin) * 3 + c;
+        const int *k = hk + x * hks;
+        int acc = 1 << (LZ_PREC - 1);
+        for (int j = 0; j < cnt; ++j) acc += (int)p[j * 3] * k[j];
+        tile[idx] = (uint8_t)min(max(acc >> LZ_PREC, 0), 255);
+    }
+    __syncthreads();
+    float *dst = out + ((size_t)f * NH + y0) * NW * 3;
+    for (int idx = threadIdx.x; idx < (y1 - y0) * NW * 3; idx += 256) {
+        int c = idx % 3, x = (idx / 3) % NW, yy = idx / (3 * NW);
+        int y = y0 + yy;
+        int ymin = vb[2 * y], cnt = vb[2 * y + 1];
+        const int *k = vk + y * vks;
+        const uint8_t *p = tile + ((ymin - r_lo) * NW + x) * 3 + c;
+        int acc = 1 << (LZ_PREC - 1);
+        for (int j = 0; j < cnt; ++j) acc += (int)p[j * NW * 3] * k[j];
+        int v = min(max(acc >> LZ_PREC, 0), 255);
+        dst[idx] = lut[c * 256 + v];
+    }
+}
+
+static double lz_sinc(double x) {
+    if (x == 0.0) return 1.0;
+    x *= M_PI;
+    return sin(x) / x;
+}
+static double lz_filter(double x) { return (-3.0 <= x && x < 3.0) ? lz_sinc(x) * lz_sinc(x / 3.0) : 0.0; }
+
+// Pillow's precompute_coeffs + normalize_coeffs_8bpc.  Identity table when sizes match
+// (Pillow skips that pass).
+static void lanczos_tab(int in_size, int out_size, std::vector<int> &bounds, std::vector<int> &coef, int &ksize) {
+    bounds.assign(2 * out_size, 0);
+    if (in_size == out_size) {
+        ksize = 1;
+        coef.assign(out_size, 1 << LZ_PREC);
+        for (int i = 0; i < out_size; ++i) { bounds[2 * i] = i; bounds[2 * i + 1] = 1; }
+        return;
+    }
+    double scale = (double)in_size / out_size, filterscale = std::max(scale, 1.0);
+    double support = 3.0 * filterscale, ss = 1.0 / filterscale;
+    ksize = (int)ceil(support) * 2 + 1;
+    coef.assign((size_t)out_size * ksize, 0);
+    std::vector<double> k(ksize);
+    for (int xx = 0; xx < out_size; ++xx) {
+        double center = (xx + 0.5) * scale, ww = 0.0;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < xmax; ++x) {
+            k[x] = lz_filter((x + xmin - center + 0.5) * ss);
+            ww += k[x];
+        }
+        for (int x = 0; x < xmax; ++x) {
+            double v = (ww != 0.0) ? k[x] / ww : k[x];
+            coef[(size_t)xx * ksize + x] = v < 0 ? (int)(-0.5 + v * (1 << LZ_PREC)) : (int)(0.5 + v * (1 << LZ_PREC));
+        }
+        bounds[2 * xx] = xmin;
+        bounds[2 * xx + 1] = xmax;
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// stem: 3x3 stride 2 pad 1, 3 -> 32, +bias, ReLU6.  One thread = one pixel x 4 channels.
+// w layout [ky][kx][ci][co]
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stem(const float *__restrict__ X, const float *__restrict__ Wt,
+                                              const float *__restrict__ bias, float *__restrict__ Y, int n,
+                                              int H, int W, int OH, int OW) {
+    __shared__ float ws[27 * 32 + 32];
+    for (int i = threadIdx.x; i < 27 * 32; i += 256) ws[i] = Wt[i];
+    if (threadIdx.x < 32) ws[27 * 32 + threadIdx.x] = bias[threadIdx.x];
+    __syncthreads();
+    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t total = (size_t)n * OH * OW * 8;
+    if (gid >= total) return;
+    int c4 = gid & 7;
+    size_t pix = gid >> 3;
+    int ox = pix % OW, oy = (pix / OW) % OH, f = pix / ((size_t)OW * OH);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *xf = X + (size_t)f * H * W * 3;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        int iy = 2 * oy - 1 + ky;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            int ix = 2 * ox - 1 + kx;
+            if (ix < 0 || ix >= W) continue;
+            const float *px = xf + ((size_t)iy * W + ix) * 3;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                float v = px[ci];
+                const float *wp = ws + ((ky * 3 + kx) * 3 + ci) * 32 + c4 * 4;
+                acc.x = fmaf(v, wp[0], acc.x);
+                acc.y = fmaf(v, wp[1], acc.y);
+                acc.z = fmaf(v, wp[2], acc.z);
+                acc.w = fmaf(v, wp[3], acc.w);
+            }
+        }
+    }
+    const float *b = ws + 27 * 32 + c4 * 4;
+    acc.x = fminf(fmaxf(acc.x + b[0], 0.f), 6.f);
+    acc.y = fminf(fmaxf(acc.y + b[1], 0.f), 6.f);
+    acc.z = fminf(fmaxf(acc.z + b[2], 0.f), 6.f);
+    acc.w = fminf(fmaxf(acc.w + b[3], 0.f), 6.f);
+    *(float4 *)(Y + gid * 4) = acc;
+}
+
+// --------------------------------------------------------------------------------------
+// pointwise conv as a GEMM on the f32 MFMA:  Y[M,N] = act(X[M,K] * W[N,K]^T + b) (+ R)
+// Block = 4 waves; wave v owns rows m0+32v..+31 and TN column tiles of 32.
+// Lane l (r = l&31, hh = l>>5) feeds A[r][k] and B[k][r] with k = kk + 4*hh + s for the
+// s-th MFMA of an 8-deep K chunk: both operands come from one float4 per lane, read
+// straight from global memory (the k order inside a chunk is a consistent permutation).
+// --------------------------------------------------------------------------------------
+template <int TN>
+__global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx, const float *__restrict__ Wt,
+                                            const float *__restrict__ bias, const float *__restrict__ R, int ldr,
+                                            float *__restrict__ Y, int ldy, int M, int N, int Npad, int K,
+                                            int relu6) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int m0 = blockIdx.x * 128 + wave * 32;
+    const int n0 = blockIdx.y * (32 * TN);
+    if (m0 >= M) return;
+    const int row = min(m0 + r, M - 1);
+    const float *xp = X + (size_t)row * ldx + 4 * hh;
+    const float *wp[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        int col = min(n0 + t * 32 + r, Npad - 1);
+        wp[t] = Wt + (size_t)col * K + 4 * hh;
+    }
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll 2
+    for (int k = 0; k < K; k += 8) {
+        const float4 a = *(const float4 *)(xp + k);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const float4 b = *(const float4 *)(wp[t] + k);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int col = n0 + t * 32 + r;
+        if (col >= N) continue;
+        const float bv = bias[col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rr = m0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            if (rr < M) {
+                float v = acc[t][i] + bv;
+                if (R) v += R[(size_t)rr * ldr + col];
+                if (relu6) v = fminf(fmaxf(v, 0.f), 6.f);
+                Y[(size_t)rr * ldy + col] = v;
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// depthwise 3x3 pad 1, stride S, + bias, ReLU6.  NHWC, one thread = one pixel x 4 channels.
+// w layout [9][C]
+// --------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void k_dw(const float *__restrict__ X, const float *__restrict__ Wt,
+                                            const float *__restrict__ bias, float *__restrict__ Y, int n, int H,
+                                            int W, int C, int OH, int OW) {
+    const int C4 = C >> 2;
+    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t total = (size_t)n * OH * OW * C4;
+    if (gid >= total) return;
+    int c4 = gid % C4;
+    size_t pix = gid / C4;
+    int ox = pix % OW, oy = (pix / OW) % OH, f = pix / ((size_t)OW * OH);
+    const float *xf = X + (size_t)f * H * W * C + c4 * 4;
+    const float *wf = Wt + c4 * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        int iy = oy * S - 1 + ky;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            int ix = ox * S - 1 + kx;
+            if (ix < 0 || ix >= W) continue;
+            const float4 x = *(const float4 *)(xf + ((size_t)iy * W + ix) * C);
+            const float4 w = *(const float4 *)(wf + (ky * 3 + kx) * C);
+            acc.x = fmaf(x.x, w.x, acc.x);
+            acc.y = fmaf(x.y, w.y, acc.y);
+            acc.z = fmaf(x.z, w.z, acc.z);
+            acc.w = fmaf(x.w, w.w, acc.w);
+        }
+    }
+    const float4 b = *(const float4 *)(bias + c4 * 4);
+    acc.x = fminf(fmaxf(acc.x + b.x, 0.f), 6.f);
+    acc.y = fminf(fmaxf(acc.y + b.y, 0.f), 6.f);
+    acc.z = fminf(fmaxf(acc.z + b.z, 0.f), 6.f);
+    acc.w = fminf(fmaxf(acc.w + b.w, 0.f), 6.f);
+    *(float4 *)(Y + gid * 4) = acc;
+}
+
+__global__ __launch_bounds__(256) void k_subsample(const float *__restrict__ X, float *__restrict__ Y, int n, int H,
+                                                   int W, int C) {
+    const int C4 = C >> 2, OH = H >> 1, OW = W >> 1;
+    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t total = (size_t)n * OH * OW * C4;
+    if (gid >= total) return;
+    int c4 = gid % C4;
+    size_t pix = gid / C4;
+    int ox = pix % OW, oy = (pix / OW) % OH, f = pix / ((size_t)OW * OH);
+    *(float4 *)(Y + gid * 4) = *(const float4 *)(X + (((size_t)f * H + 2 * oy) * W + 2 * ox) * C + c4 * 4);
+}
+
+// Y[f][pos][c_off + j] = G[pos][j], j < 16
+__global__ __launch_bounds__(256) void k_gauss_fill(const float *__restrict__ G, float *__restrict__ Y, int n,
+                                                    int npos, int ldy, int c_off) {
+    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t total = (size_t)n * npos * 16;
+    if (gid >= total) return;
+    int j = gid & 15;
+    size_t fp = gid >> 4;
+    int pos = fp % npos;
+    Y[fp * ldy + c_off + j] = G[pos * 16 + j];
+}
+
+// bilinear x2 (align_corners=False): X[n][H][W][C] -> Y[n][2H][2W][ldy] channels 0..C-1
+__global__ __launch_bounds__(256) void k_upsample2x(const float *__restrict__ X, float *__restrict__ Y, int n,
+                                                    int H, int W, int C, int ldy) {
+    const int C4 = C >> 2, OH = 2 * H, OW = 2 * W;
+    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t total = (size_t)n * OH * OW * C4;
+    if (gid >= total) return;
+    int c4 = gid % C4;
+    size_t pix = gid / C4;
+    int ox = pix % OW, oy = (pix / OW) % OH, f = pix / ((size_t)OW * OH);
+    float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ox + 0.5f) - 0.5f, 0.f);
+    int y0 = (int)sy, x0 = (int)sx;
+    int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const float *xf = X + (size_t)f * H * W * C + c4 * 4;
+    const float4 v00 = *(const float4 *)(xf + ((size_t)y0 * W + x0) * C);
+    const float4 v01 = *(const float4 *)(xf + ((size_t)y0 * W + x1) * C);
+    const float4 v10 = *(const float4 *)(xf + ((size_t)y1 * W + x0) * C);
+    const float4 v11 = *(const float4 *)(xf + ((size_t)y1 * W + x1) * C);
+    float4 o;
+    o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+    o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+    o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+    o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+    *(float4 *)(Y + pix * ldy + c4 * 4) = o;
+}
+
+// adaptation: logit[p] = sum_c X[p][c] * w[c] + b, C = 64
+__global__ __launch_bounds__(256) void k_adapt(const float *__restrict__ X, const float *__restrict__ w,
+                                               const float *__restrict__ b, float *__restrict__ Y, size_t npix) {
+    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= npix) return;
+    const float4 *x = (const float4 *)(X + gid * 64);
+    const float4 *w4 = (const float4 *)w;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float4 a = x[i], c = w4[i];
+        s = fmaf(a.x, c.x, s);
+        s = fmaf(a.y, c.y, s);
+        s = fmaf(a.z, c.z, s);
+        s = fmaf(a.w, c.w, s);
+    }
+    Y[gid] = s + b[0];
+}
+
+__device__ __forceinline__ unsigned enc_f32(float v) {
+    unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f32(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+
+// nearest x8 -> replicate pad 20 -> 41x41 conv, evaluated as 64 phase kernels of 7x7
+// low-res taps, then bilinear (align_corners=False) down to (h, w).  One block = one
+// frame x rows_per_block output rows; the needed rows of the NHxNW map live in LDS.
+__global__ __launch_bounds__(256) void k_smooth_down(const float *__restrict__ logit, const float *__restrict__ phase,
+                                                     float *__restrict__ pre, unsigned *__restrict__ fmax, int LH,
+                                                     int LW, int NH, int NW, int h, int w, int rows_per_block,
+                                                     int tile_cap) {
+    extern __shared__ float sm[];
+    float *L = sm, *ph = sm + LH * LW, *tile = ph + 64 * 49;
+    __shared__ unsigned wmax[4];
+    const int f = blockIdx.y;
+    const int oy0 = blockIdx.x * rows_per_block, oy1 = min(h, oy0 + rows_per_block);
+    const float scy = (float)NH / (float)h, scx = (float)NW / (float)w;
+    const int ylo = (int)fmaxf(scy * (oy0 + 0.5f) - 0.5f, 0.f);
+    const int yhi = min((int)fmaxf(scy * ((oy1 - 1) + 0.5f) - 0.5f, 0.f) + 1, NH - 1);
+    const int nrows = min(yhi - ylo + 1, tile_cap);
+    for (int i = threadIdx.x; i < LH * LW; i += 256) L[i] = logit[(size_t)f * LH * LW + i];
+    for (int i = threadIdx.x; i < 64 * 49; i += 256) ph[i] = phase[i];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nrows * NW; idx += 256) {
+        int ry = idx / NW, x = idx - ry * NW;
+        int y = ylo + ry;
+        int cy = y >> 3, py = y & 7, cx = x >> 3, px = x & 7;
+        const float *p = ph + (py * 8 + px) * 49;
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 7; ++a) {
+            int yy = min(max(cy + a - 3, 0), LH - 1);
+#pragma unroll
+            for (int b = 0; b < 7; ++b) {
+                int xx = min(max(cx + b - 3, 0), LW - 1);
+                s = fmaf(p[a * 7 + b], L[yy * LW + xx], s);
+            }
+        }
+        tile[idx] = s;
+    }
+    __syncthreads();
+    float lmax = -INFINITY;
+    for (int idx = threadIdx.x; idx < (oy1 - oy0) * w; idx += 256) {
+        int oy = oy0 + idx / w, ox = idx % w;
+        float sy = fmaxf(scy * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(scx * (ox + 0.5f) - 0.5f, 0.f);
+        int y0 = (int)sy, x0 = (int)sx;
+        int y1 = y0 + (y0 < NH - 1 ? 1 : 0), x1 = x0 + (x0 < NW - 1 ? 1 : 0);
+        float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float *t0 = tile + (y0 - ylo) * NW, *t1 = tile + (y1 - ylo) * NW;
+        float v = ly0 * (lx0 * t0[x0] + lx1 * t0[x1]) + ly1 * (lx0 * t1[x0] + lx1 * t1[x1]);
+        pre[((size_t)f * h + oy) * w + ox] = v;
+        lmax = fmaxf(lmax, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = enc_f32(lmax);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(fmax + f, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+}
+
+// u8 = trunc(255 * exp(x - max x)): the softmax normaliser cancels in p / max p.
+__global__ __launch_bounds__(256) void k_quantise(const float *__restrict__ pre, const unsigned *__restrict__ fmax,
+                                                  uint8_t *__restrict__ out, int n, int hw) {
+    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t total = (size_t)n * hw;
+    if (gid >= total) return;
+    float m = dec_f32(fmax[gid / hw]);
+    float e = expf(pre[gid] - m);
+    out[gid] = (uint8_t)(e * 255.0f);
+}
+
+// --------------------------------------------------------------------------------------
+// plan / workspace
+// --------------------------------------------------------------------------------------
+enum Buf { B_IN, B_P0, B_P1, B_E0, B_E1, B_F4X, B_F2X, B_S4E, B_S2E, B_CAT1, B_PCD, B_PC, B_CAT2, B_U2E, B_U2D,
+           B_U2, B_CAT3, B_P3E, B_P3D, B_DEC, B_LOGIT, B_PRE, B_COUNT };
+
+struct NetPlan {
+    int h = 0, w = 0, NH = 0, NW = 0, nb = 0;
+    size_t off[B_COUNT + 1];      // per-frame float offsets
+    DevBuf ws, fmax, lut, gauss;
+    DevBuf hb, hk, vb, vk;
+    int hks = 0, vks = 0, lz_rows = 16, lz_tile_cap = 0;
+    int sd_rows = 14, sd_tile_cap = 0;
+    int last_n = 0;
+    float *buf(int b) const { return (float *)ws.p + off[b] * (size_t)nb; }
+    size_t per_frame(int b) const { return off[b + 1] - off[b]; }
+};
+
+static void optimal_out_size(int h, int w, int &NH, int &NW) {      // data.py:1086-1103
+    double ar = (double)h / w, best = -1.0;
+    int b1 = 8, b2 = 13;
+    for (int n1 = 7; n1 < 14; ++n1)
+        for (int n2 = 7; n2 < 14; ++n2)
+            if (n1 * n2 >= 100 && n1 * n2 <= 120) {
+                double t = (double)n1 / n2;
+                double ratio = std::min(ar, t) / std::max(ar, t);
+                if (ratio > best) { best = ratio; b1 = n1; b2 = n2; }
+            }
+    NH = b1 * 32;
+    NW = b2 * 32;
+}
+
+// torch.linspace(0, 1, steps) in float32 (symmetric evaluation around the midpoint)
+static void linspace01(int steps, std::vector<float> &v) {
+    v.resize(steps);
+    if (steps == 1) { v[0] = 0.f; return; }
+    float step = 1.0f / (float)(steps - 1);
+    int half = steps / 2;
+    for (int i = 0; i < steps; ++i) v[i] = (i < half) ? (0.f + step * i) : (1.f - step * (steps - 1 - i));
+}
+
+static int build_plan(SvcHandle *h, int height, int width, int nb) {
+    NetPlan *p = h->plan;
+    if (!p) p = h->plan = new NetPlan();
+    if (p->h == height && p->w == width && p->nb >= nb) return SVC_OK;
+    int NH, NW;
+    optimal_out_size(height, width, NH, NW);
+    const bool same_size = (p->h == height && p->w == width);
+    p->h = height; p->w = width; p->NH = NH; p->NW = NW; p->nb = nb;
+    const size_t H1 = NH / 2, W1 = NW / 2, H2 = NH / 4, W2 = NW / 4, H3 = NH / 8, W3 = NW / 8, H4 = NH / 16,
+                 W4 = NW / 16, H5 = NH / 32, W5 = NW / 32;
+    size_t sz[B_COUNT];
+    sz[B_IN] = (size_t)NH * NW * 3;
+    sz[B_P0] = sz[B_P1] = H1 * W1 * 32;
+    // expanded tensors: f2 expand at H1 (96 ch) is the largest
+    sz[B_E0] = std::max(std::max(H1 * W1 * 96, H2 * W2 * 144), std::max(H3 * W3 * 192, std::max(H4 * W4 * 576, H5 * W5 * 960)));
+    sz[B_E1] = std::max(std::max(H1 * W1 * 32, H2 * W2 * 144), std::max(H3 * W3 * 192, std::max(H4 * W4 * 576, H5 * W5 * 960)));
+    sz[B_F4X] = H3 * W3 * 64;  sz[B_F2X] = H4 * W4 * 160;
+    sz[B_S4E] = H3 * W3 * 128; sz[B_S2E] = H4 * W4 * 320;
+    sz[B_CAT1] = H5 * W5 * 1296; sz[B_PCD] = H5 * W5 * 1296; sz[B_PC] = H5 * W5 * 256;
+    sz[B_CAT2] = H4 * W4 * 384; sz[B_U2E] = H4 * W4 * 768; sz[B_U2D] = H4 * W4 * 768; sz[B_U2] = H4 * W4 * 128;
+    sz[B_CAT3] = H3 * W3 * 192; sz[B_P3E] = H3 * W3 * 384; sz[B_P3D] = H3 * W3 * 384; sz[B_DEC] = H3 * W3 * 64;
+    sz[B_LOGIT] = (H3 * W3 + 3) / 4 * 4;
+    sz[B_PRE] = ((size_t)height * width + 3) / 4 * 4;
+    p->off[0] = 0;
+    for (int b = 0; b < B_COUNT; ++b) p->off[b + 1] = p->off[b] + (sz[b] + 3) / 4 * 4;
+    int rc = p->ws.ensure(p->off[B_COUNT] * (size_t)nb * sizeof(float));
+    if (rc) return rc;
+    rc = p->fmax.ensure((size_t)nb * sizeof(unsigned));
+    if (rc) return rc;
+    if (same_size) return SVC_OK;
+    // resampling tables
+    std::vector<int> hb, hk, vb, vk;
+    lanczos_tab(width, NW, hb, hk, p->hks);
+    lanczos_tab(height, NH, vb, vk, p->vks);
+    int cap = 0;
+    for (int y0 = 0; y0 < NH; y0 += p->lz_rows) {
+        int y1 = std::min(NH, y0 + p->lz_rows);
+        cap = std::max(cap, vb[2 * (y1 - 1)] + vb[2 * (y1 - 1) + 1] - vb[2 * y0]);
+    }
+    p->lz_tile_cap = cap;
+    if ((rc = p->hb.ensure(hb.size() * 4)) || (rc = p->hk.ensure(hk.size() * 4)) || (rc = p->vb.ensure(vb.size() * 4)) ||
+        (rc = p->vk.ensure(vk.size() * 4)))
+        return rc;
+    SVC_HIP(hipMemcpy(p->hb.p, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    SVC_HIP(hipMemcpy(p->hk.p, hk.data(), hk.size() * 4, hipMemcpyHostToDevice));
+    SVC_HIP(hipMemcpy(p->vb.p, vb.data(), vb.size() * 4, hipMemcpyHostToDevice));
+    SVC_HIP(hipMemcpy(p->vk.p, vk.data(), vk.size() * 4, hipMemcpyHostToDevice));
+    // ToTensor (/255) + Normalize LUT, float32 arithmetic like torchvision
+    std::vector<float> lut(3 * 256);
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
+    for (int c = 0; c < 3; ++c)
+        for (int v = 0; v < 256; ++v) {
+            volatile float t = (float)v / 255.0f;
+            volatile float d = t - mean[c];
+            lut[c * 256 + v] = d / sd[c];
+        }
+    if ((rc = p->lut.ensure(lut.size() * 4))) return rc;
+    SVC_HIP(hipMemcpy(p->lut.p, lut.data(), lut.size() * 4, hipMemcpyHostToDevice));
+    // Gaussian prior maps [H5][W5][16]  (model.py:348-378, float32)
+    std::vector<float> ys, xs, g(H5 * W5 * 16);
+    linspace01((int)H5, ys);
+    linspace01((int)W5, xs);
+    for (int i = 0; i < 16; ++i) {
+        const float *gp = h->gauss_params.data() + i * 4;      // [y/x][mu/logstd]
+        float sy = expf(gp[1]), sx = expf(gp[3]);
+        for (size_t y = 0; y < H5; ++y)
+            for (size_t x = 0; x < W5; ++x) {
+                float dy = (ys[y] - gp[0]) / sy, dx = (xs[x] - gp[2]) / sx;
+                float m = 1.0f;
+                m *= expf(-(dy * dy) / 2.0f);
+                m *= expf(-(dx * dx) / 2.0f);
+                g[(y * W5 + x) * 16 + i] = m * 6.0f;
+            }
+    }
+    if ((rc = p->gauss.ensure(g.size() * 4))) return rc;
+    SVC_HIP(hipMemcpy(p->gauss.p, g.data(), g.size() * 4, hipMemcpyHostToDevice));
+    // tile rows for k_smooth_down
+    float scy = (float)NH / (float)height;
+    cap = 0;
+    for (int oy0 = 0; oy0 < height; oy0 += p->sd_rows) {
+        int oy1 = std::min(height, oy0 + p->sd_rows);
+        int ylo = (int)std::max(scy * (oy0 + 0.5f) - 0.5f, 0.f);
+        int yhi = std::min((int)std::max(scy * ((oy1 - 1) + 0.5f) - 0.5f, 0.f) + 1, NH - 1);
+        cap = std::max(cap, yhi - ylo + 1);
+    }
+    p->sd_tile_cap = cap;
+    return SVC_OK;
+}
+
+int svc_net_release(SvcHandle *h) {
+    if (h->plan) {
+        NetPlan *p = h->plan;
+        p->ws.release(); p->fmax.release(); p->lut.release(); p->gauss.release();
+        p->hb.release(); p->hk.release(); p->vb.release(); p->vk.release();
+        delete p;
+        h->plan = nullptr;
+    }
+    for (auto &kv : h->cvtabs) kv.second.release();
+    h->cvtabs.clear();
+    return SVC_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// launch helpers
+// --------------------------------------------------------------------------------------
+static inline unsigned blocks256(size_t total) { return (unsigned)((total + 255) / 256); }
+
+static int launch_pw(hipStream_t s, const float *X, int ldx, const SvcLayer &L, const float *R, int ldr, float *Y,
+                     int ldy, int M) {
+    const int N = L.cout, K = L.cin, Npad = (N + 31) / 32 * 32, tiles = Npad / 32;
+    const int rb = ceil_div(M, 128);
+    int TN = 4;
+    while (TN > 1 && (TN > tiles || rb * ceil_div(tiles, TN) < 512)) --TN;
+    dim3 grid(rb, ceil_div(tiles, TN));
+#define PW_ARGS X, ldx, L.w.dev, L.b.dev, R, ldr, Y, ldy, M, N, Npad, K, L.relu6
+    switch (TN) {
+        case 4: k_pw<4><<<grid, 256, 0, s>>>(PW_ARGS); break;
+        case 3: k_pw<3><<<grid, 256, 0, s>>>(PW_ARGS); break;
+        case 2: k_pw<2><<<grid, 256, 0, s>>>(PW_ARGS); break;
+        default: k_pw<1><<<grid, 256, 0, s>>>(PW_ARGS); break;
+    }
+#undef PW_ARGS
+    SVC_CHECK_LAUNCH();
+    return SVC_OK;
+}
+
+static int launch_dw(hipStream_t s, const float *X, const SvcLayer &L, float *Y, int n, int H, int W, int stride) {
+    const int C = L.cout, OH = stride == 2 ? H / 2 : H, OW = stride == 2 ? W / 2 : W;
+    size_t total = (size_t)n * OH * OW * (C / 4);
+    if (stride == 2)
+        k_dw<2><<<blocks256(total), 256, 0, s>>>(X, L.w.dev, L.b.dev, Y, n, H, W, C, OH, OW);
+    else
+        k_dw<1><<<blocks256(total), 256, 0, s>>>(X, L.w.dev, L.b.dev, Y, n, H, W, C, OH, OW);
+    SVC_CHECK_LAUNCH();
+    return SVC_OK;
+}
+
+#define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+// One pass of the network over n <= plan->nb frames.
+static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *maps, hipStream_t s) {
+    NetPlan *p = h->plan;
+    const int NH = p->NH, NW = p->NW;
+    int H = NH / 2, W = NW / 2;
+    size_t li = 0;
+    auto next = [&]() -> const SvcLayer & { return h->layers[li++]; };
+    float *IN = p->buf(B_IN), *P[2] = {p->buf(B_P0), p->buf(B_P1)}, *E0 = p->buf(B_E0), *E1 = p->buf(B_E1);
+    // K0
+    {
+        dim3 grid(ceil_div(NH, p->lz_rows), n);
+        size_t lds = (size_t)p->lz_tile_cap * NW * 3;
+        k_lanczos_norm<<<grid, 256, lds, s>>>(frames, IN, p->h, p->w, NH, NW, (const int *)p->hb.p, (const int *)p->hk.p,
+                                             p->hks, (const int *)p->vb.p, (const int *)p->vk.p, p->vks,
+                                             (const float *)p->lut.p, p->lz_rows, p->lz_tile_cap);
+        SVC_CHECK_LAUNCH();
+    }
+    // stem
+    {
+        const SvcLayer &L = next();
+        k_stem<<<blocks256((size_t)n * H * W * 8), 256, 0, s>>>(IN, L.w.dev, L.b.dev, P[0], n, NH, NW, H, W);
+        SVC_CHECK_LAUNCH();
+    }
+    int cur = 0;
+    // backbone blocks 1..17  (MobileNetV2.py:111-136)
+    static const int T[7] = {1, 6, 6, 6, 6, 6, 6}, Cc[7] = {16, 24, 32, 64, 96, 160, 320}, Nn[7] = {1, 2, 3, 4, 3, 3, 1},
+                     Ss[7] = {1, 2, 2, 2, 1, 2, 1};
+    int idx = 1, inp = 32;
+    for (int st = 0; st < 7; ++st)
+        for (int i = 0; i < Nn[st]; ++i, ++idx) {
+            const int oup = Cc[st], stride = (i == 0) ? Ss[st] : 1, t = T[st];
+            const bool res = (stride == 1 && inp == oup);
+            const bool tap = (idx == 7 || idx == 14);             // full-resolution output feeds a skip
+            const int dws = (stride == 2 && !tap) ? 2 : 1;        // stride-2 dw == stride-1 dw + ::2 sub-sampling
+            const float *x = P[cur];
+            const float *dwin = x;
+            if (t != 1) {
+                RC(launch_pw(s, x, inp, next(), nullptr, 0, E0, inp * t, n * H * W));
+                dwin = E0;
+            }
+            const SvcLayer &Ld = next();
+            RC(launch_dw(s, dwin, Ld, E1, n, H, W, dws));
+            int OH = H / dws, OW = W / dws;
+            float *y = tap ? p->buf(idx == 7 ? B_F4X : B_F2X) : P[cur ^ 1];
+            RC(launch_pw(s, E1, inp * t, next(), res ? x : nullptr, oup, y, oup, n * OH * OW));
+            if (tap) {
+                k_subsample<<<blocks256((size_t)n * (OH / 2) * (OW / 2) * (oup / 4)), 256, 0, s>>>(y, P[cur ^ 1], n, OH,
+                                                                                                  OW, oup);
+                SVC_CHECK_LAUNCH();
+                OH /= 2; OW /= 2;
+            }
+            H = OH; W = OW;
+            cur ^= 1;
+            inp = oup;
+        }
+    // features.18 -> CAT1[:, 0:1280], Gaussian maps -> CAT1[:, 1280:1296]
+    const int H5 = H, W5 = W, H4 = 2 * H5, W4 = 2 * W5, H3 = 4 * H5, W3 = 4 * W5;
+    float *CAT1 = p->buf(B_CAT1);
+    RC(launch_pw(s, P[cur], 320, next(), nullptr, 0, CAT1, 1296, n * H5 * W5));
+    // skips (model.py:443-444)
+    float *CAT2 = p->buf(B_CAT2), *CAT3 = p->buf(B_CAT3);
+    RC(launch_pw(s, p->buf(B_F2X), 160, next(), nullptr, 0, p->buf(B_S2E), 320, n * H4 * W4));
+    RC(launch_pw(s, p->buf(B_S2E), 320, next(), nullptr, 0, CAT2 + 256, 384, n * H4 * W4));
+    RC(launch_pw(s, p->buf(B_F4X), 64, next(), nullptr, 0, p->buf(B_S4E), 128, n * H3 * W3));
+    RC(launch_pw(s, p->buf(B_S4E), 128, next(), nullptr, 0, CAT3 + 128, 192, n * H3 * W3));
+    next();   // GAUSS placeholder layer (raw parameters; maps live in plan->gauss)
+    k_gauss_fill<<<blocks256((size_t)n * H5 * W5 * 16), 256, 0, s>>>((const float *)p->gauss.p, CAT1, n, H5 * W5, 1296,
+                                                                     1280);
+    SVC_CHECK_LAUNCH();
+    // post_cnn
+    RC(launch_dw(s, CAT1, next(), p->buf(B_PCD), n, H5, W5, 1));
+    RC(launch_pw(s, p->buf(B_PCD), 1296, next(), nullptr, 0, p->buf(B_PC), 256, n * H5 * W5));
+    // US1 + concat, US2 block
+    k_upsample2x<<<blocks256((size_t)n * H4 * W4 * 64), 256, 0, s>>>(p->buf(B_PC), CAT2, n, H5, W5, 256, 384);
+    SVC_CHECK_LAUNCH();
+    RC(launch_pw(s, CAT2, 384, next(), nullptr, 0, p->buf(B_U2E), 768, n * H4 * W4));
+    RC(launch_dw(s, p->buf(B_U2E), next(), p->buf(B_U2D), n, H4, W4, 1));
+    RC(launch_pw(s, p->buf(B_U2D), 768, next(), nullptr, 0, p->buf(B_U2), 128, n * H4 * W4));
+    k_upsample2x<<<blocks256((size_t)n * H3 * W3 * 32), 256, 0, s>>>(p->buf(B_U2), CAT3, n, H4, W4, 128, 192);
+    SVC_CHECK_LAUNCH();
+    RC(launch_pw(s, CAT3, 192, next(), nullptr, 0, p->buf(B_P3E), 384, n * H3 * W3));
+    RC(launch_dw(s, p->buf(B_P3E), next(), p->buf(B_P3D), n, H3, W3, 1));
+    RC(launch_pw(s, p->buf(B_P3D), 384, next(), nullptr, 0, p->buf(B_DEC), 64, n * H3 * W3));
+    // adaptation, smoothing, resize, quantise
+    const SvcLayer &La = next();
+    k_adapt<<<blocks256((size_t)n * H3 * W3), 256, 0, s>>>(p->buf(B_DEC), La.w.dev, La.b.dev, p->buf(B_LOGIT),
+                                                          (size_t)n * H3 * W3);
+    SVC_CHECK_LAUNCH();
+    // B_LOGIT per-frame stride may exceed H3*W3 (rounded to 4): compact layout is used instead
+    const SvcLayer &Ls = next();
+    SVC_HIP(hipMemsetAsync(p->fmax.p, 0, (size_t)n * sizeof(unsigned), s));
+    {
+        dim3 grid(ceil_div(p->h, p->sd_rows), n);
+        size_t lds = ((size_t)H3 * W3 + 64 * 49 + (size_t)p->sd_tile_cap * NW) * sizeof(float);
+        k_smooth_down<<<grid, 256, lds, s>>>(p->buf(B_LOGIT), Ls.w.dev, p->buf(B_PRE), (unsigned *)p->fmax.p, H3, W3, NH,
+                                             NW, p->h, p->w, p->sd_rows, p->sd_tile_cap);
+        SVC_CHECK_LAUNCH();
+    }
+    k_quantise<<<blocks256((size_t)n * p->h * p->w), 256, 0, s>>>(p->buf(B_PRE), (const unsigned *)p->fmax.p, maps, n,
+                                                                 p->h * p->w);
+    SVC_CHECK_LAUNCH();
+    p->last_n = n;
+    return SVC_OK;
+}
+
+extern "C" int svc_saliency_u8(SvcHandle *h, const uint8_t *frames, int n, int height, int width, uint8_t *maps,
+                               void *stream) {
+    if (!h || !frames || !maps || n < 0 || height < 8 || width < 8) {
+        svc_set_error("svc_saliency_u8: invalid argument");
+        return SVC_E_INVALID;
+    }
+    if (n == 0) return SVC_OK;
+    SVC_HIP(hipSetDevice(h->device));
+    const int nb = std::min(n, h->chunk);
+    RC(build_plan(h, height, width, nb));
+    const size_t fin = (size_t)height * width * 3, fout = (size_t)height * width;
+    for (int i = 0; i < n; i += h->plan->nb) {
+        int m = std::min(h->plan->nb, n - i);
+        RC(forward_chunk(h, frames + i * fin, m, maps + i * fout, (hipStream_t)stream));
+    }
+    return SVC_OK;
+}
+
+extern "C" int svc_debug_tap(SvcHandle *h, int which, int frame, float *out_host, size_t cap_floats) {
+    if (!h || !h->plan || !out_host) { svc_set_error("svc_debug_tap: no forward pass has run"); return SVC_E_INVALID; }
+    NetPlan *p = h->plan;
+    static const int map[7] = {B_IN, B_F4X, B_F2X, B_CAT1, B_PC, B_DEC, B_PRE};
+    if (which < 0 || which > 6 || frame < 0 || frame >= p->last_n) { svc_set_error("svc_debug_tap: bad tap/frame"); return SVC_E_INVALID; }
+    const int NH = p->NH, NW = p->NW;
+    size_t count;
+    switch (which) {
+        case SVC_TAP_INPUT: count = (size_t)NH * NW * 3; break;
+        case SVC_TAP_FEAT4X: count = (size_t)(NH / 8) * (NW / 8) * 64; break;
+        case SVC_TAP_FEAT2X: count = (size_t)(NH / 16) * (NW / 16) * 160; break;
+        case SVC_TAP_FEAT1X: count = (size_t)(NH / 32) * (NW / 32) * 1296; break;
+        case SVC_TAP_POSTCNN: count = (size_t)(NH / 32) * (NW / 32) * 256; break;
+        case SVC_TAP_DEC: count = (size_t)(NH / 8) * (NW / 8) * 64; break;
+        default: count = (size_t)p->h * p->w; break;
+    }
+    if (count > cap_floats) { svc_set_error("svc_debug_tap: buffer too small (%zu needed)", count); return SVC_E_INVALID; }
+    SVC_HIP(hipSetDevice(h->device));
+    SVC_HIP(hipDeviceSynchronize());
+    SVC_HIP(hipMemcpy(out_host, p->buf(map[which]) + (size_t)frame * count, count * sizeof(float), hipMemcpyDeviceToHost));
+    return (int)count;
+}
+
+// --------------------------------------------------------------------------------------
+// create / destroy
+// --------------------------------------------------------------------------------------
+static const uint64_t BLOB_MAGIC = 0x53564331ull;
+
+static int take(SvcHandle *h, size_t &ti, size_t expect, SvcTensor &out, const char *what) {
+    if (ti >= h->tensors.size()) { svc_set_error("blob: ran out of tensors at %s", what); return SVC_E_BLOB; }
+    if (h->tensors[ti].n != expect) {
+        svc_set_error("blob: tensor %zu (%s) has %zu floats, expected %zu", ti, what, h->tensors[ti].n, expect);
+        return SVC_E_BLOB;
+    }
+    out = h->tensors[ti++];
+    return SVC_OK;
+}
+
+static int add_pw(SvcHandle *h, size_t &ti, int cin, int cout, int relu6, const char *what) {
+    SvcLayer L{SvcLayer::PW, cin, cout, 1, relu6, {}, {}};
+    const size_t npad = (cout + 31) / 32 * 32;
+    RC(take(h, ti, npad * cin, L.w, what));
+    RC(take(h, ti, (size_t)cout, L.b, what));
+    h->layers.push_back(L);
+    return SVC_OK;
+}
+static int add_dw(SvcHandle *h, size_t &ti, int c, int stride, const char *what) {
+    SvcLayer L{SvcLayer::DW, c, c, stride, 1, {}, {}};
+    RC(take(h, ti, (size_t)9 * c, L.w, what));
+    RC(take(h, ti, (size_t)c, L.b, what));
+    h->layers.push_back(L);
+    return SVC_OK;
+}
+static int add_inv_res(SvcHandle *h, size_t &ti, int inp, int oup, int t, int stride, const char *what) {
+    if (t != 1) RC(add_pw(h, ti, inp, inp * t, 1, what));
+    RC(add_dw(h, ti, inp * t, stride, what));
+    RC(add_pw(h, ti, inp * t, oup, 0, what));
+    return SVC_OK;
+}
+
+extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, SvcHandle **out) {
+    if (!blob_host || !out || n_bytes < 16) { svc_set_error("svc_create: invalid argument"); return SVC_E_INVALID; }
+    const uint64_t *hd = (const uint64_t *)blob_host;
+    if (hd[0] != BLOB_MAGIC) { svc_set_error("svc_create: bad blob magic"); return SVC_E_BLOB; }
+    const size_t nt = hd[1];
+    if (16 + 16 * nt > n_bytes) { svc_set_error("svc_create: truncated blob header"); return SVC_E_BLOB; }
+    int ndev = 0;
+    SVC_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) { svc_set_error("svc_create: device %d of %d", device, ndev); return SVC_E_INVALID; }
+    SVC_HIP(hipSetDevice(device));
+    SvcHandle *h = new SvcHandle();
+    h->device = device;
+    const char *env = getenv("SVC_CHUNK");
+    if (env && atoi(env) > 0) h->chunk = atoi(env);
+    int rc = h->blob.ensure(n_bytes);
+    if (rc) { delete h; return rc; }
+    if (hipMemcpy(h->blob.p, blob_host, n_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        svc_set_error("svc_create: blob upload failed");
+        h->blob.release(); delete h;
+        return SVC_E_HIP;
+    }
+    for (size_t i = 0; i < nt; ++i) {
+        uint64_t off = hd[2 + 2 * i], cnt = hd[3 + 2 * i];
+        if ((off + cnt) * 4 > n_bytes) { svc_set_error("svc_create: tensor %zu out of range", i); svc_destroy(h); return SVC_E_BLOB; }
+        h->tensors.push_back(SvcTensor{(const float *)h->blob.p + off, (size_t)cnt});
+    }
+    // walk the fixed graph (same order as retargetvid_amd.weights.fold_state_dict)
+    size_t ti = 0;
+    auto fail = [&](int code) { svc_destroy(h); return code; };
+    {
+        SvcLayer L{SvcLayer::STEM, 3, 32, 2, 1, {}, {}};
+        if ((rc = take(h, ti, 27 * 32, L.w, "stem.w")) || (rc = take(h, ti, 32, L.b, "stem.b"))) return fail(rc);
+        h->layers.push_back(L);
+    }
+    static const int T[7] = {1, 6, 6, 6, 6, 6, 6}, Cc[7] = {16, 24, 32, 64, 96, 160, 320}, Nn[7] = {1, 2, 3, 4, 3, 3, 1},
+                     Ss[7] = {1, 2, 2, 2, 1, 2, 1};
+    int inp = 32;
+    for (int st = 0; st < 7; ++st)
+        for (int i = 0; i < Nn[st]; ++i) {
+            if ((rc = add_inv_res(h, ti, inp, Cc[st], T[st], i == 0 ? Ss[st] : 1, "backbone"))) return fail(rc);
+            inp = Cc[st];
+        }
+    if ((rc = add_pw(h, ti, 320, 1280, 1, "features.18"))) return fail(rc);
+    if ((rc = add_pw(h, ti, 160, 320, 1, "skip_2x.expansion")) || (rc = add_pw(h, ti, 320, 128, 0, "skip_2x.reduction")) ||
+        (rc = add_pw(h, ti, 64, 128, 1, "skip_4x.expansion")) || (rc = add_pw(h, ti, 128, 64, 0, "skip_4x.reduction")))
+        return fail(rc);
+    {
+        SvcLayer L{SvcLayer::GAUSS, 16, 16, 1, 0, {}, {}};
+        if ((rc = take(h, ti, 64, L.w, "gaussians"))) return fail(rc);
+        h->layers.push_back(L);
+        h->gauss_params.resize(64);
+        const uint8_t *base = (const uint8_t *)blob_host;
+        memcpy(h->gauss_params.data(), base + ((const uint8_t *)L.w.dev - (const uint8_t *)h->blob.p), 64 * 4);
+    }
+    if ((rc = add_inv_res(h, ti, 1296, 256, 1, 1, "post_cnn")) || (rc = add_inv_res(h, ti, 384, 128, 2, 1, "upsampling_2")) ||
+        (rc = add_inv_res(h, ti, 192, 64, 2, 1, "post_upsampling_2")))
+        return fail(rc);
+    {
+        SvcLayer L{SvcLayer::ADAPT, 64, 1, 1, 0, {}, {}};
+        if ((rc = take(h, ti, 64, L.w, "adaptation.w")) || (rc = take(h, ti, 1, L.b, "adaptation.b"))) return fail(rc);
+        h->layers.push_back(L);
+        SvcLayer S{SvcLayer::SMOOTH, 1, 1, 1, 0, {}, {}};
+        if ((rc = take(h, ti, 64 * 49, S.w, "smoothing phase table"))) return fail(rc);
+        h->layers.push_back(S);
+    }
+    if (ti != h->tensors.size()) { svc_set_error("svc_create: %zu unused tensors in blob", h->tensors.size() - ti); return fail(SVC_E_BLOB); }
+    *out = h;
+    return SVC_OK;
+}
+
+extern "C" int svc_destroy(SvcHandle *h) {
+    if (!h) return SVC_OK;
+    (void)hipSetDevice(h->device);
+    svc_net_release(h);
+    h->tail_ws.release();
+    h->tail_offsets.release();
+    h->blob.release();
+    delete h;
+    return SVC_OK;
+}

@@ -1,0 +1,718 @@
+// svc_tail.hip — per-pixel tail of the SmartVidCrop hot path for gfx950:
+// threshold, cut blend, filtering-through-clustering (HDBSCAN*), grey CLOSE 5x5,
+// centre of focus, IoU.  Integer / byte work: results are bit-identical to the CPU
+// oracle (oracle/tail_ref.py, oracle/hdbscan_ref.py).
+//
+// One workgroup of 1024 threads (16 wavefronts of 64) owns one saliency map; maps are
+// independent except for the cut blend, which is handled by running the kernels in
+// "rounds" (a map blended from its predecessor runs one round later).
+//
+// Reference semantics (paths relative to the reference tree):
+//   k_threshold   sc_threshold                      smartVidCrop.py:1050-1059
+//   k_blend       cut-adjacent blend, u8 wrap        smartVidCrop.py:2369-2373
+//   k_compact     coo_matrix gather, raster order    smartVidCrop.py:1089-1091
+//   k_core        HDBSCAN core distances  \
+//   k_prim        Prim on mutual reachability } hdbscan generic path, call site smartVidCrop.py:1099
+//   k_finish      sort, hierarchy, EOM, labels /    + cluster weights / first arg-max / zeroing
+//                 (smartVidCrop.py:1107-1122), CLOSE 5x5 (:1126-1128), centroid (:1163-1219)
+//   k_iou         bb_intersection_over_union         smartVidCrop.py:927-944
+#include <math.h>
+
+#include <algorithm>
+
+#include "hdb_tree.h"
+#include "svc_internal.h"
+
+#define TB 1024                 // threads per frame workgroup
+#define NW16 (TB / 64)          // wavefronts per workgroup
+#define RING_R 40               // ring-walk radius for core distances
+#define REACH_INF 0x1FFFFu      // > any squared distance on a <=256x256 grid (17 bits)
+
+// --------------------------------------------------------------------------------------
+// per-frame workspace layout (all offsets in bytes from the frame base)
+// --------------------------------------------------------------------------------------
+struct FrameWS {
+    uint32_t hdr;        // int32[16]: [0]=N  [1]=nsel  [2]=kept cluster  [3]=clustered flag
+    uint32_t pts;        // u32[cap]   row | col<<8 | value<<16
+    uint32_t core;       // u32[cap]
+    uint32_t mst;        // Edge[cap]  Prim order
+    uint32_t ea, eb;     // Edge[cap]  radix ping-pong (ea = sorted result)
+    uint32_t labels;     // i32[cap]
+    uint32_t reach;      // u32[cap]   (generic large-N Prim only)
+    uint32_t sp, ssz, absc, absw, sdn, dparent;
+    uint32_t cup, ctp, cleft, cright, cbirthw, cminw, csize, ccnt, cdn, csplit, cacc, csel, crep, cweight;
+    uint32_t total;
+};
+
+static FrameWS make_layout(int cap, int mc) {
+    FrameWS L;
+    uint32_t o = 0;
+    auto take = [&](size_t bytes) { uint32_t r = o; o += (uint32_t)((bytes + 63) / 64 * 64); return r; };
+    L.hdr = take(64);
+    L.pts = take(4u * cap); L.core = take(4u * cap);
+    L.mst = take(8u * cap); L.ea = take(8u * cap); L.eb = take(8u * cap);
+    L.labels = take(4u * cap); L.reach = take(4u * cap);
+    L.sp = take(2u * cap); L.ssz = take(2u * cap); L.absc = take(2u * cap); L.absw = take(4u * cap);
+    L.sdn = take(4u * cap); L.dparent = take(8u * cap);
+    L.cup = take(2u * mc); L.ctp = take(4u * mc); L.cleft = take(4u * mc); L.cright = take(4u * mc);
+    L.cbirthw = take(4u * mc); L.cminw = take(4u * mc); L.csize = take(4u * mc); L.ccnt = take(4u * mc);
+    L.cdn = take(4u * mc); L.csplit = take(4u * mc); L.cacc = take(8u * mc); L.csel = take(1u * mc);
+    L.crep = take(4u * mc); L.cweight = take(4u * mc);
+    L.total = o;
+    return L;
+}
+
+struct TailArgs {
+    uint8_t *maps;          // [n][h][w]
+    uint8_t *ws;            // per-frame workspace
+    size_t ws_stride;
+    const uint8_t *depth;   // [n] round in which each frame runs
+    int round;
+    int n, h, w;
+    int mcs, min_samples, select_sum, op_close, clust_filt;
+    const uint32_t *ring;   // sorted neighbour offsets
+    int n_ring;
+    double *xy;
+    int32_t *stats;
+    FrameWS L;
+};
+
+// --------------------------------------------------------------------------------------
+// small device helpers
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long t = __shfl_xor(v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// exclusive prefix sum of one int per thread over the 1024-thread block; total in *tot
+__device__ __forceinline__ int block_excl_scan(int v, int *lds16, int *tot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) lds16[wave] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < NW16; ++i) {
+        int c = lds16[i];
+        if (i < wave) base += c;
+        total += c;
+    }
+    __syncthreads();
+    *tot = total;
+    return base + inc - v;
+}
+
+// --------------------------------------------------------------------------------------
+// threshold / blend / IoU
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_threshold(uint8_t *maps, size_t n, int t) {
+    size_t i16 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i16 >= n) return;
+    if (i16 + 16 <= n && (((uintptr_t)(maps + i16)) & 15) == 0) {
+        uint4 v = *(uint4 *)(maps + i16);
+        uint32_t *p = (uint32_t *)&v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t x = p[j], r = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                uint32_t c = (x >> (8 * b)) & 255u;
+                r |= ((int)c < t ? 0u : c) << (8 * b);
+            }
+            p[j] = r;
+        }
+        *(uint4 *)(maps + i16) = v;
+    } else {
+        for (size_t i = i16; i < n && i < i16 + 16; ++i) maps[i] = maps[i] < t ? 0 : maps[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_blend(uint8_t *maps, const uint8_t *depth, int round, int hw) {
+    const int f = blockIdx.y;
+    if (depth[f] != round) return;
+    uint8_t *cur = maps + (size_t)f * hw;
+    const uint8_t *prev = cur - hw;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256)
+        cur[i] = (uint8_t)(((cur[i] + prev[i]) & 255) >> 1);
+}
+
+__global__ __launch_bounds__(256) void k_iou(const int4 *__restrict__ a, const int4 *__restrict__ b, size_t n,
+                                             double *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int4 A = a[i], B = b[i];
+    long long xa = max(A.x, B.x), ya = max(A.y, B.y), xb = min(A.z, B.z), yb = min(A.w, B.w);
+    long long inter = max(0LL, xb - xa + 1) * max(0LL, yb - ya + 1);
+    long long aa = (long long)(A.z - A.x + 1) * (A.w - A.y + 1), ab = (long long)(B.z - B.x + 1) * (B.w - B.y + 1);
+    out[i] = (double)inter / (double)(aa + ab - inter);
+}
+
+// --------------------------------------------------------------------------------------
+// k_compact: non-zero pixels in raster order
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TB) void k_compact(TailArgs A) {
+    const int f = blockIdx.x;
+    if (A.depth[f] != A.round) return;
+    __shared__ int lds16[NW16];
+    const int hw = A.h * A.w;
+    const uint8_t *map = A.maps + (size_t)f * hw;
+    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
+    uint32_t *pts = (uint32_t *)(ws + A.L.pts);
+    int32_t *hdr = (int32_t *)(ws + A.L.hdr);
+    const int per = (hw + TB - 1) / TB;
+    const int lo = min(hw, (int)threadIdx.x * per), hi = min(hw, lo + per);
+    int cnt = 0;
+    for (int i = lo; i < hi; ++i) cnt += map[i] != 0;
+    int total;
+    int pos = block_excl_scan(cnt, lds16, &total);
+    for (int i = lo; i < hi; ++i) {
+        uint32_t v = map[i];
+        if (v) {
+            uint32_t r = i / A.w, c = i - r * A.w;
+            pts[pos++] = r | (c << 8) | (v << 16);
+        }
+    }
+    if (threadIdx.x == 0) {
+        hdr[0] = total;
+        hdr[1] = 0;
+        hdr[2] = -1;
+        hdr[3] = (A.clust_filt && total > A.mcs + 1) ? 1 : 0;
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// k_core: squared distance to the k-th nearest other point.  Each thread walks the
+// neighbour offsets of its point in increasing distance over the occupancy map held
+// in LDS; points with fewer than k neighbours inside RING_R fall back to a wave-wide
+// bisection over all points.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TB) void k_core(TailArgs A) {
+    const int f = blockIdx.x;
+    if (A.depth[f] != A.round) return;
+    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
+    const int32_t *hdr = (const int32_t *)(ws + A.L.hdr);
+    if (!hdr[3]) return;
+    const int N = hdr[0];
+    extern __shared__ uint8_t sm_core[];
+    const int hw = A.h * A.w;
+    uint8_t *occ = sm_core;                                   // [hw]
+    uint32_t *ring = (uint32_t *)(sm_core + (hw + 15) / 16 * 16);   // [n_ring]
+    __shared__ int n_fb;
+    const uint8_t *map = A.maps + (size_t)f * hw;
+    for (int i = threadIdx.x; i < hw; i += TB) occ[i] = map[i];
+    for (int i = threadIdx.x; i < A.n_ring; i += TB) ring[i] = A.ring[i];
+    if (threadIdx.x == 0) n_fb = 0;
+    __syncthreads();
+    const uint32_t *pts = (const uint32_t *)(ws + A.L.pts);
+    uint32_t *core = (uint32_t *)(ws + A.L.core);
+    int32_t *fb = (int32_t *)(ws + A.L.labels);               // scratch list of fallback points
+    int k = A.min_samples > 0 ? A.min_samples : A.mcs;
+    k = min(N - 1, k);
+    if (k == 0) k = 1;
+    for (int p = threadIdx.x; p < N; p += TB) {
+        const uint32_t v = pts[p];
+        const int r = v & 255, c = (v >> 8) & 255;
+        int cnt = 0;
+        uint32_t res = 0xFFFFFFFFu;
+        for (int i = 0; i < A.n_ring; ++i) {
+            const uint32_t o = ring[i];
+            const int rr = r + (int)(o & 255) - 128, cc = c + (int)((o >> 8) & 255) - 128;
+            if ((unsigned)rr < (unsigned)A.h && (unsigned)cc < (unsigned)A.w && occ[rr * A.w + cc]) {
+                if (++cnt == k) { res = o >> 16; break; }
+            }
+        }
+        core[p] = res;
+        if (res == 0xFFFFFFFFu) fb[atomicAdd(&n_fb, 1)] = p;
+    }
+    __syncthreads();
+    const int nf = n_fb;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t maxd = (uint32_t)((A.h - 1) * (A.h - 1) + (A.w - 1) * (A.w - 1));
+    for (int q = wave; q < nf; q += NW16) {
+        const int p = fb[q];
+        const uint32_t v = pts[p];
+        const int r = v & 255, c = (v >> 8) & 255;
+        uint32_t lo = 1, hi = maxd;                            // smallest t with #{d2 <= t} >= k+1 (self included)
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            int cnt = 0;
+            for (int j = lane; j < N; j += 64) {
+                const uint32_t u = pts[j];
+                const int dr = (int)(u & 255) - r, dc = (int)((u >> 8) & 255) - c;
+                cnt += (uint32_t)(dr * dr + dc * dc) <= mid;
+            }
+            cnt = wave_sum_i32(cnt);
+            if (cnt >= k + 1) hi = mid; else lo = mid + 1;
+        }
+        if (lane == 0) core[p] = lo;
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// k_prim: the library's Prim over the mutual-reachability graph, start node 0, lowest
+// index wins ties, edge = (last added node, new node, weight).  Each thread keeps the
+// running reachability and core distance of PT points in registers; coordinates live
+// in LDS; one 64-bit min-reduction (reach | index | core) per step, one barrier per step.
+// --------------------------------------------------------------------------------------
+template <int PT>
+__device__ __forceinline__ void prim_regs(const uint32_t *__restrict__ core_g, hdb::Edge *__restrict__ mst, int N,
+                                          const uint16_t *rc16, unsigned long long *slots) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t reach[PT], corev[PT];
+    unsigned long long alive = 0;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int p = tid + i * TB;
+        reach[i] = REACH_INF;
+        corev[i] = 0;
+        if (p < N) { corev[i] = core_g[p]; alive |= 1ull << i; }
+    }
+    uint32_t cur = 0;
+    uint32_t cv = rc16[0];
+    int cr = cv & 255, cc = cv >> 8;
+    uint32_t ccore = core_g[0];
+    if (tid == 0) alive &= ~1ull;
+    for (int step = 0; step < N - 1; ++step) {
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            if ((alive >> i) & 1ull) {
+                const int p = tid + i * TB;
+                const uint32_t v = rc16[p];
+                const int dr = (int)(v & 255) - cr, dc = (int)(v >> 8) - cc;
+                uint32_t m = (uint32_t)(dr * dr + dc * dc);
+                m = max(max(m, corev[i]), ccore);
+                if (m < reach[i]) reach[i] = m;
+                const unsigned long long key =
+                    ((unsigned long long)reach[i] << 33) | ((unsigned long long)p << 17) | corev[i];
+                best = key < best ? key : best;
+            }
+        }
+        best = wave_min_u64(best);
+        unsigned long long *sl = slots + (step & 1) * NW16;
+        if (lane == 0) sl[wave] = best;
+        __syncthreads();
+        unsigned long long w = sl[0];
+#pragma unroll
+        for (int i = 1; i < NW16; ++i) { unsigned long long t = sl[i]; w = t < w ? t : w; }
+        const uint32_t nidx = (uint32_t)(w >> 17) & 0xFFFFu;
+        if (tid == 0) mst[step] = hdb::Edge{(uint16_t)cur, (uint16_t)nidx, (uint32_t)(w >> 33)};
+        if ((int)(nidx & (TB - 1)) == tid) alive &= ~(1ull << (nidx >> 10));
+        ccore = (uint32_t)w & 0x1FFFFu;
+        cv = rc16[nidx];
+        cr = cv & 255; cc = cv >> 8;
+        cur = nidx;
+    }
+}
+
+// generic path for very large N: reachability kept in global memory
+__device__ __forceinline__ void prim_global(const uint32_t *__restrict__ core_g, uint32_t *__restrict__ reach_g,
+                                            hdb::Edge *__restrict__ mst, int N, const uint16_t *rc16,
+                                            unsigned long long *slots) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int p = tid; p < N; p += TB) reach_g[p] = REACH_INF;        // bit 31 marks "in tree"
+    if (tid == 0) reach_g[0] = 0x80000000u;
+    __syncthreads();
+    uint32_t cur = 0, cv = rc16[0];
+    int cr = cv & 255, cc = cv >> 8;
+    uint32_t ccore = core_g[0];
+    for (int step = 0; step < N - 1; ++step) {
+        unsigned long long best = ~0ull;
+        for (int p = tid; p < N; p += TB) {
+            uint32_t rv = reach_g[p];
+            if (rv & 0x80000000u) continue;
+            const uint32_t v = rc16[p], cj = core_g[p];
+            const int dr = (int)(v & 255) - cr, dc = (int)(v >> 8) - cc;
+            uint32_t m = max(max((uint32_t)(dr * dr + dc * dc), cj), ccore);
+            if (m < rv) { rv = m; reach_g[p] = rv; }
+            const unsigned long long key = ((unsigned long long)rv << 33) | ((unsigned long long)p << 17) | cj;
+            best = key < best ? key : best;
+        }
+        best = wave_min_u64(best);
+        unsigned long long *sl = slots + (step & 1) * NW16;
+        if (lane == 0) sl[wave] = best;
+        __syncthreads();
+        unsigned long long w = sl[0];
+#pragma unroll
+        for (int i = 1; i < NW16; ++i) { unsigned long long t = sl[i]; w = t < w ? t : w; }
+        const uint32_t nidx = (uint32_t)(w >> 17) & 0xFFFFu;
+        if (tid == 0) mst[step] = hdb::Edge{(uint16_t)cur, (uint16_t)nidx, (uint32_t)(w >> 33)};
+        if ((int)(nidx & (TB - 1)) == tid) reach_g[nidx] = 0x80000000u;   // same thread re-reads it next step
+        ccore = (uint32_t)w & 0x1FFFFu;
+        cv = rc16[nidx];
+        cr = cv & 255; cc = cv >> 8;
+        cur = nidx;
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_prim(TailArgs A) {
+    const int f = blockIdx.x;
+    if (A.depth[f] != A.round) return;
+    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
+    const int32_t *hdr = (const int32_t *)(ws + A.L.hdr);
+    if (!hdr[3]) return;
+    const int N = hdr[0];
+    extern __shared__ uint8_t sm_prim[];
+    unsigned long long *slots = (unsigned long long *)sm_prim;       // [2][NW16]
+    uint16_t *rc16 = (uint16_t *)(sm_prim + 2 * NW16 * 8);           // [N]
+    const uint32_t *pts = (const uint32_t *)(ws + A.L.pts);
+    for (int p = threadIdx.x; p < N; p += TB) rc16[p] = (uint16_t)(pts[p] & 0xFFFFu);
+    __syncthreads();
+    const uint32_t *core = (const uint32_t *)(ws + A.L.core);
+    hdb::Edge *mst = (hdb::Edge *)(ws + A.L.mst);
+    if (N <= 4 * TB) prim_regs<4>(core, mst, N, rc16, slots);
+    else if (N <= 12 * TB) prim_regs<12>(core, mst, N, rc16, slots);
+    else if (N <= 24 * TB) prim_regs<24>(core, mst, N, rc16, slots);
+    else prim_global(core, (uint32_t *)(ws + A.L.reach), mst, N, rc16, slots);
+}
+
+// --------------------------------------------------------------------------------------
+// k_finish: stable LSD radix sort of the MST edges by weight, hierarchy + EOM
+// (hdb_tree.h, one lane), labels, cluster weights, zeroing, CLOSE 5x5, centroid.
+// --------------------------------------------------------------------------------------
+// one stable 6-bit counting pass over n edges: src -> dst
+__device__ void radix_pass(const hdb::Edge *__restrict__ src, hdb::Edge *__restrict__ dst, int n, int shift,
+                           int *hist /*64*/, int *run /*64*/, uint16_t *wcnt /*[NW16][64]*/) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 64) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += TB) atomicAdd(&hist[(src[i].w >> shift) & 63], 1);
+    __syncthreads();
+    if (tid < 64) {                                  // exclusive scan of the 64 bins by wave 0
+        int v = hist[tid], inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        run[tid] = inc - v;
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int base = 0; base < n; base += TB) {
+        const int i = base + tid;
+        const bool valid = i < n;
+        hdb::Edge e = valid ? src[i] : hdb::Edge{0, 0, 0};
+        const int d = valid ? (int)((e.w >> shift) & 63) : 64;
+        unsigned long long mask = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const unsigned long long bal = __ballot((d >> b) & 1);
+            mask &= ((d >> b) & 1) ? bal : ~bal;
+        }
+        const int rank = __popcll(mask & lt), cnt = __popcll(mask);
+        wcnt[wave * 64 + lane] = 0;
+        __syncthreads();
+        if (valid && rank == 0) wcnt[wave * 64 + d] = (uint16_t)cnt;
+        __syncthreads();
+        int pre = 0;
+        if (valid) {
+            for (int wv = 0; wv < wave; ++wv) pre += wcnt[wv * 64 + d];
+            dst[run[d] + pre + rank] = e;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            int tot = 0;
+#pragma unroll
+            for (int wv = 0; wv < NW16; ++wv) tot += wcnt[wv * 64 + tid];
+            run[tid] += tot;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
+    const int f = blockIdx.x;
+    if (A.depth[f] != A.round) return;
+    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
+    int32_t *hdr = (int32_t *)(ws + A.L.hdr);
+    const int N = hdr[0];
+    const int hw = A.h * A.w;
+    uint8_t *map = A.maps + (size_t)f * hw;
+    extern __shared__ uint8_t sm_fin[];
+    uint8_t *m0 = sm_fin;                            // [hw]
+    uint8_t *m1 = sm_fin + (hw + 15) / 16 * 16;      // [hw]
+    __shared__ int hist[64], run[64];
+    __shared__ uint16_t wcnt[NW16 * 64];
+    __shared__ int s_nsel, s_best;
+    __shared__ unsigned long long red[3 * NW16];
+    const int tid = threadIdx.x;
+    const bool clustered = hdr[3] != 0;
+    for (int i = tid; i < hw; i += TB) m0[i] = map[i];
+    if (clustered) {
+        hdb::Edge *mst = (hdb::Edge *)(ws + A.L.mst), *ea = (hdb::Edge *)(ws + A.L.ea), *eb = (hdb::Edge *)(ws + A.L.eb);
+        radix_pass(mst, ea, N - 1, 0, hist, run, wcnt);
+        radix_pass(ea, eb, N - 1, 6, hist, run, wcnt);
+        radix_pass(eb, ea, N - 1, 12, hist, run, wcnt);
+        hdb::Tree t;
+        t.sp = (uint16_t *)(ws + A.L.sp); t.ssz = (uint16_t *)(ws + A.L.ssz); t.absc = (uint16_t *)(ws + A.L.absc);
+        t.absw = (uint32_t *)(ws + A.L.absw); t.sdn = (uint32_t *)(ws + A.L.sdn); t.dparent = (uint32_t *)(ws + A.L.dparent);
+        t.cup = (uint16_t *)(ws + A.L.cup); t.ctp = (int32_t *)(ws + A.L.ctp); t.cleft = (int32_t *)(ws + A.L.cleft);
+        t.cright = (int32_t *)(ws + A.L.cright); t.cbirthw = (uint32_t *)(ws + A.L.cbirthw);
+        t.cminw = (uint32_t *)(ws + A.L.cminw); t.csize = (uint32_t *)(ws + A.L.csize); t.ccnt = (uint32_t *)(ws + A.L.ccnt);
+        t.cdn = (uint32_t *)(ws + A.L.cdn); t.csplit = (uint32_t *)(ws + A.L.csplit); t.cacc = (double *)(ws + A.L.cacc);
+        t.csel = (uint8_t *)(ws + A.L.csel); t.crep = (int32_t *)(ws + A.L.crep);
+        t.nclusters = 0; t.n = N;
+        {
+            const int per = (N + TB - 1) / TB;
+            hdb::init_points(t, min(N, tid * per), min(N, tid * per + per));
+        }
+        __syncthreads();
+        uint32_t *cweight = (uint32_t *)(ws + A.L.cweight);
+        if (tid == 0) {
+            hdb::build(t, ea, N, A.mcs);
+            s_nsel = hdb::select(t);
+            hdr[4] = t.nclusters;
+            for (int c = 0; c < t.nclusters; ++c) cweight[c] = 0;
+        }
+        __syncthreads();
+        t.nclusters = hdr[4];
+        const int nsel = s_nsel;
+        const uint32_t *pts = (const uint32_t *)(ws + A.L.pts);
+        int32_t *labels = (int32_t *)(ws + A.L.labels);
+        for (int p = tid; p < N; p += TB) {
+            const int c = hdb::point_cluster(t, (uint32_t)p, nsel);
+            labels[p] = c;
+            if (c >= 0) {
+                const uint32_t val = pts[p] >> 16;
+                if (A.select_sum == 1) atomicAdd(&cweight[c], val); else atomicMax(&cweight[c], val);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (tid == 0) {
+            int best = -1;
+            for (int c = 0; c < t.nclusters; ++c) {
+                if (t.crep[c] != c) continue;
+                if (best < 0 || cweight[c] > cweight[best] ||
+                    (cweight[c] == cweight[best] && hdb::cluster_before(t, c, best)))
+                    best = c;
+            }
+            s_best = best;
+            hdr[1] = nsel;
+            hdr[2] = best;
+        }
+        __syncthreads();
+        const int best = s_best;
+        if (best >= 0) {
+            for (int p = tid; p < N; p += TB)
+                if (labels[p] != best) {
+                    const uint32_t v = pts[p];
+                    m0[(v & 255) * A.w + ((v >> 8) & 255)] = 0;
+                }
+            __syncthreads();
+            if (A.op_close) {
+                // grey CLOSE with a 5x5 rectangle = separable max (dilate) then separable min (erode);
+                // out-of-image samples are ignored
+                for (int i = tid; i < hw; i += TB) {
+                    const int r = i / A.w, c = i - r * A.w;
+                    int v = 0;
+                    for (int d = -2; d <= 2; ++d) { int cc = c + d; if ((unsigned)cc < (unsigned)A.w) v = max(v, (int)m0[r * A.w + cc]); }
+                    m1[i] = (uint8_t)v;
+                }
+                __syncthreads();
+                for (int i = tid; i < hw; i += TB) {
+                    const int r = i / A.w, c = i - r * A.w;
+                    int v = 0;
+                    for (int d = -2; d <= 2; ++d) { int rr = r + d; if ((unsigned)rr < (unsigned)A.h) v = max(v, (int)m1[rr * A.w + c]); }
+                    m0[i] = (uint8_t)v;
+                }
+                __syncthreads();
+                for (int i = tid; i < hw; i += TB) {
+                    const int r = i / A.w, c = i - r * A.w;
+                    int v = 255;
+                    for (int d = -2; d <= 2; ++d) { int cc = c + d; if ((unsigned)cc < (unsigned)A.w) v = min(v, (int)m0[r * A.w + cc]); }
+                    m1[i] = (uint8_t)v;
+                }
+                __syncthreads();
+                for (int i = tid; i < hw; i += TB) {
+                    const int r = i / A.w, c = i - r * A.w;
+                    int v = 255;
+                    for (int d = -2; d <= 2; ++d) { int rr = r + d; if ((unsigned)rr < (unsigned)A.h) v = min(v, (int)m1[rr * A.w + c]); }
+                    m0[i] = (uint8_t)v;
+                }
+                __syncthreads();
+            }
+            for (int i = tid; i < hw; i += TB) map[i] = m0[i];
+        }
+    }
+    __syncthreads();
+    // centroid of the non-zero pixels of the final map
+    unsigned long long cnt = 0, sr = 0, sc = 0;
+    for (int i = tid; i < hw; i += TB)
+        if (m0[i]) { const int r = i / A.w; ++cnt; sr += r; sc += i - r * A.w; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o); sr += __shfl_xor(sr, o); sc += __shfl_xor(sc, o); }
+    if ((tid & 63) == 0) { red[tid >> 6] = cnt; red[NW16 + (tid >> 6)] = sr; red[2 * NW16 + (tid >> 6)] = sc; }
+    __syncthreads();
+    if (tid == 0) {
+        cnt = sr = sc = 0;
+        for (int i = 0; i < NW16; ++i) { cnt += red[i]; sr += red[NW16 + i]; sc += red[2 * NW16 + i]; }
+        if (cnt) {
+            A.xy[2 * f] = (double)sc / (double)cnt;
+            A.xy[2 * f + 1] = (double)sr / (double)cnt;
+        } else {
+            A.xy[2 * f] = A.xy[2 * f + 1] = __longlong_as_double(0x7FF8000000000000LL);
+        }
+        if (A.stats) {
+            A.stats[4 * f] = N;
+            A.stats[4 * f + 1] = clustered ? hdr[1] : 0;
+            A.stats[4 * f + 2] = clustered ? hdr[2] : -1;
+            A.stats[4 * f + 3] = (int)cnt;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------------
+extern "C" int svc_threshold_u8(SvcHandle *h, uint8_t *maps, size_t n_bytes, int t, void *stream) {
+    if (!h || !maps) { svc_set_error("svc_threshold_u8: invalid argument"); return SVC_E_INVALID; }
+    if (n_bytes == 0) return SVC_OK;
+    SVC_HIP(hipSetDevice(h->device));
+    k_threshold<<<(unsigned)((n_bytes + 4095) / 4096), 256, 0, (hipStream_t)stream>>>(maps, n_bytes, t);
+    SVC_CHECK_LAUNCH();
+    return SVC_OK;
+}
+
+extern "C" int svc_iou_i32(const int32_t *a, const int32_t *b, size_t n, double *out, void *stream) {
+    if (!a || !b || !out) { svc_set_error("svc_iou_i32: invalid argument"); return SVC_E_INVALID; }
+    if (n == 0) return SVC_OK;
+    k_iou<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>((const int4 *)a, (const int4 *)b, n, out);
+    SVC_CHECK_LAUNCH();
+    return SVC_OK;
+}
+
+static int ensure_ring(SvcHandle *h) {
+    if (h->tail_n_offsets) return SVC_OK;
+    std::vector<uint32_t> v;
+    for (int dr = -RING_R; dr <= RING_R; ++dr)
+        for (int dc = -RING_R; dc <= RING_R; ++dc) {
+            int d2 = dr * dr + dc * dc;
+            if (d2 == 0 || d2 > RING_R * RING_R) continue;
+            v.push_back((uint32_t)(dr + 128) | ((uint32_t)(dc + 128) << 8) | ((uint32_t)d2 << 16));
+        }
+    std::stable_sort(v.begin(), v.end(), [](uint32_t x, uint32_t y) { return (x >> 16) < (y >> 16); });
+    int rc = h->tail_offsets.ensure(v.size() * 4);
+    if (rc) return rc;
+    SVC_HIP(hipMemcpy(h->tail_offsets.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    h->tail_n_offsets = (int)v.size();
+    return SVC_OK;
+}
+
+extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height, int width,
+                                  const uint8_t *blend_flags_host, const SvcParams *params, double *xy,
+                                  int32_t *stats, void *stream) {
+    if (!h || !maps || !params || !xy || n < 0 || height < 1 || width < 1) {
+        svc_set_error("svc_cluster_center: invalid argument");
+        return SVC_E_INVALID;
+    }
+    if (height > 255 || width > 255 || height * width > 65535) {
+        svc_set_error("svc_cluster_center: map %dx%d exceeds the supported 255x255", height, width);
+        return SVC_E_INVALID;
+    }
+    if (params->hdbscan_min < 2) { svc_set_error("svc_cluster_center: hdbscan_min must be >= 2"); return SVC_E_INVALID; }
+    if (n == 0) return SVC_OK;
+    SVC_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_ring(h);
+    if (rc) return rc;
+    const int cap = height * width;
+    const int mc = hdb::max_clusters(cap, params->hdbscan_min);
+    FrameWS L = make_layout(cap, mc);
+    // depth (round) of every map: a map blended from its predecessor runs one round later
+    std::vector<uint8_t> depth(n, 0);
+    int maxd = 0;
+    for (int i = 1; i < n; ++i)
+        if (blend_flags_host && blend_flags_host[i - 1]) {
+            if (depth[i - 1] == 255) { svc_set_error("svc_cluster_center: blend chain longer than 255"); return SVC_E_INVALID; }
+            depth[i] = depth[i - 1] + 1;
+            maxd = std::max(maxd, (int)depth[i]);
+        }
+    if ((rc = h->tail_ws.ensure((size_t)L.total * n + (size_t)n))) return rc;
+    uint8_t *depth_dev = (uint8_t *)h->tail_ws.p + (size_t)L.total * n;
+    // make sure earlier work that still reads the depth array has drained before it is overwritten
+    SVC_HIP(hipStreamSynchronize(s));
+    SVC_HIP(hipMemcpyAsync(depth_dev, depth.data(), n, hipMemcpyHostToDevice, s));
+    SVC_HIP(hipStreamSynchronize(s));
+    h->tail_frames = n; h->tail_h = height; h->tail_w = width; h->tail_frame_stride = L.total;
+    TailArgs A;
+    A.maps = maps; A.ws = (uint8_t *)h->tail_ws.p; A.ws_stride = L.total; A.depth = depth_dev; A.round = 0;
+    A.n = n; A.h = height; A.w = width;
+    A.mcs = params->hdbscan_min; A.min_samples = params->hdbscan_min_samples; A.select_sum = params->select_sum;
+    A.op_close = params->op_close; A.clust_filt = params->clust_filt;
+    A.ring = (const uint32_t *)h->tail_offsets.p; A.n_ring = h->tail_n_offsets;
+    A.xy = xy; A.stats = stats; A.L = L;
+    const int hw = height * width;
+    const size_t lds_core = (size_t)(hw + 15) / 16 * 16 + (size_t)h->tail_n_offsets * 4;
+    const size_t lds_prim = 2 * NW16 * 8 + (size_t)hw * 2;
+    const size_t lds_fin = 2 * ((size_t)(hw + 15) / 16 * 16);
+    static bool attr_done = false;
+    if (!attr_done) {
+        SVC_HIP(hipFuncSetAttribute((const void *)k_core, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_prim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16 * 1024));
+        attr_done = true;
+    }
+    for (int r = 0; r <= maxd; ++r) {
+        A.round = r;
+        if (r > 0) {
+            k_blend<<<dim3(8, n), 256, 0, s>>>(maps, depth_dev, r, hw);
+            SVC_CHECK_LAUNCH();
+        }
+        k_compact<<<n, TB, 0, s>>>(A);
+        SVC_CHECK_LAUNCH();
+        if (params->clust_filt) {
+            k_core<<<n, TB, lds_core, s>>>(A);
+            SVC_CHECK_LAUNCH();
+            k_prim<<<n, TB, lds_prim, s>>>(A);
+            SVC_CHECK_LAUNCH();
+        }
+        k_finish<<<n, TB, lds_fin, s>>>(A);
+        SVC_CHECK_LAUNCH();
+    }
+    return SVC_OK;
+}
+
+extern "C" int svc_debug_cluster_state(SvcHandle *h, int frame, int cap, uint32_t *pts_host, uint32_t *core_host,
+                                       uint32_t *mst_host, int32_t *labels_host) {
+    if (!h || !h->tail_ws.p || frame < 0 || frame >= h->tail_frames) {
+        svc_set_error("svc_debug_cluster_state: no such frame");
+        return SVC_E_INVALID;
+    }
+    SVC_HIP(hipSetDevice(h->device));
+    SVC_HIP(hipDeviceSynchronize());
+    const int fcap = h->tail_h * h->tail_w;
+    FrameWS L = make_layout(fcap, 1);      // point-array offsets do not depend on the cluster capacity
+    const uint8_t *ws = (const uint8_t *)h->tail_ws.p + (size_t)frame * h->tail_frame_stride;
+    int32_t hdr[16];
+    SVC_HIP(hipMemcpy(hdr, ws + L.hdr, sizeof hdr, hipMemcpyDeviceToHost));
+    const int N = hdr[0];
+    const int m = std::min(N, cap);
+    if (pts_host) SVC_HIP(hipMemcpy(pts_host, ws + L.pts, (size_t)m * 4, hipMemcpyDeviceToHost));
+    if (hdr[3]) {
+        if (core_host) SVC_HIP(hipMemcpy(core_host, ws + L.core, (size_t)m * 4, hipMemcpyDeviceToHost));
+        if (labels_host) SVC_HIP(hipMemcpy(labels_host, ws + L.labels, (size_t)m * 4, hipMemcpyDeviceToHost));
+        if (mst_host && m > 1) {
+            std::vector<hdb::Edge> e(m - 1);
+            SVC_HIP(hipMemcpy(e.data(), ws + L.mst, (size_t)(m - 1) * 8, hipMemcpyDeviceToHost));
+            for (int i = 0; i < m - 1; ++i) { mst_host[3 * i] = e[i].a; mst_host[3 * i + 1] = e[i].b; mst_host[3 * i + 2] = e[i].w; }
+        }
+    } else {
+        if (core_host) memset(core_host, 0, (size_t)m * 4);
+        if (labels_host) for (int i = 0; i < m; ++i) labels_host[i] = -1;
+    }
+    return N;
+}

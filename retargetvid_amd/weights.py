@@ -250,7 +250,7 @@ def smoothing_phase_table(k41):
     return np.einsum('pad,qbe,de->pqab', sel, sel, k).astype(np.float32)
 
 
-def fold_state_dict(sd, feat_hw=(8, 13)):
+def fold_state_dict(sd):
     """-> ordered list of layer dicts in execution order (see csrc/svc_net.cpp)."""
     sd = to_numpy_state_dict(sd)
     L = []
@@ -265,9 +265,10 @@ def fold_state_dict(sd, feat_hw=(8, 13)):
         L.append(_pw(*_fold(sd, name + '.expansion.0.weight', name + '.expansion.1'), True, name + '.expand'))
         L.append(_pw(*_fold(sd, name + '.reduction.0.weight', name + '.reduction.1',
                             name + '.reduction.0.bias'), False, name + '.reduce'))
+    # raw Gaussian parameters [16][y/x][mu/logstd]; the library evaluates the prior maps
+    # (model.py:348-378) for whatever feature size the input aspect ratio selects
     L.append(dict(kind='const', name='gaussians',
-                  w=np.ascontiguousarray(gaussian_maps_np(sd['coarse_gaussians_salicon'], *feat_hw)
-                                         .transpose(1, 2, 0))))            # [h][w][16]
+                  w=sd['coarse_gaussians_salicon'].astype(np.float32).reshape(64)))
     L += _fold_inv_res(sd, 'post_cnn.inv_res.conv', 1, 1, 'post_cnn')
     L += _fold_inv_res(sd, 'upsampling_2.inv_res.conv', 2, 1, 'us2')
     L += _fold_inv_res(sd, 'post_upsampling_2.inv_res.conv', 2, 1, 'post_us2')
@@ -291,7 +292,12 @@ def pack_blob(layers):
     csrc/svc_net.cpp walks the same order."""
     tensors = []
     for l in layers:
-        tensors.append(np.ascontiguousarray(l['w'], np.float32).ravel())
+        w = np.ascontiguousarray(l['w'], np.float32)
+        if l['kind'] == 'pw':                       # rows padded to a multiple of the 32-wide MFMA tile
+            pad = (-w.shape[0]) % 32
+            if pad:
+                w = np.concatenate([w, np.zeros((pad, w.shape[1]), np.float32)])
+        tensors.append(w.ravel())
         if 'b' in l:
             tensors.append(np.ascontiguousarray(l['b'], np.float32).ravel())
     head = 16 + 16 * len(tensors)

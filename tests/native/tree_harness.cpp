@@ -1,0 +1,34 @@
+// CPU harness for retargetvid_amd/csrc/hdb_tree.h (the hierarchy stage the HIP kernel
+// inlines).  Built by tests/ only (g++), never loaded by the product.
+#include <algorithm>
+#include <vector>
+#include "../../retargetvid_amd/csrc/hdb_tree.h"
+
+extern "C" int tree_labels(const uint16_t *a, const uint16_t *b, const uint32_t *w, int n, int mcs,
+                           int32_t *labels) {
+    using namespace hdb;
+    std::vector<Edge> edges(n - 1);
+    for (int i = 0; i < n - 1; ++i) edges[i] = Edge{a[i], b[i], w[i]};
+    const int mc = max_clusters(n, mcs);
+    std::vector<uint16_t> sp(n), ssz(n), absc(n), cup(mc);
+    std::vector<uint32_t> absw(n), sdn(n), dparent(2 * n), cbirthw(mc), cminw(mc), csize(mc), ccnt(mc), cdn(mc), csplit(mc);
+    std::vector<int32_t> ctp(mc), cleft(mc), cright(mc), crep(mc);
+    std::vector<double> cacc(mc);
+    std::vector<uint8_t> csel(mc);
+    Tree t{sp.data(), ssz.data(), absc.data(), absw.data(), sdn.data(), dparent.data(), cup.data(), ctp.data(),
+           cleft.data(), cright.data(), cbirthw.data(), cminw.data(), csize.data(), ccnt.data(), cdn.data(),
+           csplit.data(), cacc.data(), csel.data(), crep.data(), 0, n};
+    init_points(t, 0, n);
+    build(t, edges.data(), n, mcs);
+    const int nsel = select(t);
+    std::vector<int> sel;
+    for (int c = 0; c < t.nclusters; ++c) if (t.crep[c] == c) sel.push_back(c);
+    std::sort(sel.begin(), sel.end(), [&](int x, int y) { return cluster_before(t, x, y); });
+    std::vector<int> lab(t.nclusters, -1);
+    for (size_t i = 0; i < sel.size(); ++i) lab[sel[i]] = (int)i;
+    for (int p = 0; p < n; ++p) {
+        int c = point_cluster(t, p, nsel);
+        labels[p] = c < 0 ? -1 : lab[c];
+    }
+    return nsel;
+}

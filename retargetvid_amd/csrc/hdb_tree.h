@@ -11,10 +11,12 @@
 // bottom-up pass over the sorted edges: a component that first reaches
 // min_cluster_size opens a condensed cluster; a smaller component merging into it is
 // a batch of points "falling out" of that cluster at lambda = 1/w; two large
-// components merging is a true split that opens their parent.  Stability is
-// accumulated as  sum(lambda*size) - birth*sum(size)  per cluster, in float64.
-// The result is identical to the library's whenever its `subtree > own` comparisons
-// are not exact floating-point ties (summation order differs).
+// components merging is a true split that opens their parent.  Every such event is
+// logged per edge; stabilities are then summed from the log in REVERSE edge order,
+// one (lambda - birth) * size term per condensed-tree row, which is exactly the order
+// and the float64 arithmetic of the library's row loop (rows of a cluster appear
+// top-down, i.e. by increasing lambda; a batch of s points is s rows of size 1), so
+// even exact ties in its `subtree > own` comparisons resolve identically.
 //
 // Cluster numbering: the library numbers condensed clusters in BFS order of the
 // dendrogram; the caller only needs that order to break ties between equally
@@ -51,6 +53,10 @@ struct Tree {
     uint16_t *absc;    // cluster that absorbed this small component (valid at roots), NONE16 = not yet
     uint32_t *absw;    // weight at absorption (valid at roots)
     uint32_t *sdn;     // dendrogram node id of a live small component (valid at roots)
+    // per edge: the condensed-tree rows the merge produced
+    uint16_t *evc;     // cluster the rows belong to (NONE16 = none)
+    uint32_t *evs;     // points falling out (size-1 rows), or the left child's size for a split
+    uint32_t *evs2;    // 0, or the right child's size for a split (two cluster rows)
     // dendrogram: parent link of every node (2n-1 entries): parent << 1 | is_right
     uint32_t *dparent;
     // per cluster
@@ -60,10 +66,9 @@ struct Tree {
     uint32_t *cbirthw; // weight at which the cluster is born top-down (0 = root: lambda 0)
     uint32_t *cminw;   // smallest weight among the cluster's rows (largest lambda)
     uint32_t *csize;   // points in the component while this cluster is its top
-    uint32_t *ccnt;    // sum of row sizes
     uint32_t *cdn;     // dendrogram node of the component while this cluster is its top
     uint32_t *csplit;  // dendrogram node at which the cluster's children were created
-    double *cacc;      // sum of lambda * row size, later the (propagated) stability
+    double *cacc;      // stability (after select(): propagated subtree stability)
     uint8_t *csel;     // selected by excess of mass
     int32_t *crep;     // nearest selected ancestor-or-self, ROOT_NOISE if none
     int32_t nclusters;
@@ -107,7 +112,6 @@ SVC_HD int32_t new_cluster(Tree &t, uint32_t w, uint32_t size, uint32_t node, in
     t.cbirthw[c] = 0;
     t.cminw[c] = w;
     t.csize[c] = size;
-    t.ccnt[c] = size;
     t.cdn[c] = node;
     t.csplit[c] = node;
     t.cacc[c] = 0.0;
@@ -133,7 +137,6 @@ SVC_HD void build(Tree &t, const Edge *edges, int n, int mcs) {
     for (int i = 0; i < n - 1; ++i) {
         const Edge e = edges[i];
         const uint32_t w = e.w;
-        const double lam = 1.0 / (double)w;
         uint32_t ra = find_small(t, e.a), rb = find_small(t, e.b);
         const bool abig = t.absc[ra] != NONE16, bbig = t.absc[rb] != NONE16;
         uint32_t ca = 0, cb = 0, sa, sb, na, nb;
@@ -144,6 +147,9 @@ SVC_HD void build(Tree &t, const Edge *edges, int n, int mcs) {
         const uint32_t node = (uint32_t)(n + i);
         t.dparent[na] = node << 1;
         t.dparent[nb] = (node << 1) | 1u;
+        t.evc[i] = (uint16_t)NONE16;
+        t.evs[i] = 0;
+        t.evs2[i] = 0;
         if (!abig && !bbig) {
             const uint32_t s = sa + sb;
             if ((int)s < mcs) {
@@ -154,21 +160,20 @@ SVC_HD void build(Tree &t, const Edge *edges, int n, int mcs) {
                 t.sdn[big] = node;
             } else {                                   // a condensed cluster is born bottom-up
                 int32_t c = new_cluster(t, w, s, node, -1, -1);
-                t.cacc[c] = lam * (double)sa + lam * (double)sb;
+                t.evc[i] = (uint16_t)c; t.evs[i] = s;
                 t.absc[ra] = (uint16_t)c; t.absw[ra] = w;
                 t.absc[rb] = (uint16_t)c; t.absw[rb] = w;
             }
         } else if (abig && bbig) {                     // true split: both sides >= mcs
             int32_t p = new_cluster(t, w, sa + sb, node, (int32_t)ca, (int32_t)cb);
-            t.cacc[p] = lam * (double)sa + lam * (double)sb;
+            t.evc[i] = (uint16_t)p; t.evs[i] = sa; t.evs2[i] = sb;
             t.cup[ca] = (uint16_t)p; t.cup[cb] = (uint16_t)p;
             t.ctp[ca] = p; t.ctp[cb] = p;
             t.cbirthw[ca] = w; t.cbirthw[cb] = w;
         } else {                                       // small side falls out of the big side's cluster
             uint32_t c = abig ? ca : cb, r = abig ? rb : ra, s = abig ? sb : sa;
             t.absc[r] = (uint16_t)c; t.absw[r] = w;
-            t.cacc[c] += lam * (double)s;
-            t.ccnt[c] += s;
+            t.evc[i] = (uint16_t)c; t.evs[i] = s;
             t.csize[c] += s;
             t.cdn[c] = node;
         }
@@ -178,11 +183,26 @@ SVC_HD void build(Tree &t, const Edge *edges, int n, int mcs) {
 
 // Stability, excess-of-mass selection (root allowed) and nearest-selected-ancestor map.
 // Returns the number of selected clusters.
-SVC_HD int select(Tree &t) {
+SVC_HD int select(Tree &t, const Edge *edges) {
     const int nc = t.nclusters;
-    for (int c = 0; c < nc; ++c) {                      // creation order: children before parents
+    // stabilities: the library's row loop, rows in its condensed-tree order (see header)
+    for (int i = t.n - 2; i >= 0; --i) {
+        const uint16_t c = t.evc[i];
+        if (c == NONE16) continue;
+        const double lam = 1.0 / (double)edges[i].w;
         const double birth = t.cbirthw[c] ? 1.0 / (double)t.cbirthw[c] : 0.0;
-        double stab = t.cacc[c] - birth * (double)t.ccnt[c];
+        double acc = t.cacc[c];
+        if (t.evs2[i]) {
+            acc += (lam - birth) * (double)t.evs[i];
+            acc += (lam - birth) * (double)t.evs2[i];
+        } else {
+            const double term = (lam - birth) * 1.0;
+            for (uint32_t k = 0; k < t.evs[i]; ++k) acc += term;
+        }
+        t.cacc[c] = acc;
+    }
+    for (int c = 0; c < nc; ++c) {                      // creation order: children before parents
+        double stab = t.cacc[c];
         double sub = 0.0;
         if (t.cleft[c] >= 0) sub = t.cacc[t.cleft[c]] + t.cacc[t.cright[c]];
         if (sub > stab) {

@@ -39,8 +39,8 @@ struct FrameWS {
     uint32_t ea, eb;     // Edge[cap]  radix ping-pong (ea = sorted result)
     uint32_t labels;     // i32[cap]
     uint32_t reach;      // u32[cap]   (generic large-N Prim only)
-    uint32_t sp, ssz, absc, absw, sdn, dparent;
-    uint32_t cup, ctp, cleft, cright, cbirthw, cminw, csize, ccnt, cdn, csplit, cacc, csel, crep, cweight;
+    uint32_t sp, ssz, absc, absw, sdn, evc, evs, evs2, dparent;
+    uint32_t cup, ctp, cleft, cright, cbirthw, cminw, csize, cdn, csplit, cacc, csel, crep, cweight;
     uint32_t total;
 };
 
@@ -53,9 +53,10 @@ static FrameWS make_layout(int cap, int mc) {
     L.mst = take(8u * cap); L.ea = take(8u * cap); L.eb = take(8u * cap);
     L.labels = take(4u * cap); L.reach = take(4u * cap);
     L.sp = take(2u * cap); L.ssz = take(2u * cap); L.absc = take(2u * cap); L.absw = take(4u * cap);
-    L.sdn = take(4u * cap); L.dparent = take(8u * cap);
+    L.sdn = take(4u * cap); L.evc = take(2u * cap); L.evs = take(4u * cap); L.evs2 = take(4u * cap);
+    L.dparent = take(8u * cap);
     L.cup = take(2u * mc); L.ctp = take(4u * mc); L.cleft = take(4u * mc); L.cright = take(4u * mc);
-    L.cbirthw = take(4u * mc); L.cminw = take(4u * mc); L.csize = take(4u * mc); L.ccnt = take(4u * mc);
+    L.cbirthw = take(4u * mc); L.cminw = take(4u * mc); L.csize = take(4u * mc);
     L.cdn = take(4u * mc); L.csplit = take(4u * mc); L.cacc = take(8u * mc); L.csel = take(1u * mc);
     L.crep = take(4u * mc); L.cweight = take(4u * mc);
     L.total = o;
@@ -459,9 +460,10 @@ __global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
         hdb::Tree t;
         t.sp = (uint16_t *)(ws + A.L.sp); t.ssz = (uint16_t *)(ws + A.L.ssz); t.absc = (uint16_t *)(ws + A.L.absc);
         t.absw = (uint32_t *)(ws + A.L.absw); t.sdn = (uint32_t *)(ws + A.L.sdn); t.dparent = (uint32_t *)(ws + A.L.dparent);
+        t.evc = (uint16_t *)(ws + A.L.evc); t.evs = (uint32_t *)(ws + A.L.evs); t.evs2 = (uint32_t *)(ws + A.L.evs2);
         t.cup = (uint16_t *)(ws + A.L.cup); t.ctp = (int32_t *)(ws + A.L.ctp); t.cleft = (int32_t *)(ws + A.L.cleft);
         t.cright = (int32_t *)(ws + A.L.cright); t.cbirthw = (uint32_t *)(ws + A.L.cbirthw);
-        t.cminw = (uint32_t *)(ws + A.L.cminw); t.csize = (uint32_t *)(ws + A.L.csize); t.ccnt = (uint32_t *)(ws + A.L.ccnt);
+        t.cminw = (uint32_t *)(ws + A.L.cminw); t.csize = (uint32_t *)(ws + A.L.csize);
         t.cdn = (uint32_t *)(ws + A.L.cdn); t.csplit = (uint32_t *)(ws + A.L.csplit); t.cacc = (double *)(ws + A.L.cacc);
         t.csel = (uint8_t *)(ws + A.L.csel); t.crep = (int32_t *)(ws + A.L.crep);
         t.nclusters = 0; t.n = N;
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
         uint32_t *cweight = (uint32_t *)(ws + A.L.cweight);
         if (tid == 0) {
             hdb::build(t, ea, N, A.mcs);
-            s_nsel = hdb::select(t);
+            s_nsel = hdb::select(t, ea);
             hdr[4] = t.nclusters;
             for (int c = 0; c < t.nclusters; ++c) cweight[c] = 0;
         }

@@ -1,0 +1,383 @@
+"""Drop-in counterpart of the reference's ``smartVidCrop.py`` for the saliency-to-crop path.
+
+Same entry points, argument meaning, return values and result-file format:
+
+  sc_init_crop_params(print_dict=False, use_best_settings=False)      smartVidCrop.py:132-209
+  smart_vid_crop(video_path, CP=None, ...) -> (VD, smart_crop_results)  smartVidCrop.py:2218-2614
+  smartVidCrop = smart_vid_crop            (the spelling used in BASELINE.json)
+  smart_crop_version() -> '1.4.0'          smartVidCrop.py:2617-2618
+  bb_intersection_over_union(boxA, boxB)   smartVidCrop.py:927-944
+  write_results(...)                       result / info files, smartVidCrop.py:2777-2785
+
+What runs where: frame down-scale, UNISAL saliency, threshold, cluster filter, cut
+blend, centre of focus and IoU run on the MI355X through the C ABI in include/svc.h
+(retargetvid_amd.ops); frame selection, shot bookkeeping, empty-centre fill,
+interpolation, low-pass, LOESS and box arithmetic stay on the host
+(retargetvid_amd.temporal), as BASELINE.json's north_star prescribes.  There is no CPU
+fallback for the device stages: without a GPU and the built HIP library every call raises.
+
+Input door: the reference decodes video files with OpenCV/imutils and detects shots with
+TransNetV1; both stay outside this package.  ``video_path`` is therefore either a
+``.pkl`` written in the reference's ingest_pickle format (smartVidCrop.py:560-573: dict
+with fr, frame_count, w, h, frames [RGB uint8], trans_inds) or that dict itself.
+Failures raise exceptions; nothing blocks on input() (the reference does at :544-545).
+"""
+import math
+import pickle
+import time
+
+import numpy as np
+
+from . import temporal
+
+_ENGINE = None            # module-level singleton like the reference's unisal_model (:77)
+
+
+def get_engine(state_dict=None, seed=0):
+    """The process-wide device engine (weights + workspace).  Built on first use."""
+    global _ENGINE
+    if _ENGINE is None or state_dict is not None:
+        from . import ops
+        _ENGINE = ops.Engine(state_dict, seed=seed)
+    return _ENGINE
+
+
+def set_engine(engine):
+    global _ENGINE
+    _ENGINE = engine
+
+
+# ---- time registry (smartVidCrop.py:98-127) ------------------------------------------------
+sc_times = {}
+
+
+def sc_init_time():
+    global sc_times
+    sc_times = {}
+
+
+def sc_register_time(t, key_name):
+    sc_times[key_name] = sc_times.get(key_name, 0.0) + (time.perf_counter() - t)
+
+
+def sc_all_times(vid_dur):
+    t_dict, sum_t, sum_p = {}, 0.0, 0.0
+    for k, v in sc_times.items():
+        if k.startswith('_'):
+            sum_t += v
+            sum_p += (v / vid_dur) * 100.0
+        t_dict[k] = '%7.3fs, %6.3f%%' % (v, (v / vid_dur) * 100.0)
+    t_dict['total'] = '%7.3fs, %6.3f%%' % (sum_t, sum_p)
+    return t_dict
+
+
+# ---- parameters (smartVidCrop.py:132-209) ---------------------------------------------------
+def sc_init_crop_params(print_dict=False, use_best_settings=False):
+    crop_params = {
+        'out_ratio': '4:5', 'max_input_d': 250, 'skip': 6, 'read_batch': 2000,
+        'resize_factor': 1.0, 'resize_type': 1, 'op_close': True, 'value_bias': 1.0,
+        'exit_on_spread_sal': False, 'exit_on_low_cvrg': False, 'com_km': True, 'clust_filt': True,
+        'select_sum': 2, 'min_d_jump': 10, 'focus_stability': False, 'foces_stab_t': 60,
+        'foces_stab_s': 1.5, 'hdbscan_min': 26, 'hdbscan_min_samples': None, 'shift_time': 0,
+        'loess_filt': 1, 'loess_w_secs': 2, 'loess_degree': 2, 'lp_filt': 1, 'lp_cutoff': 2,
+        'lp_order': 5, 't_sal': 40, 't_cvrg': 0.60, 't_threshold': 120, 't_border': -1, 't_cut': 120,
+    }
+    if use_best_settings:
+        crop_params.update({
+            't_threshold': 90, 'hdbscan_min': 5, 'hdbscan_min_samples': 3, 'min_d_jump': 1,
+            'resize_factor': 4, 'op_close': True, 'value_bias': 1.0, 'select_sum': 1,
+            'focus_stability': True, 'foces_stab_t': 60, 'foces_stab_s': 1.5, 't_border': -1,
+            'lp_filt': 1, 'lp_cutoff': 1, 'lp_order': 2, 'loess_filt': 0})
+    if print_dict:
+        for k, v in crop_params.items():
+            print(k, ':', v)
+    return crop_params
+
+
+def smart_crop_version():
+    return '1.4.0'
+
+
+def bb_intersection_over_union(boxA, boxB):
+    """IoU of two [x1,y1,x2,y2] boxes (inclusive +1 convention) — evaluated by the svc_iou_i32
+    kernel; use retargetvid_amd.ops.iou_boxes for batches."""
+    from . import ops
+    return float(ops.iou_boxes(np.asarray([boxA], np.int32), np.asarray([boxB], np.int32))[0])
+
+
+# ---- geometry (host) ---------------------------------------------------------------------
+def sc_calc_dest_size(vid_data, crop_params, verbose=False):
+    """smartVidCrop.py:946-977."""
+    a, b = (float(v) for v in crop_params['out_ratio'].split(':'))
+    w, h = vid_data['w_orig'], vid_data['h_orig']
+    if abs(float(w) / float(h) - a / b) < 0.0000001:
+        vid_data['conversion_mode'], vid_data['w_final'], vid_data['h_final'] = 0, w, h
+    else:
+        vid_data['w_final'], vid_data['h_final'] = int(math.floor((a / b) * h)), h
+        vid_data['conversion_mode'] = 1
+        if vid_data['w_final'] > w or vid_data['h_final'] > h:
+            vid_data['w_final'], vid_data['h_final'] = w, int(math.floor((b / a) * w))
+            vid_data['conversion_mode'] = 2
+    if verbose:
+        print(' orig. (hxw): (%dx%d)' % (h, w))
+        print(' final (hxw): (%dx%d)' % (vid_data['h_final'], vid_data['w_final']))
+    return vid_data
+
+
+def sc_compute_bb(vid_data, crop_params, verbose=False):
+    """smartVidCrop.py:979-1048: centres (saliency-map pixels) -> [x1,y1,x2,y2] per frame."""
+    fw, fh = vid_data['w_orig'], vid_data['h_orig']
+    scale_h = float(vid_data['h_process']) / float(fh)
+    scale_w = float(vid_data['w_process']) / float(fw)
+    bt, bb, bl, br = (vid_data.get(k, 0) for k in ('border_t', 'border_b', 'border_l', 'border_r'))
+    xs, ys = vid_data['dxs'], vid_data['dys']
+    for i in range(vid_data['fc']):
+        xs[i] = int(xs[i] / scale_w)
+        ys[i] = int(ys[i] / scale_h)
+    bb_w, bb_h = vid_data['w_final'], vid_data['h_final']
+    fbb_w, fbb_h = bb_w, bb_h
+    if bb_h == fh:
+        fbb_h = bb_h - bt - bb
+        fbb_w = int((float(fbb_h) / float(bb_h)) * bb_w)
+    if bb_w == fw:
+        fbb_w = bb_w - bl - br
+        fbb_h = int((float(fbb_w) / float(bb_w)) * bb_h)
+    vid_data['fbb_w'], vid_data['fbb_h'] = fbb_w, fbb_h
+    hw1 = int(fbb_w / 2.0)
+    hw2 = fbb_w - hw1
+    hh1 = int(fbb_h / 2.0)
+    hh2 = fbb_h - hh1
+    out = []
+    for i in range(vid_data['fc']):
+        x1, y1, x2, y2 = xs[i] - hw1, ys[i] - hh1, xs[i] + hw2, ys[i] + hh2
+        if x1 < bl:
+            x1, x2 = bl, bl + fbb_w
+        if x2 > fw - br:
+            x2 = fw - br
+            x1 = x2 - fbb_w
+        if y1 < bt:
+            y1, y2 = bt, bt + fbb_h
+        if y2 > fh - bb:
+            y2 = fh - bb
+            y1 = y2 - fbb_h
+        out.append([x1, y1, x2, y2])
+    vid_data['bbs'] = out
+    return vid_data
+
+
+# ---- ingest (host bookkeeping + device saliency) ---------------------------------------------
+def _select_frames(n_frames, frame_count, trans_inds, skip, read_batch):
+    """Frame selection of ingest_pickle (smartVidCrop.py:621-718), including the
+    batch-local after-cut test (:683).  -> true_inds, map2orig, [(first, count)] per read batch."""
+    true_inds, map2orig, batches = [], [], []
+    total, after_cut = -1, False
+    trans = set(int(t) for t in trans_inds)
+    for b0 in range(0, n_frames, read_batch):
+        first = len(true_inds)
+        for i in range(min(read_batch, n_frames - b0)):
+            g = b0 + i
+            if (g == true_inds[-1] + skip if true_inds else True) or after_cut or g == frame_count - 1:
+                total += 1
+                true_inds.append(g)
+            after_cut = (i - 1) in trans
+            map2orig.append(total)
+        batches.append((first, len(true_inds) - first))
+    return true_inds, map2orig, batches
+
+
+def ingest_frames(video, crop_params, engine=None, verbose=False):
+    """Counterpart of ingest_pickle (smartVidCrop.py:560-836) for an in-memory video dict.
+    The down-scale to saliency size and the UNISAL forward run on the device.  Keeps the
+    reference's off-by-one: the last selected frame of each read batch gets an all-zero map."""
+    import torch
+    engine = engine or get_engine()
+    t = time.perf_counter()
+    fr, frame_count, w, h = video['fr'], int(video['frame_count']), int(video['w']), int(video['h'])
+    frames = video['frames']
+    n_frames = len(frames)
+    dsr = float(max(w, h)) / crop_params['max_input_d']
+    sal_h, sal_w = int(h / dsr), int(w / dsr)
+    trans_inds = [int(v) for v in video['trans_inds']]
+    true_inds, map2orig, batches = _select_frames(n_frames, frame_count, trans_inds, crop_params['skip'],
+                                                  crop_params['read_batch'])
+    sc_register_time(t, '_read_shot_det')
+    t = time.perf_counter()
+    n_sel = len(true_inds)
+    dev = engine.device
+    smaps = torch.zeros((n_sel, sal_h, sal_w), dtype=torch.uint8, device=dev)
+    for first, cnt in batches:
+        if cnt > 1:
+            idx = true_inds[first:first + cnt - 1]
+            if torch.is_tensor(frames):
+                sel = frames[torch.as_tensor(idx, device=frames.device)].to(dev)
+            else:
+                sel = torch.from_numpy(np.ascontiguousarray(np.asarray(frames)[idx])).to(dev)
+            small = engine.resize_frames(sel.contiguous(), sal_h, sal_w)
+            smaps[first:first + cnt - 1] = engine.saliency(small)
+    torch.cuda.synchronize(dev)
+    sc_register_time(t, '_read_sal_det')
+    scenes = []
+    for i in range(len(trans_inds)):
+        if frame_count - trans_inds[i] < 2:
+            break
+        if i + 1 < len(trans_inds):
+            scenes.append([trans_inds[i], trans_inds[i + 1] - 1])
+    if not scenes:
+        raise ValueError('trans_inds %r yields no scenes; pass at least [0, frame_count]' % (trans_inds,))
+    seg = np.array(scenes, dtype=np.int32)
+    seg_sel = np.array([[map2orig[v] for v in row] for row in seg], dtype=np.int32)
+    vid_data = dict(smaps_dev=smaps, segmentation=seg, segmentation_sel=seg_sel, true_inds=true_inds,
+                    inds_to_orig=map2orig, fr=fr, fc=n_frames, fc_sel=n_sel, h_orig=h, w_orig=w,
+                    h_process=sal_h, w_process=sal_w)
+    # the reference's sanity checks (:799-825), as exceptions
+    if vid_data['fc'] > frame_count or len(map2orig) != n_frames or seg[-1][-1] != n_frames - 1 or \
+            seg_sel[-1][-1] != n_sel - 1 or map2orig[-1] != n_sel - 1:
+        raise ValueError('inconsistent frame / segment bookkeeping (frame_count=%d, frames=%d, segmentation end=%d)'
+                         % (frame_count, n_frames, int(seg[-1][-1])))
+    return vid_data
+
+
+def blend_flags(fc_sel, segmentation_sel):
+    """Which maps are blended into their successor (smartVidCrop.py:2324-2327, :2369-2370)."""
+    cuts = set(int(s[0]) for s in segmentation_sel)
+    cuts.add(int(segmentation_sel[-1][1]))
+    flags = np.zeros(fc_sel, np.uint8)
+    for i in range(fc_sel):
+        if i < fc_sel - 2 and ((i - 1) in cuts or i in cuts or (i + 1) in cuts):
+            flags[i] = 1
+    return flags
+
+
+class _LazySmaps(dict):
+    """VD dict whose 'smaps' ([H,W,n] u8, the reference's layout) is materialised from the device
+    only when somebody asks for it."""
+
+    def __missing__(self, key):
+        if key == 'smaps' and 'smaps_dev' in self:
+            self['smaps'] = np.ascontiguousarray(self['smaps_dev'].permute(1, 2, 0).cpu().numpy())
+            return self['smaps']
+        raise KeyError(key)
+
+
+def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn='', frames_dir='',
+                   temp_path=None, verbose=False, save_vid=True, callback_progress=None,
+                   callback_session=None, callback_status=None, copy_sound=False, engine=None):
+    """Saliency -> crop windows for one video.  Returns (VD, smart_crop_results) like the
+    reference; VD['bbs'] holds one [x1,y1,x2,y2] per decoded frame."""
+    import torch
+    sc_init_time()
+    results = {}
+    if CP is None:
+        CP = sc_init_crop_params()
+    if CP['exit_on_spread_sal'] or CP['exit_on_low_cvrg'] or CP['t_border'] != -1:
+        raise NotImplementedError('mean-saliency / coverage gates and border detection are disabled in both '
+                                  'published parameter sets and are not part of this path')
+    if CP['resize_factor'] != 1.0 or CP['focus_stability'] or not CP['com_km']:
+        raise NotImplementedError('resize_factor != 1, focus_stability and com_km=False (use_best_settings) '
+                                  'are not implemented on the device path yet (SURVEY.md §8(f)-3)')
+    if save_vid and (final_vid_fn or demo_fn):
+        raise NotImplementedError('video rendering is outside the saliency-to-crop path; pass save_vid=False')
+    engine = engine or get_engine()
+    if callback_status is not None and callback_session is not None:
+        callback_status(callback_session, 'sc', 'SC VIDEO ANALYSIS', 'smart-cropping video analysis')
+    if isinstance(video_path, dict):
+        video = video_path
+    elif isinstance(video_path, str) and video_path.endswith('.pkl'):
+        with open(video_path, 'rb') as fp:
+            video = pickle.load(fp)
+    else:
+        raise NotImplementedError('decoding video files and TransNetV1 shot detection stay outside this '
+                                  'package: pass the ingest_pickle dict (fr, frame_count, w, h, frames, '
+                                  'trans_inds) or a .pkl holding it')
+    VD = _LazySmaps(ingest_frames(video, CP, engine, verbose=verbose))
+    if callback_status is not None and callback_session is not None:
+        callback_status(callback_session, 'sc', 'SC PROCESSING', 'smart-cropping main process')
+    VD['segm_backup'] = VD['segmentation'].copy()
+
+    t = time.perf_counter()
+    VD = sc_calc_dest_size(VD, CP, verbose=verbose)
+    sc_register_time(t, '_calc_dest_size')
+    t = time.perf_counter()
+    VD['border_t'] = VD['border_b'] = VD['border_l'] = VD['border_r'] = 0
+    sc_register_time(t, '_border_det')
+    VD['mean_sal_score'] = None
+    VD['mean_cvrg_score'] = None
+
+    maps = VD['smaps_dev']
+    t = time.perf_counter()
+    engine.threshold_(maps, CP['t_threshold'])
+    torch.cuda.synchronize(maps.device)
+    sc_register_time(t, '_thresh')
+
+    t = time.perf_counter()
+    flags = blend_flags(VD['fc_sel'], VD['segmentation_sel']) if CP['clust_filt'] else None
+    xy = engine.cluster_center_(maps, flags, CP).cpu().numpy()       # one D2H of n x 2 doubles
+    results['cuts_clust'] = 0
+    sc_register_time(t, '_clustering')
+
+    t = time.perf_counter()
+    VD['dx'] = [None if math.isnan(v) else float(v) for v in xy[:, 0]]
+    VD['dy'] = [None if math.isnan(v) else float(v) for v in xy[:, 1]]
+    sc_register_time(t, '_center_of_mass')
+
+    t = time.perf_counter()
+    VD['dx'], VD['dy'] = temporal.handle_empty_centers(VD['dx'], VD['dy'], VD['segmentation_sel'])
+    if any(v is None for v in VD['dx']):
+        raise ValueError('no saliency centre found in any selected frame')
+    sc_register_time(t, '_center_empty_handle')
+    VD['jumps'] = [255] * len(VD['dx'])
+    VD['jumps_inds'] = []
+    VD['dxnf'], VD['dynf'] = list(VD['dx']), list(VD['dy'])
+
+    t = time.perf_counter()
+    VD['dxi'], VD['dyi'] = temporal.interpolate(VD['dx'], VD['dy'], VD['segmentation'], VD['segmentation_sel'],
+                                                VD['true_inds'])
+    sc_register_time(t, '_interpolation')
+    t = time.perf_counter()
+    VD['dxs'], VD['dys'] = temporal.smoothing(VD['dxi'], VD['dyi'], VD['segmentation'], VD['fr'], CP)
+    sc_register_time(t, '_smooth')
+    t = time.perf_counter()
+    VD = sc_compute_bb(VD, CP, verbose=verbose)
+    sc_register_time(t, '_bb')
+    t = time.perf_counter()
+    if CP['shift_time'] > 0:
+        temporal.shift_time(VD['bbs'], CP['shift_time'])
+    sc_register_time(t, '_shift')
+    if callback_status is not None and callback_session is not None:
+        callback_status(callback_session, 'sc', 'SC RENDERING', 'smart-cropping rendering')
+
+    results['result'] = 'smart cropped'
+    results['info'] = ' (%dx%d)->(%dx%d)->(%dx%d)->(%dx%d)\n' % (
+        VD['h_orig'], VD['w_orig'], VD['h_process'], VD['w_process'], VD['h_final'], VD['w_final'],
+        VD['fbb_h'], VD['fbb_w'])
+    results['params'] = ''.join(' %-18s : %s\n' % (k, str(v)) for k, v in CP.items())
+    results['mean_sal_score'] = VD['mean_sal_score']
+    results['mean_sal_score_t'] = CP['t_sal']
+    results['coverage_score'] = VD['mean_cvrg_score']
+    results['coverage_score_t'] = CP['t_cvrg']
+    t_dict = sc_all_times(VD['fc'] / VD['fr'])
+    for k in t_dict:
+        if k.startswith('_'):
+            results['t_' + k] = t_dict[k]
+    for k in t_dict:
+        if not k.startswith('_'):
+            results['t_' + k] = t_dict[k]
+    return VD, results
+
+
+smartVidCrop = smart_vid_crop      # BASELINE.json's spelling of the entry point
+
+
+def write_results(results_out, vid_fn, out_ratio, vid_data, info_dict):
+    """The two files the evaluator reads (smartVidCrop.py:2730-2731, :2777-2785):
+    <vid>_<w>-<h>.txt with one 'x1,y1,x2,y2' line per frame, and <same>_info.txt with key:value lines."""
+    import os
+    os.makedirs(results_out, exist_ok=True)
+    suffix = vid_fn + '_' + str(out_ratio.replace(':', '-'))
+    with open(os.path.join(results_out, suffix + '_info.txt'), 'w') as fp:
+        for k in info_dict:
+            fp.write(k + ':' + str(info_dict[k]) + '\n')
+    with open(os.path.join(results_out, suffix + '.txt'), 'w') as fp:
+        for bb in vid_data['bbs']:
+            fp.write('%d,%d,%d,%d\n' % (bb[0], bb[1], bb[2], bb[3]))
+    return os.path.join(results_out, suffix + '.txt')

@@ -1,0 +1,141 @@
+"""Host-side temporal stages between per-frame centres and crop boxes.
+
+These stay on the host by design (BASELINE.json north_star: "TransNetV1 shot detection
+and LOESS smoothing stay on host").  Same results as the reference functions, written
+for speed where the reference is a Python loop (LOESS is evaluated for all frames of a
+shot at once with batched 3x3 pseudo-inverses instead of one ``Loess.estimate`` call per
+frame).
+
+Reference (smartVidCrop.py unless noted):
+  handle_empty_centers   sc_handle_empty_centers            :1221-1300
+  interpolate            interp_handler / sc_interpolate    :1528-1597
+  butter_lowpass         sc_butter_lowpass_filter           :1599-1627
+  loess / loess_handler  loess_handler :1629-1646 and 3rd_party_libs/loess/pyloess.py:13-95
+  smoothing              sc_smoothing                       :1648-1734
+  shift_time             sc_shift_time                      :1740-1746
+"""
+import numpy as np
+from scipy import interpolate as _interp, signal as _signal
+
+
+def handle_empty_centers(dx, dy, segmentation_sel):
+    """Fill runs of missing centres (None) from the nearest shot-consistent neighbour."""
+    dx, dy = list(dx), list(dy)
+    missing = np.array([v is None for v in dx], bool)
+    if not missing.any():
+        return dx, dy
+    starts = np.array([int(s[0]) for s in segmentation_sel])
+    ends = np.array([int(s[1]) for s in segmentation_sel])
+    edges = np.flatnonzero(np.diff(np.concatenate([[0], missing.view(np.int8), [0]])))
+    for lo, hi in zip(edges[0::2], edges[1::2] - 1):
+        d_start = int(np.min(np.abs(starts - lo)))
+        d_end = int(np.min(np.abs(ends - hi)))
+        src = hi + 1 if d_start < d_end else lo - 1        # a negative index wraps, as in the reference
+        for j in range(lo, hi + 1):
+            dx[j], dy[j] = dx[src], dy[src]
+    return dx, dy
+
+
+def _interp_segment(d, sampled_t, true_t):
+    n = len(d)
+    if n < 3:
+        return [float(d[0])] * len(true_t)
+    f = _interp.interp1d(sampled_t, d, fill_value='extrapolate', kind='linear' if n <= 6 else 'quadratic')
+    return list(f(true_t))
+
+
+def interpolate(dx, dy, segmentation, segmentation_sel, true_inds):
+    """Per shot: selected-frame centres -> one centre per decoded frame."""
+    dxi, dyi = [], []
+    for seg, sel in zip(segmentation, segmentation_sel):
+        si, ei = int(seg[0]), int(seg[1]) + 1
+        sis, eis = int(sel[0]), int(sel[1]) + 1
+        st = np.asarray(true_inds[sis:eis])
+        st = list(st - st.min())
+        tt = np.arange(0, ei - si)
+        dxi += _interp_segment(dx[sis:eis], st, tt)
+        dyi += _interp_segment(dy[sis:eis], st, tt)
+    return dxi, dyi
+
+
+def butter_lowpass(x, cutoff, fs, order):
+    """Zero-phase Butterworth low-pass with the reference's fall-back chain for short series."""
+    try:
+        b, a = _signal.butter(order, cutoff / (0.5 * fs), btype='lowpass', analog=False)
+        return _signal.filtfilt(b, a, x)
+    except Exception:
+        pass
+    for width in (5, 3):
+        try:
+            y = np.convolve(x, np.ones(width), 'same') / 5
+            x[2:len(x) - 2] = y[2:len(x) - 2]
+            return x
+        except Exception:
+            pass
+    return x
+
+
+def loess(y, window, degree):
+    """pyloess.Loess(arange(n), y).estimate(j, window, degree=degree) for every j, vectorised."""
+    y = np.asarray(y, np.float64)
+    n = y.shape[0]
+    ymin, ymax = y.min(), y.max()
+    with np.errstate(all='ignore'):
+        ny = (y - ymin) / (ymax - ymin)
+        nx = np.arange(n, dtype=np.float64) / (n - 1)
+        h = window // 2
+        j = np.arange(n)
+        # neighbourhood chosen by get_min_range: grow right on ties, clamp at the ends
+        lo = np.clip(j - h, 0, n - window)
+        idx = lo[:, None] + np.arange(window)[None, :]                # [n, window]
+        dist = np.abs(nx[idx] - nx[j][:, None])
+        r = dist / dist.max(axis=1, keepdims=True)
+        w = np.where((r >= -1) & (r <= 1), (1.0 - np.abs(r) ** 3) ** 3, 0.0)
+        if degree > 1:
+            xm = nx[idx][:, :, None] ** np.arange(degree + 1)[None, None, :]     # [n, window, d+1]
+            xtw = np.transpose(xm, (0, 2, 1)) * w[:, None, :]                    # X^T W
+            beta = np.linalg.pinv(xtw @ xm) @ xtw @ ny[idx][:, :, None]          # [n, d+1, 1]
+            xp = nx[j][:, None] ** np.arange(degree + 1)[None, :]
+            est = np.einsum('nd,nd->n', beta[:, :, 0], xp)
+        else:
+            sx, sy = nx[idx], ny[idx]
+            sw = w.sum(axis=1)
+            mx, my = (sx * w).sum(1) / sw, (sy * w).sum(1) / sw
+            b = ((sx * sy * w).sum(1) - mx * my * sw) / ((sx * sx * w).sum(1) - mx * mx * sw)
+            est = (my - b * mx) + b * nx[j]
+        return est * (ymax - ymin) + ymin
+
+
+def loess_handler(di, loess_filt, window, degree):
+    n = len(di)
+    if n < 10:
+        return list(di)
+    if loess_filt:
+        ds = loess(di, window, degree)
+        return list(di) if np.isnan(np.sum(ds)) else list(ds)
+    return list(_signal.savgol_filter(di, window, degree))
+
+
+def smoothing(dxi, dyi, segmentation, fr, CP):
+    """Per shot: low-pass then LOESS (or Savitzky-Golay).  -> (dxs, dys) over all frames."""
+    dxs, dys = [], []
+    for seg in segmentation:
+        si, ei = int(seg[0]), int(seg[1]) + 1
+        cl = ei - si
+        win = min(int(fr * CP['loess_w_secs']), cl - 2)
+        if win % 2 == 0:
+            win -= 1
+        for series, out in ((dxi, dxs), (dyi, dys)):
+            d = np.array(series[si:ei])
+            dl = butter_lowpass(d, CP['lp_cutoff'], fr, CP['lp_order']) if CP['lp_filt'] else d
+            out += loess_handler(dl, CP['loess_filt'], win, CP['loess_degree'])
+    return dxs, dys
+
+
+def shift_time(bbs, shift):
+    if shift > 0:
+        for i in range(shift):
+            bbs[-i + 1] = bbs[-1]
+        for i in range(len(bbs) - shift):
+            bbs[i] = bbs[i + shift]
+    return bbs

@@ -1,0 +1,178 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+Integer / byte stages must match bit for bit; the fp32 network within the stated tolerance."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cv_ref, hdbscan_ref as H, pipeline_ref as P, tail_ref as T, unisal_ref as U
+from retargetvid_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_tail(maps, flags, CP):
+    """Oracle: threshold -> (filter, blend) loop -> centres on [n,h,w] u8."""
+    ref = maps.copy()
+    T.threshold(ref, CP['t_threshold'])
+    hwn = np.ascontiguousarray(np.transpose(ref, (1, 2, 0)))
+    npts = []
+    for i in range(hwn.shape[2]):
+        info = {}
+        hwn[:, :, i] = T.clustering_filt(hwn[:, :, i], CP, info) if CP['clust_filt'] else hwn[:, :, i]
+        npts.append(info.get('n_points', 0))
+        if i + 1 < hwn.shape[2] and flags is not None and flags[i]:
+            hwn[:, :, i + 1] = T.blend_next(hwn[:, :, i], hwn[:, :, i + 1])
+    dx, dy = T.centers(hwn, CP)
+    return np.transpose(hwn, (2, 0, 1)), dx, dy, npts
+
+
+def _check_tail(engine, maps, flags, CP):
+    ref_maps, dx, dy, _ = _ref_tail(maps, flags, CP)
+    dm = torch.from_numpy(maps.copy()).cuda()
+    engine.threshold_(dm, CP['t_threshold'])
+    xy, stats = engine.cluster_center_(dm, flags, CP, want_stats=True)
+    got, xy = dm.cpu().numpy(), xy.cpu().numpy()
+    assert np.array_equal(got, ref_maps)
+    for i in range(maps.shape[0]):
+        if dx[i] is None:
+            assert np.isnan(xy[i]).all()
+        else:
+            assert xy[i, 0] == dx[i] and xy[i, 1] == dy[i]          # exact: integer sums / count in float64
+    return stats.cpu().numpy()
+
+
+def test_ingest_resize_bit_exact(engine):
+    for (h, w, sh, sw) in [(360, 640, 140, 250), (1080, 1920, 140, 250), (480, 640, 187, 250), (37, 53, 20, 31)]:
+        fr = np.random.RandomState(h).randint(0, 256, (2, h, w, 3)).astype(np.uint8)
+        got = engine.resize_frames(torch.from_numpy(fr).cuda(), sh, sw).cpu().numpy()
+        ref = np.stack([cv_ref.resize_linear_u8(f, sh, sw) for f in fr])
+        assert np.array_equal(got, ref)
+
+
+def test_saliency_against_oracle_and_reference_golden(engine, synthetic_sd, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'unisal_golden.npz'))
+    frames = g['frames']
+    maps = engine.saliency(torch.from_numpy(frames).cuda()).cpu().numpy()
+    taps = {}
+    ref = U.saliency_u8(synthetic_sd, frames, taps)
+    t = taps['frames'][0]
+    assert np.array_equal(engine.tap(ops.TAP_INPUT, 0, (256, 416, 3)), t['input'][0].permute(1, 2, 0).numpy())   # K0 bit-exact
+    # fp32 tolerance: 2e-4 of the tensor's max magnitude (accumulation order differs from the CPU)
+    for which, shape, key in [(ops.TAP_FEAT4X, (32, 52, 64), 'feat_4x'), (ops.TAP_FEAT2X, (16, 26, 160), 'feat_2x'),
+                              (ops.TAP_POSTCNN, (8, 13, 256), 'post_cnn'), (ops.TAP_DEC, (32, 52, 64), 'dec')]:
+        r = t[key][0].permute(1, 2, 0).numpy()
+        assert np.abs(engine.tap(which, 0, shape) - r).max() <= 2e-4 * np.abs(r).max(), key
+    f1 = engine.tap(ops.TAP_FEAT1X, 0, (8, 13, 1296))
+    r = t['feat_1x'][0].permute(1, 2, 0).numpy()
+    assert np.abs(f1[:, :, :1280] - r).max() <= 2e-4 * np.abs(r).max()
+    assert np.abs(engine.tap(ops.TAP_PRE, 0, (140, 250)) - t['pre'][0].numpy()).max() < 1e-4
+    # u8 maps: |diff| <= 1 on < 0.1 % of the pixels, against the oracle AND the reference model's own output
+    for r8 in (ref, g['smaps_u8']):
+        d = np.abs(np.transpose(maps, (1, 2, 0)).astype(int) - r8.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+def test_saliency_other_aspect_ratio(engine, synthetic_sd):
+    fr = synth.blob_frames(2, 187, 250, seed=4)           # 4:3 -> network 288x384
+    assert U.get_optimal_out_size((187, 250)) == (288, 384)
+    maps = engine.saliency(torch.from_numpy(fr).cuda()).cpu().numpy()
+    ref = U.saliency_u8(synthetic_sd, fr)
+    d = np.abs(np.transpose(maps, (1, 2, 0)).astype(int) - ref.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+def test_saliency_batch_and_chunk_independence(engine):
+    fr = torch.from_numpy(synth.blob_frames(40, 140, 250, seed=9)).cuda()      # 40 > default chunk of 32
+    full = engine.saliency(fr)
+    assert torch.equal(engine.saliency(fr[3:4])[0], full[3])
+    assert torch.equal(engine.saliency(fr[33:40]), full[33:40])
+
+
+def test_tail_bit_exact_default_settings(engine, golden_dir):
+    CP = P.init_crop_params()
+    g = np.load(os.path.join(golden_dir, 'unisal_golden.npz'))
+    base = np.transpose(g['smaps_u8'], (2, 0, 1)).copy()
+    rng = np.random.RandomState(3)
+    extra = [np.zeros((140, 250), np.uint8)]                                          # empty -> None
+    m = np.zeros((140, 250), np.uint8); m[10:13, 10:14] = 200; extra.append(m)        # 12 points: unclustered, unclosed
+    m = np.zeros((140, 250), np.uint8); m[3:6, 3:12] = 200; extra.append(m)           # exactly hdbscan_min + 1
+    m = np.zeros((140, 250), np.uint8); m[3:6, 3:12] = 200; m[8, 3] = 130; extra.append(m)   # hdbscan_min + 2
+    m = (rng.rand(140, 250) < 0.03) * rng.randint(120, 256, (140, 250)); m[50:80, 100:160] = 250
+    extra.append(m.astype(np.uint8))                                                  # speckle + block
+    m = base[1].copy(); m[m < 60] = 0; extra.append(m)                                # large regions
+    extra.append(np.full((140, 250), 200, np.uint8))                                  # every pixel set: N = 35000
+    maps = np.concatenate([base, np.stack(extra)])
+    flags = np.zeros(len(maps), np.uint8)
+    flags[[0, 1, 5, 8]] = 1                                                           # blend chains 0->1->2, 5->6, 8->9
+    stats = _check_tail(engine, maps, flags, CP)
+    assert stats[4, 0] == 0 and stats[5, 0] == 12 and stats[-1, 0] > 12 * 1024
+    # intermediate state of one map: core distances and the MST in Prim order
+    st = engine.cluster_state(3, 35000)
+    X = np.stack([st['pts'] & 255, (st['pts'] >> 8) & 255], 1).astype(np.int64)
+    core = H.core_distances(X, H.effective_min_samples(len(X), 26, None))
+    assert np.array_equal(core, st['core'])
+    assert np.array_equal(np.stack(H.prim_mst(X, core), 1), st['mst'])
+
+
+def test_tail_bit_exact_other_parameters(engine):
+    rng = np.random.RandomState(5)
+    maps = []
+    for s in range(6):
+        m = np.zeros((140, 250), np.uint8)
+        for _ in range(rng.randint(1, 5)):
+            cy, cx, ry, rx = rng.randint(15, 125), rng.randint(20, 230), rng.randint(4, 14), rng.randint(4, 20)
+            ys, xs = np.mgrid[0:140, 0:250]
+            blob = (((ys - cy) / ry) ** 2 + ((xs - cx) / rx) ** 2) < 1
+            m[blob] = rng.randint(90, 256)
+        m[rng.rand(140, 250) < 0.004] = rng.randint(90, 256)
+        maps.append(m)
+    maps = np.stack(maps)
+    best = dict(P.init_crop_params(), t_threshold=90, hdbscan_min=5, hdbscan_min_samples=3, select_sum=1)
+    _check_tail(engine, maps, None, best)
+    _check_tail(engine, maps, np.array([1, 0, 1, 1, 0, 0], np.uint8), dict(P.init_crop_params(), op_close=False))
+    _check_tail(engine, maps, None, dict(P.init_crop_params(), clust_filt=False))
+    _check_tail(engine, maps, None, dict(P.init_crop_params(), hdbscan_min=40, hdbscan_min_samples=10))
+
+
+def test_tail_ragged_sizes_and_sparse_points(engine):
+    rng = np.random.RandomState(8)
+    CP = P.init_crop_params()
+    for (h, w) in [(187, 250), (250, 140), (33, 47)]:
+        m = np.zeros((3, h, w), np.uint8)
+        m[0, h // 4:h // 2, w // 4:w // 2] = 200
+        m[1][rng.rand(h, w) < 0.02] = 180              # sparse: core distances beyond the ring table
+        m[2, :, :] = (rng.rand(h, w) < 0.5) * 150
+        _check_tail(engine, m, np.array([0, 1, 0], np.uint8), CP)
+
+
+def test_tail_batch_independence_at_full_size(engine):
+    """Size-independent property at BASELINE config 2 (B=32, 640x360): every map's result is
+    independent of the batch it is processed in, and filtering only ever removes/closes."""
+    CP = P.init_crop_params()
+    fr = torch.from_numpy(synth.blob_frames(32, 360, 640, seed=0)).cuda()
+    maps = engine.saliency(engine.resize_frames(fr, 140, 250))
+    engine.threshold_(maps, CP['t_threshold'])
+    thr = maps.clone()
+    xy = engine.cluster_center_(maps, None, CP)
+    for i in (0, 7, 31):
+        one = thr[i:i + 1].clone()
+        xy1 = engine.cluster_center_(one, None, CP)
+        assert torch.equal(one[0], maps[i]) and torch.equal(xy1[0], xy[i])
+    t = thr.cpu().numpy()
+    closed = np.stack([cv_ref.morph_close_5x5(x) for x in t])
+    assert (maps.cpu().numpy() <= closed).all()
+    xyc = xy.cpu().numpy()
+    assert (xyc[:, 0] >= 0).all() and (xyc[:, 0] <= 249).all() and (xyc[:, 1] >= 0).all() and (xyc[:, 1] <= 139).all()
+
+
+def test_iou_bit_exact(engine):
+    rng = np.random.RandomState(0)
+    a = rng.randint(-5, 600, (5000, 4)).astype(np.int32); a[:, 2:] += np.abs(a[:, :2])
+    b = rng.randint(-5, 600, (5000, 4)).astype(np.int32); b[:, 2:] += np.abs(b[:, :2])
+    got = ops.iou_boxes(a, b)
+    ref = np.array([T.iou(x, y) for x, y in zip(a.tolist(), b.tolist())])
+    assert np.array_equal(got, ref)
+    from retargetvid_amd import smartVidCrop as S
+    assert S.bb_intersection_over_union([0, 0, 9, 9], [5, 0, 14, 9]) == T.iou([0, 0, 9, 9], [5, 0, 14, 9])

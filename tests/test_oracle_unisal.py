@@ -1,0 +1,59 @@
+"""Pins oracle/unisal_ref.py and oracle/lanczos_ref.py to outputs of the REFERENCE model code
+(tests/golden/unisal_golden.npz, made by tools/make_golden_unisal.py) and of Pillow."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import lanczos_ref, unisal_ref as U
+
+
+def test_optimal_out_size():
+    assert U.get_optimal_out_size((140, 250)) == (256, 416)      # 16:9 -> (8,13)*32, SURVEY fact 3
+    assert U.get_optimal_out_size((360, 640)) == (256, 416)
+    assert U.get_optimal_out_size((250, 250)) == (320, 320)
+    assert U.get_optimal_out_size((250, 140)) == (416, 256)
+
+
+def test_lanczos_matches_pillow_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'lanczos_golden.npz'))
+    for i in range(4):
+        a, ref = g['in_%d' % i], g['out_%d' % i]
+        got = lanczos_ref.resize_lanczos_u8(a, ref.shape[0], ref.shape[1])
+        assert np.array_equal(got, ref), 'case %d differs from Pillow %s' % (i, g['pillow_version'])
+
+
+def test_lanczos_matches_installed_pillow():
+    PIL = __import__('pytest').importorskip('PIL.Image')
+    a = np.random.RandomState(1).randint(0, 256, (140, 250, 3)).astype(np.uint8)
+    ref = np.asarray(PIL.fromarray(a).resize((416, 256), PIL.LANCZOS))
+    assert np.array_equal(lanczos_ref.resize_lanczos_u8(a, 256, 416), ref)
+
+
+def test_forward_matches_reference_model(golden_dir, synthetic_sd):
+    torch.set_num_threads(1)             # the golden was generated single-threaded
+    g = np.load(os.path.join(golden_dir, 'unisal_golden.npz'))
+    frames = g['frames']
+    taps = {}
+    maps = U.saliency_u8(synthetic_sd, frames, taps)
+    assert maps.shape == (140, 250, frames.shape[0]) and maps.dtype == np.uint8
+    t0 = taps['frames'][0]
+    assert np.array_equal(t0['input'][0].numpy(), g['input_0'])
+    for k in ('feat_1x', 'feat_2x', 'feat_4x', 'post_cnn'):
+        ref = g[k + '_0']
+        assert np.abs(t0[k][0].numpy() - ref).max() <= 1e-4 * np.abs(ref).max(), k
+    d = np.abs(maps.astype(int) - g['smaps_u8'].astype(int))
+    # same torch ops as the reference: identical up to thread-count dependent summation order
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    for i in range(frames.shape[0]):
+        lp = torch.log_softmax(taps['frames'][i]['pre'].reshape(1, -1), 1).reshape(140, 250).numpy()
+        assert np.abs(lp - g['logp_%d' % i]).max() < 1e-4
+
+
+def test_quantise_is_floor_of_scaled_softmax():
+    x = torch.randn(2, 140, 250)
+    q = U.quantise_u8(x)
+    m = x.reshape(2, -1).max(1).values.reshape(2, 1, 1)
+    approx = np.floor(255.0 * torch.exp(x - m).double().numpy())
+    assert np.abs(q.astype(int) - approx).max() <= 1
+    assert q.max() == 255

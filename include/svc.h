@@ -89,6 +89,27 @@ int svc_cluster_center(SvcHandle *h, uint8_t *maps_nhw, int n, int height, int w
 /* a[n][4], b[n][4] int32 boxes (x1,y1,x2,y2) -> out[n] float64 IoU, inclusive +1 pixel convention. */
 int svc_iou_i32(const int32_t *a, const int32_t *b, size_t n, double *out, void *stream);
 
+/* Measurement door (bench.py): record HIP events around every launch of one kernel class on
+ * the stream it is launched on.  kernel_class = one of SVC_K_*, or -1 to switch recording off.
+ * svc_profile_read synchronises the device, returns the summed duration (ms) and the number
+ * of launches recorded since the last read, and resets the log.  Nothing like it exists in the
+ * reference (its timers are host wall-clock accumulators, smartVidCrop.py:98-127). */
+#define SVC_K_RESIZE 0
+#define SVC_K_LANCZOS 1
+#define SVC_K_STEM 2
+#define SVC_K_PW 3
+#define SVC_K_DW 4
+#define SVC_K_RESAMPLE 5   /* subsample / upsample / gauss fill / adapt */
+#define SVC_K_SMOOTH 6     /* k_smooth_down + k_quantise */
+#define SVC_K_THRESHOLD 7
+#define SVC_K_COMPACT 8
+#define SVC_K_CORE 9
+#define SVC_K_PRIM 10
+#define SVC_K_FINISH 11
+#define SVC_K_COUNT 12
+int svc_profile_enable(SvcHandle *h, int kernel_class);
+int svc_profile_read(SvcHandle *h, double *total_ms, int *launches);
+
 /* Test/diagnostic door: copy internal per-frame clustering state of the LAST
  * svc_cluster_center call to HOST buffers (any may be NULL).  Synchronises.
  *   pts_host[cap]   packed points: row | col<<8 | value<<16, raster order

@@ -10,7 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsvc_hip.so')
 
 EXPORTS = ('svc_last_error', 'svc_create', 'svc_destroy', 'svc_resize_frames_u8', 'svc_saliency_u8',
-           'svc_threshold_u8', 'svc_cluster_center', 'svc_iou_i32', 'svc_debug_cluster_state', 'svc_debug_tap')
+           'svc_threshold_u8', 'svc_cluster_center', 'svc_iou_i32', 'svc_debug_cluster_state', 'svc_debug_tap',
+           'svc_profile_enable', 'svc_profile_read')
 
 
 class SvcParams(ctypes.Structure):
@@ -46,6 +47,8 @@ def load():
     lib.svc_iou_i32.argtypes = [vp, vp, sz, vp, vp]
     lib.svc_debug_cluster_state.argtypes = [vp, i32, i32, vp, vp, vp, vp]
     lib.svc_debug_tap.argtypes = [vp, i32, i32, vp, sz]
+    lib.svc_profile_enable.argtypes = [vp, i32]
+    lib.svc_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     for name in EXPORTS:
         if name != 'svc_last_error':
             getattr(lib, name).restype = i32

@@ -81,6 +81,18 @@ struct SvcHandle {
     int tail_frames = 0, tail_h = 0, tail_w = 0;
     size_t tail_frame_stride = 0;      // bytes of per-frame tail workspace
     int chunk = 32;                    // frames per network pass
+    // per-kernel-class event log (svc_profile_*)
+    int prof_class = -1;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+};
+
+// Records an event pair around the launches in its scope when the class is being profiled.
+struct ProfScope {
+    SvcHandle *h; hipStream_t s; bool on; hipEvent_t a, b;
+    ProfScope(SvcHandle *h_, int cls, hipStream_t s_) : h(h_), s(s_), on(h_->prof_class == cls) {
+        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
+    }
+    ~ProfScope() { if (on) { (void)hipEventRecord(b, s); h->prof_events.emplace_back(a, b); } }
 };
 
 int svc_net_release(SvcHandle *h);

@@ -121,6 +121,7 @@ extern "C" int svc_resize_frames_u8(SvcHandle *h, const uint8_t *frames, int n, 
         it = h->cvtabs.emplace(key, buf).first;
     }
     size_t total = (size_t)n * sh * sw;
+    ProfScope ps(h, SVC_K_RESIZE, (hipStream_t)stream);
     k_cv_resize<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
         frames, out, (const int *)it->second.p, n, height, width, sh, sw);
     SVC_CHECK_LAUNCH();
@@ -650,8 +651,9 @@ int svc_net_release(SvcHandle *h) {
 // --------------------------------------------------------------------------------------
 static inline unsigned blocks256(size_t total) { return (unsigned)((total + 255) / 256); }
 
-static int launch_pw(hipStream_t s, const float *X, int ldx, const SvcLayer &L, const float *R, int ldr, float *Y,
-                     int ldy, int M) {
+static int launch_pw(SvcHandle *h, hipStream_t s, const float *X, int ldx, const SvcLayer &L, const float *R, int ldr,
+                     float *Y, int ldy, int M) {
+    ProfScope ps(h, SVC_K_PW, s);
     const int N = L.cout, K = L.cin, Npad = (N + 31) / 32 * 32, tiles = Npad / 32;
     const int rb = ceil_div(M, 128);
     int TN = 4;
@@ -669,7 +671,9 @@ static int launch_pw(hipStream_t s, const float *X, int ldx, const SvcLayer &L, 
     return SVC_OK;
 }
 
-static int launch_dw(hipStream_t s, const float *X, const SvcLayer &L, float *Y, int n, int H, int W, int stride) {
+static int launch_dw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer &L, float *Y, int n, int H, int W,
+                     int stride) {
+    ProfScope ps(h, SVC_K_DW, s);
     const int C = L.cout, OH = stride == 2 ? H / 2 : H, OW = stride == 2 ? W / 2 : W;
     size_t total = (size_t)n * OH * OW * (C / 4);
     if (stride == 2)
@@ -692,6 +696,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     float *IN = p->buf(B_IN), *P[2] = {p->buf(B_P0), p->buf(B_P1)}, *E0 = p->buf(B_E0), *E1 = p->buf(B_E1);
     // K0
     {
+        ProfScope ps(h, SVC_K_LANCZOS, s);
         dim3 grid(ceil_div(NH, p->lz_rows), n);
         size_t lds = (size_t)p->lz_tile_cap * NW * 3;
         k_lanczos_norm<<<grid, 256, lds, s>>>(frames, IN, p->h, p->w, NH, NW, (const int *)p->hb.p, (const int *)p->hk.p,
@@ -701,6 +706,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     }
     // stem
     {
+        ProfScope ps(h, SVC_K_STEM, s);
         const SvcLayer &L = next();
         k_stem<<<blocks256((size_t)n * H * W * 8), 256, 0, s>>>(IN, L.w.dev, L.b.dev, P[0], n, NH, NW, H, W);
         SVC_CHECK_LAUNCH();
@@ -719,15 +725,16 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
             const float *x = P[cur];
             const float *dwin = x;
             if (t != 1) {
-                RC(launch_pw(s, x, inp, next(), nullptr, 0, E0, inp * t, n * H * W));
+                RC(launch_pw(h, s, x, inp, next(), nullptr, 0, E0, inp * t, n * H * W));
                 dwin = E0;
             }
             const SvcLayer &Ld = next();
-            RC(launch_dw(s, dwin, Ld, E1, n, H, W, dws));
+            RC(launch_dw(h, s, dwin, Ld, E1, n, H, W, dws));
             int OH = H / dws, OW = W / dws;
             float *y = tap ? p->buf(idx == 7 ? B_F4X : B_F2X) : P[cur ^ 1];
-            RC(launch_pw(s, E1, inp * t, next(), res ? x : nullptr, oup, y, oup, n * OH * OW));
+            RC(launch_pw(h, s, E1, inp * t, next(), res ? x : nullptr, oup, y, oup, n * OH * OW));
             if (tap) {
+                ProfScope ps(h, SVC_K_RESAMPLE, s);
                 k_subsample<<<blocks256((size_t)n * (OH / 2) * (OW / 2) * (oup / 4)), 256, 0, s>>>(y, P[cur ^ 1], n, OH,
                                                                                                   OW, oup);
                 SVC_CHECK_LAUNCH();
@@ -740,39 +747,52 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     // features.18 -> CAT1[:, 0:1280], Gaussian maps -> CAT1[:, 1280:1296]
     const int H5 = H, W5 = W, H4 = 2 * H5, W4 = 2 * W5, H3 = 4 * H5, W3 = 4 * W5;
     float *CAT1 = p->buf(B_CAT1);
-    RC(launch_pw(s, P[cur], 320, next(), nullptr, 0, CAT1, 1296, n * H5 * W5));
+    RC(launch_pw(h, s, P[cur], 320, next(), nullptr, 0, CAT1, 1296, n * H5 * W5));
     // skips (model.py:443-444)
     float *CAT2 = p->buf(B_CAT2), *CAT3 = p->buf(B_CAT3);
-    RC(launch_pw(s, p->buf(B_F2X), 160, next(), nullptr, 0, p->buf(B_S2E), 320, n * H4 * W4));
-    RC(launch_pw(s, p->buf(B_S2E), 320, next(), nullptr, 0, CAT2 + 256, 384, n * H4 * W4));
-    RC(launch_pw(s, p->buf(B_F4X), 64, next(), nullptr, 0, p->buf(B_S4E), 128, n * H3 * W3));
-    RC(launch_pw(s, p->buf(B_S4E), 128, next(), nullptr, 0, CAT3 + 128, 192, n * H3 * W3));
+    RC(launch_pw(h, s, p->buf(B_F2X), 160, next(), nullptr, 0, p->buf(B_S2E), 320, n * H4 * W4));
+    RC(launch_pw(h, s, p->buf(B_S2E), 320, next(), nullptr, 0, CAT2 + 256, 384, n * H4 * W4));
+    RC(launch_pw(h, s, p->buf(B_F4X), 64, next(), nullptr, 0, p->buf(B_S4E), 128, n * H3 * W3));
+    RC(launch_pw(h, s, p->buf(B_S4E), 128, next(), nullptr, 0, CAT3 + 128, 192, n * H3 * W3));
     next();   // GAUSS placeholder layer (raw parameters; maps live in plan->gauss)
-    k_gauss_fill<<<blocks256((size_t)n * H5 * W5 * 16), 256, 0, s>>>((const float *)p->gauss.p, CAT1, n, H5 * W5, 1296,
-                                                                     1280);
-    SVC_CHECK_LAUNCH();
+    {
+        ProfScope ps(h, SVC_K_RESAMPLE, s);
+        k_gauss_fill<<<blocks256((size_t)n * H5 * W5 * 16), 256, 0, s>>>((const float *)p->gauss.p, CAT1, n, H5 * W5,
+                                                                         1296, 1280);
+        SVC_CHECK_LAUNCH();
+    }
     // post_cnn
-    RC(launch_dw(s, CAT1, next(), p->buf(B_PCD), n, H5, W5, 1));
-    RC(launch_pw(s, p->buf(B_PCD), 1296, next(), nullptr, 0, p->buf(B_PC), 256, n * H5 * W5));
+    RC(launch_dw(h, s, CAT1, next(), p->buf(B_PCD), n, H5, W5, 1));
+    RC(launch_pw(h, s, p->buf(B_PCD), 1296, next(), nullptr, 0, p->buf(B_PC), 256, n * H5 * W5));
     // US1 + concat, US2 block
-    k_upsample2x<<<blocks256((size_t)n * H4 * W4 * 64), 256, 0, s>>>(p->buf(B_PC), CAT2, n, H5, W5, 256, 384);
-    SVC_CHECK_LAUNCH();
-    RC(launch_pw(s, CAT2, 384, next(), nullptr, 0, p->buf(B_U2E), 768, n * H4 * W4));
-    RC(launch_dw(s, p->buf(B_U2E), next(), p->buf(B_U2D), n, H4, W4, 1));
-    RC(launch_pw(s, p->buf(B_U2D), 768, next(), nullptr, 0, p->buf(B_U2), 128, n * H4 * W4));
-    k_upsample2x<<<blocks256((size_t)n * H3 * W3 * 32), 256, 0, s>>>(p->buf(B_U2), CAT3, n, H4, W4, 128, 192);
-    SVC_CHECK_LAUNCH();
-    RC(launch_pw(s, CAT3, 192, next(), nullptr, 0, p->buf(B_P3E), 384, n * H3 * W3));
-    RC(launch_dw(s, p->buf(B_P3E), next(), p->buf(B_P3D), n, H3, W3, 1));
-    RC(launch_pw(s, p->buf(B_P3D), 384, next(), nullptr, 0, p->buf(B_DEC), 64, n * H3 * W3));
+    {
+        ProfScope ps(h, SVC_K_RESAMPLE, s);
+        k_upsample2x<<<blocks256((size_t)n * H4 * W4 * 64), 256, 0, s>>>(p->buf(B_PC), CAT2, n, H5, W5, 256, 384);
+        SVC_CHECK_LAUNCH();
+    }
+    RC(launch_pw(h, s, CAT2, 384, next(), nullptr, 0, p->buf(B_U2E), 768, n * H4 * W4));
+    RC(launch_dw(h, s, p->buf(B_U2E), next(), p->buf(B_U2D), n, H4, W4, 1));
+    RC(launch_pw(h, s, p->buf(B_U2D), 768, next(), nullptr, 0, p->buf(B_U2), 128, n * H4 * W4));
+    {
+        ProfScope ps(h, SVC_K_RESAMPLE, s);
+        k_upsample2x<<<blocks256((size_t)n * H3 * W3 * 32), 256, 0, s>>>(p->buf(B_U2), CAT3, n, H4, W4, 128, 192);
+        SVC_CHECK_LAUNCH();
+    }
+    RC(launch_pw(h, s, CAT3, 192, next(), nullptr, 0, p->buf(B_P3E), 384, n * H3 * W3));
+    RC(launch_dw(h, s, p->buf(B_P3E), next(), p->buf(B_P3D), n, H3, W3, 1));
+    RC(launch_pw(h, s, p->buf(B_P3D), 384, next(), nullptr, 0, p->buf(B_DEC), 64, n * H3 * W3));
     // adaptation, smoothing, resize, quantise
     const SvcLayer &La = next();
-    k_adapt<<<blocks256((size_t)n * H3 * W3), 256, 0, s>>>(p->buf(B_DEC), La.w.dev, La.b.dev, p->buf(B_LOGIT),
-                                                          (size_t)n * H3 * W3);
-    SVC_CHECK_LAUNCH();
+    {
+        ProfScope ps(h, SVC_K_RESAMPLE, s);
+        k_adapt<<<blocks256((size_t)n * H3 * W3), 256, 0, s>>>(p->buf(B_DEC), La.w.dev, La.b.dev, p->buf(B_LOGIT),
+                                                              (size_t)n * H3 * W3);
+        SVC_CHECK_LAUNCH();
+    }
     // B_LOGIT per-frame stride may exceed H3*W3 (rounded to 4): compact layout is used instead
     const SvcLayer &Ls = next();
     SVC_HIP(hipMemsetAsync(p->fmax.p, 0, (size_t)n * sizeof(unsigned), s));
+    ProfScope ps_smooth(h, SVC_K_SMOOTH, s);
     {
         dim3 grid(ceil_div(p->h, p->sd_rows), n);
         size_t lds = ((size_t)H3 * W3 + 64 * 49 + (size_t)p->sd_tile_cap * NW) * sizeof(float);
@@ -935,9 +955,35 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     return SVC_OK;
 }
 
+extern "C" int svc_profile_enable(SvcHandle *h, int kernel_class) {
+    if (!h || kernel_class < -1 || kernel_class >= SVC_K_COUNT) { svc_set_error("svc_profile_enable: invalid argument"); return SVC_E_INVALID; }
+    h->prof_class = kernel_class;
+    return SVC_OK;
+}
+
+extern "C" int svc_profile_read(SvcHandle *h, double *total_ms, int *launches) {
+    if (!h || !total_ms || !launches) { svc_set_error("svc_profile_read: invalid argument"); return SVC_E_INVALID; }
+    SVC_HIP(hipSetDevice(h->device));
+    SVC_HIP(hipDeviceSynchronize());
+    double tot = 0.0;
+    for (auto &e : h->prof_events) {
+        float ms = 0.f;
+        SVC_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+        tot += ms;
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    *total_ms = tot;
+    *launches = (int)h->prof_events.size();
+    h->prof_events.clear();
+    return SVC_OK;
+}
+
 extern "C" int svc_destroy(SvcHandle *h) {
     if (!h) return SVC_OK;
     (void)hipSetDevice(h->device);
+    for (auto &e : h->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    h->prof_events.clear();
     svc_net_release(h);
     h->tail_ws.release();
     h->tail_offsets.release();

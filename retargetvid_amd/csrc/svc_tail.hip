@@ -584,6 +584,7 @@ extern "C" int svc_threshold_u8(SvcHandle *h, uint8_t *maps, size_t n_bytes, int
     if (!h || !maps) { svc_set_error("svc_threshold_u8: invalid argument"); return SVC_E_INVALID; }
     if (n_bytes == 0) return SVC_OK;
     SVC_HIP(hipSetDevice(h->device));
+    ProfScope ps(h, SVC_K_THRESHOLD, (hipStream_t)stream);
     k_threshold<<<(unsigned)((n_bytes + 4095) / 4096), 256, 0, (hipStream_t)stream>>>(maps, n_bytes, t);
     SVC_CHECK_LAUNCH();
     return SVC_OK;
@@ -674,14 +675,22 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
             k_blend<<<dim3(8, n), 256, 0, s>>>(maps, depth_dev, r, hw);
             SVC_CHECK_LAUNCH();
         }
-        k_compact<<<n, TB, 0, s>>>(A);
-        SVC_CHECK_LAUNCH();
-        if (params->clust_filt) {
-            k_core<<<n, TB, lds_core, s>>>(A);
+        {
+            ProfScope ps(h, SVC_K_COMPACT, s);
+            k_compact<<<n, TB, 0, s>>>(A);
             SVC_CHECK_LAUNCH();
+        }
+        if (params->clust_filt) {
+            {
+                ProfScope ps(h, SVC_K_CORE, s);
+                k_core<<<n, TB, lds_core, s>>>(A);
+                SVC_CHECK_LAUNCH();
+            }
+            ProfScope ps(h, SVC_K_PRIM, s);
             k_prim<<<n, TB, lds_prim, s>>>(A);
             SVC_CHECK_LAUNCH();
         }
+        ProfScope ps(h, SVC_K_FINISH, s);
         k_finish<<<n, TB, lds_fin, s>>>(A);
         SVC_CHECK_LAUNCH();
     }

@@ -103,6 +103,21 @@ class Engine:
             ctypes.byref(p), _ptr(xy), _ptr(stats) if want_stats else None, _stream()))
         return (xy, stats) if want_stats else xy
 
+    # -- measurement door (bench.py) -------------------------------------------------------
+    KERNEL_CLASSES = ('resize', 'lanczos', 'stem', 'pw', 'dw', 'resample', 'smooth', 'threshold', 'compact',
+                      'core', 'prim', 'finish')
+
+    def profile_enable(self, kernel_class):
+        """kernel_class: name from KERNEL_CLASSES, or None to switch event recording off."""
+        k = -1 if kernel_class is None else self.KERNEL_CLASSES.index(kernel_class)
+        _lib.check(self.lib.svc_profile_enable(self._h, k))
+
+    def profile_read(self):
+        """-> (total_ms, launches) of the profiled class since the last read; synchronises."""
+        ms, cnt = ctypes.c_double(), ctypes.c_int()
+        _lib.check(self.lib.svc_profile_read(self._h, ctypes.byref(ms), ctypes.byref(cnt)))
+        return ms.value, cnt.value
+
     def cluster_state(self, frame, cap):
         pts = np.zeros(cap, np.uint32)
         core = np.zeros(cap, np.uint32)

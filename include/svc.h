@@ -116,9 +116,12 @@ int svc_profile_read(SvcHandle *h, double *total_ms, int *launches);
  *   core_host[cap]  core distances (squared)
  *   mst_host[cap][3] MST edges in Prim order: from, to, weight
  *   labels_host[cap] final labels (-1 = noise)
+ *   hdr_host[16]    frame header: [0] points, [1] clusters selected, [2] cluster kept, [3] clustered,
+ *                   [4] condensed clusters, [8..11] k_finish phase stamps in 10 ns units
+ *                   (sorted, hierarchy built, cluster chosen, done)
  * Returns the number of points of that frame (or a negative error). */
 int svc_debug_cluster_state(SvcHandle *h, int frame, int cap, uint32_t *pts_host, uint32_t *core_host,
-                            uint32_t *mst_host, int32_t *labels_host);
+                            uint32_t *mst_host, int32_t *labels_host, int32_t *hdr_host);
 
 /* Test/diagnostic door: copy an intermediate activation of the LAST svc_saliency_u8
  * call (NHWC fp32, frame 0..n-1) to a HOST buffer.  `which` is one of the SVC_TAP_*

@@ -45,7 +45,7 @@ def load():
     lib.svc_threshold_u8.argtypes = [vp, vp, sz, i32, vp]
     lib.svc_cluster_center.argtypes = [vp, vp, i32, i32, i32, vp, ctypes.POINTER(SvcParams), vp, vp, vp]
     lib.svc_iou_i32.argtypes = [vp, vp, sz, vp, vp]
-    lib.svc_debug_cluster_state.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+    lib.svc_debug_cluster_state.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     lib.svc_debug_tap.argtypes = [vp, i32, i32, vp, sz]
     lib.svc_profile_enable.argtypes = [vp, i32]
     lib.svc_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]

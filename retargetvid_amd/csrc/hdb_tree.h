@@ -55,8 +55,7 @@ struct Tree {
     uint32_t *sdn;     // dendrogram node id of a live small component (valid at roots)
     // per edge: the condensed-tree rows the merge produced
     uint16_t *evc;     // cluster the rows belong to (NONE16 = none)
-    uint32_t *evs;     // points falling out (size-1 rows), or the left child's size for a split
-    uint32_t *evs2;    // 0, or the right child's size for a split (two cluster rows)
+    uint16_t *evs;     // points falling out (size-1 rows); 0 marks the split that created cluster evc
     // dendrogram: parent link of every node (2n-1 entries): parent << 1 | is_right
     uint32_t *dparent;
     // per cluster
@@ -68,11 +67,13 @@ struct Tree {
     uint32_t *csize;   // points in the component while this cluster is its top
     uint32_t *cdn;     // dendrogram node of the component while this cluster is its top
     uint32_t *csplit;  // dendrogram node at which the cluster's children were created
+    uint32_t *cspa, *cspb;  // sizes of the two child clusters of a split-created cluster (its two cluster rows)
     double *cacc;      // stability (after select(): propagated subtree stability)
     uint8_t *csel;     // selected by excess of mass
     int32_t *crep;     // nearest selected ancestor-or-self, ROOT_NOISE if none
     int32_t nclusters;
     int32_t n;
+    int32_t cap_clusters;   // capacity of the per-cluster arrays
 };
 
 SVC_HD int max_clusters(int n, int mcs) {
@@ -114,6 +115,8 @@ SVC_HD int32_t new_cluster(Tree &t, uint32_t w, uint32_t size, uint32_t node, in
     t.csize[c] = size;
     t.cdn[c] = node;
     t.csplit[c] = node;
+    t.cspa[c] = 0;
+    t.cspb[c] = 0;
     t.cacc[c] = 0.0;
     t.csel[c] = 0;
     t.crep[c] = ROOT_NOISE;
@@ -131,7 +134,8 @@ SVC_HD void init_points(Tree &t, int lo, int hi) {      // callable by many thre
 }
 
 // The sequential pass.  edges must be sorted by w (stable w.r.t. Prim order).
-SVC_HD void build(Tree &t, const Edge *edges, int n, int mcs) {
+// Returns false if the per-cluster arrays (cap_clusters) are too small.
+SVC_HD bool build(Tree &t, const Edge *edges, int n, int mcs) {
     t.n = n;
     t.nclusters = 0;
     for (int i = 0; i < n - 1; ++i) {
@@ -149,7 +153,6 @@ SVC_HD void build(Tree &t, const Edge *edges, int n, int mcs) {
         t.dparent[nb] = (node << 1) | 1u;
         t.evc[i] = (uint16_t)NONE16;
         t.evs[i] = 0;
-        t.evs2[i] = 0;
         if (!abig && !bbig) {
             const uint32_t s = sa + sb;
             if ((int)s < mcs) {
@@ -159,26 +162,30 @@ SVC_HD void build(Tree &t, const Edge *edges, int n, int mcs) {
                 t.ssz[big] = (uint16_t)s;
                 t.sdn[big] = node;
             } else {                                   // a condensed cluster is born bottom-up
+                if (t.nclusters >= t.cap_clusters) return false;
                 int32_t c = new_cluster(t, w, s, node, -1, -1);
-                t.evc[i] = (uint16_t)c; t.evs[i] = s;
+                t.evc[i] = (uint16_t)c; t.evs[i] = (uint16_t)s;
                 t.absc[ra] = (uint16_t)c; t.absw[ra] = w;
                 t.absc[rb] = (uint16_t)c; t.absw[rb] = w;
             }
         } else if (abig && bbig) {                     // true split: both sides >= mcs
+            if (t.nclusters >= t.cap_clusters) return false;
             int32_t p = new_cluster(t, w, sa + sb, node, (int32_t)ca, (int32_t)cb);
-            t.evc[i] = (uint16_t)p; t.evs[i] = sa; t.evs2[i] = sb;
+            t.evc[i] = (uint16_t)p; t.evs[i] = 0;
+            t.cspa[p] = sa; t.cspb[p] = sb;
             t.cup[ca] = (uint16_t)p; t.cup[cb] = (uint16_t)p;
             t.ctp[ca] = p; t.ctp[cb] = p;
             t.cbirthw[ca] = w; t.cbirthw[cb] = w;
         } else {                                       // small side falls out of the big side's cluster
             uint32_t c = abig ? ca : cb, r = abig ? rb : ra, s = abig ? sb : sa;
             t.absc[r] = (uint16_t)c; t.absw[r] = w;
-            t.evc[i] = (uint16_t)c; t.evs[i] = s;
+            t.evc[i] = (uint16_t)c; t.evs[i] = (uint16_t)s;
             t.csize[c] += s;
             t.cdn[c] = node;
         }
     }
     t.dparent[2 * n - 2] = 0xFFFFFFFFu;               // root of the dendrogram
+    return true;
 }
 
 // Stability, excess-of-mass selection (root allowed) and nearest-selected-ancestor map.
@@ -192,9 +199,9 @@ SVC_HD int select(Tree &t, const Edge *edges) {
         const double lam = 1.0 / (double)edges[i].w;
         const double birth = t.cbirthw[c] ? 1.0 / (double)t.cbirthw[c] : 0.0;
         double acc = t.cacc[c];
-        if (t.evs2[i]) {
-            acc += (lam - birth) * (double)t.evs[i];
-            acc += (lam - birth) * (double)t.evs2[i];
+        if (t.evs[i] == 0) {                            // the two cluster rows of a split, left first
+            acc += (lam - birth) * (double)t.cspa[c];
+            acc += (lam - birth) * (double)t.cspb[c];
         } else {
             const double term = (lam - birth) * 1.0;
             for (uint32_t k = 0; k < t.evs[i]; ++k) acc += term;

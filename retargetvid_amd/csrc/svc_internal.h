@@ -77,9 +77,11 @@ struct SvcHandle {
     // tail workspace (svc_tail.hip)
     DevBuf tail_ws;
     DevBuf tail_offsets;     // ring-walk offset table
-    int tail_n_offsets = 0;
+    int tail_n_offsets = 0, tail_n_offsets1 = 0;
     int tail_frames = 0, tail_h = 0, tail_w = 0;
     size_t tail_frame_stride = 0;      // bytes of per-frame tail workspace
+    uint8_t *depth_pinned = nullptr;   // pinned staging ring for the per-map round numbers
+    unsigned depth_slot = 0;
     int chunk = 32;                    // frames per network pass
     // per-kernel-class event log (svc_profile_*)
     int prof_class = -1;

@@ -987,6 +987,7 @@ extern "C" int svc_destroy(SvcHandle *h) {
     svc_net_release(h);
     h->tail_ws.release();
     h->tail_offsets.release();
+    if (h->depth_pinned) (void)hipHostFree(h->depth_pinned);
     h->blob.release();
     delete h;
     return SVC_OK;

@@ -25,7 +25,9 @@
 
 #define TB 1024                 // threads per frame workgroup
 #define NW16 (TB / 64)          // wavefronts per workgroup
-#define RING_R 40               // ring-walk radius for core distances
+#define RING_R 40               // ring table radius for core distances
+#define RING_R1 6                // radius walked by the one-thread-per-point phase
+#define DEPTH_SLOT 4096          // maps per svc_cluster_center call
 #define REACH_INF 0x1FFFFu      // > any squared distance on a <=256x256 grid (17 bits)
 
 // --------------------------------------------------------------------------------------
@@ -39,8 +41,8 @@ struct FrameWS {
     uint32_t ea, eb;     // Edge[cap]  radix ping-pong (ea = sorted result)
     uint32_t labels;     // i32[cap]
     uint32_t reach;      // u32[cap]   (generic large-N Prim only)
-    uint32_t sp, ssz, absc, absw, sdn, evc, evs, evs2, dparent;
-    uint32_t cup, ctp, cleft, cright, cbirthw, cminw, csize, cdn, csplit, cacc, csel, crep, cweight;
+    uint32_t sp, ssz, absc, absw, sdn, evc, evs, dparent;
+    uint32_t cup, ctp, cleft, cright, cbirthw, cminw, csize, cdn, csplit, cspa, cspb, cacc, csel, crep, cweight;
     uint32_t total;
 };
 
@@ -53,11 +55,12 @@ static FrameWS make_layout(int cap, int mc) {
     L.mst = take(8u * cap); L.ea = take(8u * cap); L.eb = take(8u * cap);
     L.labels = take(4u * cap); L.reach = take(4u * cap);
     L.sp = take(2u * cap); L.ssz = take(2u * cap); L.absc = take(2u * cap); L.absw = take(4u * cap);
-    L.sdn = take(4u * cap); L.evc = take(2u * cap); L.evs = take(4u * cap); L.evs2 = take(4u * cap);
+    L.sdn = take(4u * cap); L.evc = take(2u * cap); L.evs = take(2u * cap);
     L.dparent = take(8u * cap);
     L.cup = take(2u * mc); L.ctp = take(4u * mc); L.cleft = take(4u * mc); L.cright = take(4u * mc);
     L.cbirthw = take(4u * mc); L.cminw = take(4u * mc); L.csize = take(4u * mc);
-    L.cdn = take(4u * mc); L.csplit = take(4u * mc); L.cacc = take(8u * mc); L.csel = take(1u * mc);
+    L.cdn = take(4u * mc); L.csplit = take(4u * mc); L.cspa = take(4u * mc); L.cspb = take(4u * mc);
+    L.cacc = take(8u * mc); L.csel = take(1u * mc);
     L.crep = take(4u * mc); L.cweight = take(4u * mc);
     L.total = o;
     return L;
@@ -71,8 +74,9 @@ struct TailArgs {
     int round;
     int n, h, w;
     int mcs, min_samples, select_sum, op_close, clust_filt;
+    int variant;            // diagnostic switches (SVC_VARIANT env): 1 = 64-bit Prim keys, 2 = hierarchy state in global memory
     const uint32_t *ring;   // sorted neighbour offsets
-    int n_ring;
+    int n_ring, n_ring1;    // all offsets within RING_R / the prefix within RING_R1
     double *xy;
     int32_t *stats;
     FrameWS L;
@@ -197,10 +201,13 @@ __global__ __launch_bounds__(TB) void k_compact(TailArgs A) {
 }
 
 // --------------------------------------------------------------------------------------
-// k_core: squared distance to the k-th nearest other point.  Each thread walks the
-// neighbour offsets of its point in increasing distance over the occupancy map held
-// in LDS; points with fewer than k neighbours inside RING_R fall back to a wave-wide
-// bisection over all points.
+// k_core: squared distance to the k-th nearest other point, three exact phases:
+//  1. one thread per point walks the neighbour offsets (sorted by distance) of the inner
+//     ring (d2 <= RING_R1^2) over the occupancy map in LDS — enough for points inside blobs;
+//  2. one wavefront per remaining point scans the whole ring table 64 offsets at a time
+//     (ballot + popcount), out to RING_R;
+//  3. points with fewer than k neighbours within RING_R: wave-wide bisection on the count
+//     of points within distance t over all N points.
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TB) void k_core(TailArgs A) {
     const int f = blockIdx.x;
@@ -213,42 +220,73 @@ __global__ __launch_bounds__(TB) void k_core(TailArgs A) {
     const int hw = A.h * A.w;
     uint8_t *occ = sm_core;                                   // [hw]
     uint32_t *ring = (uint32_t *)(sm_core + (hw + 15) / 16 * 16);   // [n_ring]
-    __shared__ int n_fb;
+    __shared__ int n_fb, n_fb2;
     const uint8_t *map = A.maps + (size_t)f * hw;
     for (int i = threadIdx.x; i < hw; i += TB) occ[i] = map[i];
     for (int i = threadIdx.x; i < A.n_ring; i += TB) ring[i] = A.ring[i];
-    if (threadIdx.x == 0) n_fb = 0;
+    if (threadIdx.x == 0) { n_fb = 0; n_fb2 = 0; }
     __syncthreads();
     const uint32_t *pts = (const uint32_t *)(ws + A.L.pts);
     uint32_t *core = (uint32_t *)(ws + A.L.core);
-    int32_t *fb = (int32_t *)(ws + A.L.labels);               // scratch list of fallback points
+    int32_t *fb = (int32_t *)(ws + A.L.labels);               // scratch: points left for phase 2
+    int32_t *fb2 = (int32_t *)(ws + A.L.reach);               // scratch: points left for phase 3
     int k = A.min_samples > 0 ? A.min_samples : A.mcs;
     k = min(N - 1, k);
     if (k == 0) k = 1;
+    const int h = A.h, w = A.w;
     for (int p = threadIdx.x; p < N; p += TB) {
         const uint32_t v = pts[p];
         const int r = v & 255, c = (v >> 8) & 255;
         int cnt = 0;
         uint32_t res = 0xFFFFFFFFu;
-        for (int i = 0; i < A.n_ring; ++i) {
+        for (int i = 0; i < A.n_ring1; ++i) {
             const uint32_t o = ring[i];
             const int rr = r + (int)(o & 255) - 128, cc = c + (int)((o >> 8) & 255) - 128;
-            if ((unsigned)rr < (unsigned)A.h && (unsigned)cc < (unsigned)A.w && occ[rr * A.w + cc]) {
+            if ((unsigned)rr < (unsigned)h && (unsigned)cc < (unsigned)w && occ[rr * w + cc]) {
                 if (++cnt == k) { res = o >> 16; break; }
             }
         }
-        core[p] = res;
-        if (res == 0xFFFFFFFFu) fb[atomicAdd(&n_fb, 1)] = p;
+        if (res != 0xFFFFFFFFu) core[p] = res;
+        else fb[atomicAdd(&n_fb, 1)] = p;
     }
     __syncthreads();
-    const int nf = n_fb;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t maxd = (uint32_t)((A.h - 1) * (A.h - 1) + (A.w - 1) * (A.w - 1));
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int nf = n_fb;
     for (int q = wave; q < nf; q += NW16) {
         const int p = fb[q];
         const uint32_t v = pts[p];
         const int r = v & 255, c = (v >> 8) & 255;
-        uint32_t lo = 1, hi = maxd;                            // smallest t with #{d2 <= t} >= k+1 (self included)
+        int cum = 0;
+        bool done = false;
+        for (int base = 0; base < A.n_ring; base += 64) {
+            const int i = base + lane;
+            bool hit = false;
+            uint32_t o = 0;
+            if (i < A.n_ring) {
+                o = ring[i];
+                const int rr = r + (int)(o & 255) - 128, cc = c + (int)((o >> 8) & 255) - 128;
+                hit = (unsigned)rr < (unsigned)h && (unsigned)cc < (unsigned)w && occ[rr * w + cc];
+            }
+            const unsigned long long bal = __ballot(hit);
+            const int cnt = __popcll(bal);
+            if (cum + cnt >= k) {
+                if (hit && __popcll(bal & lt) == k - cum - 1) core[p] = o >> 16;
+                done = true;
+                break;
+            }
+            cum += cnt;
+        }
+        if (!done && lane == 0) fb2[atomicAdd(&n_fb2, 1)] = p;
+    }
+    __syncthreads();
+    const int nf2 = n_fb2;
+    const uint32_t maxd = (uint32_t)((h - 1) * (h - 1) + (w - 1) * (w - 1));
+    for (int q = wave; q < nf2; q += NW16) {
+        const int p = fb2[q];
+        const uint32_t v = pts[p];
+        const int r = v & 255, c = (v >> 8) & 255;
+        uint32_t lo = RING_R * RING_R + 1, hi = maxd;         // smallest t with #{d2 <= t} >= k+1 (self included)
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
             int cnt = 0;
@@ -268,11 +306,28 @@ __global__ __launch_bounds__(TB) void k_core(TailArgs A) {
 // k_prim: the library's Prim over the mutual-reachability graph, start node 0, lowest
 // index wins ties, edge = (last added node, new node, weight).  Each thread keeps the
 // running reachability and core distance of PT points in registers; coordinates live
-// in LDS; one 64-bit min-reduction (reach | index | core) per step, one barrier per step.
+// in LDS; one min-reduction of (reach | index) per step with the winner's core distance
+// as payload, one barrier per step.  For N <= 32768 the key fits 32 bits and the
+// wavefront reduction is six DPP-fused v_min_u32; larger N use a 64-bit key.
 // --------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_min_u32(uint32_t v) {
+    const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)v, CTRL, ROW_MASK, 0xF, false);
+    return t < v ? t : v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = dpp_min_u32<0x111, 0xF>(v);      // row_shr:1
+    v = dpp_min_u32<0x112, 0xF>(v);      // row_shr:2
+    v = dpp_min_u32<0x114, 0xF>(v);      // row_shr:4
+    v = dpp_min_u32<0x118, 0xF>(v);      // row_shr:8   -> lane 15 of every row holds the row minimum
+    v = dpp_min_u32<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_min_u32<0x143, 0xC>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the minimum
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 template <int PT>
-__device__ __forceinline__ void prim_regs(const uint32_t *__restrict__ core_g, hdb::Edge *__restrict__ mst, int N,
-                                          const uint16_t *rc16, unsigned long long *slots) {
+__device__ __forceinline__ void prim_regs64(const uint32_t *__restrict__ core_g, hdb::Edge *__restrict__ mst, int N,
+                                            const uint16_t *rc16, unsigned long long *slots) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t reach[PT], corev[PT];
     unsigned long long alive = 0;
@@ -321,7 +376,64 @@ __device__ __forceinline__ void prim_regs(const uint32_t *__restrict__ core_g, h
     }
 }
 
-// generic path for very large N: reachability kept in global memory
+template <int PT>
+__device__ __forceinline__ void prim_regs32(const uint32_t *__restrict__ core_g, hdb::Edge *__restrict__ mst, int N,
+                                            const uint16_t *rc16, uint2 *slots) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t reach[PT], corev[PT];
+    uint32_t alive = 0;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int p = tid + i * TB;
+        reach[i] = REACH_INF;
+        corev[i] = 0;
+        if (p < N) { corev[i] = core_g[p]; alive |= 1u << i; }
+    }
+    uint32_t cur = 0;
+    uint32_t cv = rc16[0];
+    int cr = cv & 255, cc = cv >> 8;
+    uint32_t ccore = core_g[0];
+    if (tid == 0) alive &= ~1u;
+    for (int step = 0; step < N - 1; ++step) {
+        uint32_t best = 0xFFFFFFFFu, bcore = 0;
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            if ((alive >> i) & 1u) {
+                const int p = tid + i * TB;
+                const uint32_t v = rc16[p];
+                const int dr = (int)(v & 255) - cr, dc = (int)(v >> 8) - cc;
+                uint32_t m = (uint32_t)(dr * dr + dc * dc);
+                m = max(max(m, corev[i]), ccore);
+                if (m < reach[i]) reach[i] = m;
+                const uint32_t key = (reach[i] << 15) | (uint32_t)p;
+                if (key < best) { best = key; bcore = corev[i]; }
+            }
+        }
+        const uint32_t wmin = wave_min_u32(best);
+        uint2 *sl = slots + (step & 1) * NW16;
+        if (best == wmin) sl[wave] = make_uint2(wmin, bcore);      // one lane (keys are unique) or all-dead wave
+        __syncthreads();
+        // second level: lanes 0..15 of every row hold one slot each; row minimum by DPP, the
+        // winner's payload by readlane
+        const uint2 t = sl[lane & 15];
+        uint32_t k2 = t.x;
+        k2 = dpp_min_u32<0x111, 0xF>(k2);
+        k2 = dpp_min_u32<0x112, 0xF>(k2);
+        k2 = dpp_min_u32<0x114, 0xF>(k2);
+        k2 = dpp_min_u32<0x118, 0xF>(k2);
+        const uint32_t kmin = (uint32_t)__builtin_amdgcn_readlane((int)k2, 15);
+        const int src = __ffsll((unsigned long long)__ballot(t.x == kmin)) - 1;
+        const uint32_t nidx = kmin & 0x7FFFu;
+        if (tid == 0) mst[step] = hdb::Edge{(uint16_t)cur, (uint16_t)nidx, kmin >> 15};
+        if ((int)(nidx & (TB - 1)) == tid) alive &= ~(1u << (nidx >> 10));
+        ccore = (uint32_t)__builtin_amdgcn_readlane((int)t.y, src);
+        cv = rc16[nidx];
+        cr = cv & 255; cc = cv >> 8;
+        cur = nidx;
+    }
+}
+
+// generic path for very large N: 64-bit keys, reachability kept in global memory
 __device__ __forceinline__ void prim_global(const uint32_t *__restrict__ core_g, uint32_t *__restrict__ reach_g,
                                             hdb::Edge *__restrict__ mst, int N, const uint16_t *rc16,
                                             unsigned long long *slots) {
@@ -369,23 +481,37 @@ __global__ __launch_bounds__(TB) void k_prim(TailArgs A) {
     if (!hdr[3]) return;
     const int N = hdr[0];
     extern __shared__ uint8_t sm_prim[];
-    unsigned long long *slots = (unsigned long long *)sm_prim;       // [2][NW16]
+    unsigned long long *slots = (unsigned long long *)sm_prim;       // [2][NW16] (uint2 or u64)
     uint16_t *rc16 = (uint16_t *)(sm_prim + 2 * NW16 * 8);           // [N]
     const uint32_t *pts = (const uint32_t *)(ws + A.L.pts);
     for (int p = threadIdx.x; p < N; p += TB) rc16[p] = (uint16_t)(pts[p] & 0xFFFFu);
     __syncthreads();
     const uint32_t *core = (const uint32_t *)(ws + A.L.core);
     hdb::Edge *mst = (hdb::Edge *)(ws + A.L.mst);
-    if (N <= 4 * TB) prim_regs<4>(core, mst, N, rc16, slots);
-    else if (N <= 12 * TB) prim_regs<12>(core, mst, N, rc16, slots);
-    else if (N <= 24 * TB) prim_regs<24>(core, mst, N, rc16, slots);
+    long long t0 = wall_clock64();
+    if (A.variant & 1) {
+        if (N <= 4 * TB) prim_regs64<4>(core, mst, N, rc16, slots);
+        else if (N <= 12 * TB) prim_regs64<12>(core, mst, N, rc16, slots);
+        else prim_global(core, (uint32_t *)(ws + A.L.reach), mst, N, rc16, slots);
+    } else
+    if (N <= 2 * TB) prim_regs32<2>(core, mst, N, rc16, (uint2 *)slots);
+    else if (N <= 4 * TB) prim_regs32<4>(core, mst, N, rc16, (uint2 *)slots);
+    else if (N <= 8 * TB) prim_regs32<8>(core, mst, N, rc16, (uint2 *)slots);
+    else if (N <= 16 * TB) prim_regs32<16>(core, mst, N, rc16, (uint2 *)slots);
+    else if (N <= 32 * TB) prim_regs32<32>(core, mst, N, rc16, (uint2 *)slots);
     else prim_global(core, (uint32_t *)(ws + A.L.reach), mst, N, rc16, slots);
+    if (threadIdx.x == 0) ((int32_t *)(ws + A.L.hdr))[12] = (int)(wall_clock64() - t0);
 }
 
 // --------------------------------------------------------------------------------------
 // k_finish: stable LSD radix sort of the MST edges by weight, hierarchy + EOM
-// (hdb_tree.h, one lane), labels, cluster weights, zeroing, CLOSE 5x5, centroid.
+// (hdb_tree.h, one lane; its arrays live in LDS when N <= TREE_LDS_CAP), labels, cluster
+// weights, zeroing, CLOSE 5x5, centroid.
 // --------------------------------------------------------------------------------------
+#define TREE_LDS_CAP 4352      // points: 28 B/point of hierarchy state in LDS
+#define TREE_LDS_CLUSTERS 512  // condensed clusters kept in LDS (57 B each)
+#define FIN_LDS_BYTES (TREE_LDS_CAP * 28 + TREE_LDS_CLUSTERS * 60)
+
 // one stable 6-bit counting pass over n edges: src -> dst
 __device__ void radix_pass(const hdb::Edge *__restrict__ src, hdb::Edge *__restrict__ dst, int n, int shift,
                            int *hist /*64*/, int *run /*64*/, uint16_t *wcnt /*[NW16][64]*/) {
@@ -434,6 +560,111 @@ __device__ void radix_pass(const hdb::Edge *__restrict__ src, hdb::Edge *__restr
     }
 }
 
+template <typename T>
+__device__ __forceinline__ T *carve(uint8_t *&p, size_t count) {
+    T *r = (T *)p;
+    p += (count * sizeof(T) + 15) / 16 * 16;
+    return r;
+}
+
+struct FinShared {
+    int hist[64], run[64];
+    uint16_t wcnt[NW16 * 64];
+    int nsel, best, ok;
+    unsigned long long red[3 * NW16];
+};
+
+// Hierarchy, labels, cluster weights and the choice of the kept cluster for one map.
+// LDS = true: the hot per-point / per-cluster state lives in the dynamic LDS buffer `sm` (all
+// pointers derive from it, so the compiler emits ds_* instead of flat_* accesses);
+// LDS = false: everything in the per-frame global workspace.  Returns the kept cluster
+// (or -1), or -2 when the LDS cluster tables overflowed and the caller must redo in global.
+template <bool LDS>
+__device__ __forceinline__ int cluster_phase(const TailArgs &A, uint8_t *ws, uint8_t *sm, FinShared &S, int32_t *hdr,
+                                             int N, long long t0) {
+    const int tid = threadIdx.x;
+    const int hw = A.h * A.w;
+    hdb::Edge *ea = (hdb::Edge *)(ws + A.L.ea);
+    const hdb::Edge *edges = ea;
+    hdb::Tree t;
+    t.dparent = (uint32_t *)(ws + A.L.dparent);
+    t.nclusters = 0; t.n = N;
+    if (LDS) {
+        uint8_t *p = sm;
+        hdb::Edge *el = carve<hdb::Edge>(p, TREE_LDS_CAP);
+        t.absw = carve<uint32_t>(p, TREE_LDS_CAP); t.sdn = carve<uint32_t>(p, TREE_LDS_CAP);
+        t.sp = carve<uint16_t>(p, TREE_LDS_CAP); t.ssz = carve<uint16_t>(p, TREE_LDS_CAP);
+        t.absc = carve<uint16_t>(p, TREE_LDS_CAP); t.evc = carve<uint16_t>(p, TREE_LDS_CAP);
+        t.evs = carve<uint16_t>(p, TREE_LDS_CAP);
+        t.cacc = carve<double>(p, TREE_LDS_CLUSTERS);
+        t.ctp = carve<int32_t>(p, TREE_LDS_CLUSTERS); t.cleft = carve<int32_t>(p, TREE_LDS_CLUSTERS);
+        t.cright = carve<int32_t>(p, TREE_LDS_CLUSTERS); t.cbirthw = carve<uint32_t>(p, TREE_LDS_CLUSTERS);
+        t.cminw = carve<uint32_t>(p, TREE_LDS_CLUSTERS); t.csize = carve<uint32_t>(p, TREE_LDS_CLUSTERS);
+        t.cdn = carve<uint32_t>(p, TREE_LDS_CLUSTERS); t.csplit = carve<uint32_t>(p, TREE_LDS_CLUSTERS);
+        t.cspa = carve<uint32_t>(p, TREE_LDS_CLUSTERS); t.cspb = carve<uint32_t>(p, TREE_LDS_CLUSTERS);
+        t.crep = carve<int32_t>(p, TREE_LDS_CLUSTERS); t.cup = carve<uint16_t>(p, TREE_LDS_CLUSTERS);
+        t.csel = carve<uint8_t>(p, TREE_LDS_CLUSTERS);
+        t.cap_clusters = TREE_LDS_CLUSTERS;
+        for (int i = tid; i < N - 1; i += TB) el[i] = ea[i];
+        edges = el;
+    } else {
+        t.sp = (uint16_t *)(ws + A.L.sp); t.ssz = (uint16_t *)(ws + A.L.ssz); t.absc = (uint16_t *)(ws + A.L.absc);
+        t.absw = (uint32_t *)(ws + A.L.absw); t.sdn = (uint32_t *)(ws + A.L.sdn);
+        t.evc = (uint16_t *)(ws + A.L.evc); t.evs = (uint16_t *)(ws + A.L.evs);
+        t.cup = (uint16_t *)(ws + A.L.cup); t.ctp = (int32_t *)(ws + A.L.ctp); t.cleft = (int32_t *)(ws + A.L.cleft);
+        t.cright = (int32_t *)(ws + A.L.cright); t.cbirthw = (uint32_t *)(ws + A.L.cbirthw);
+        t.cminw = (uint32_t *)(ws + A.L.cminw); t.csize = (uint32_t *)(ws + A.L.csize);
+        t.cdn = (uint32_t *)(ws + A.L.cdn); t.csplit = (uint32_t *)(ws + A.L.csplit);
+        t.cspa = (uint32_t *)(ws + A.L.cspa); t.cspb = (uint32_t *)(ws + A.L.cspb); t.cacc = (double *)(ws + A.L.cacc);
+        t.csel = (uint8_t *)(ws + A.L.csel); t.crep = (int32_t *)(ws + A.L.crep);
+        t.cap_clusters = hdb::max_clusters(hw, A.mcs);
+    }
+    {
+        const int per = (N + TB - 1) / TB;
+        hdb::init_points(t, min(N, tid * per), min(N, tid * per + per));
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const bool ok = hdb::build(t, edges, N, A.mcs);
+        if (ok) S.nsel = hdb::select(t, edges);
+        S.ok = ok;
+        hdr[4] = t.nclusters;
+        hdr[9] = (int)(wall_clock64() - t0);
+    }
+    __syncthreads();
+    if (!S.ok) return -2;
+    t.nclusters = hdr[4];
+    const int nsel = S.nsel;
+    uint32_t *cweight = (uint32_t *)(ws + A.L.cweight);
+    for (int c = tid; c < t.nclusters; c += TB) cweight[c] = 0;
+    __syncthreads();
+    const uint32_t *pts = (const uint32_t *)(ws + A.L.pts);
+    int32_t *labels = (int32_t *)(ws + A.L.labels);
+    for (int p = tid; p < N; p += TB) {
+        const int c = hdb::point_cluster(t, (uint32_t)p, nsel);
+        labels[p] = c;
+        if (c >= 0) {
+            const uint32_t val = pts[p] >> 16;
+            if (A.select_sum == 1) atomicAdd(&cweight[c], val); else atomicMax(&cweight[c], val);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+        int b = -1;
+        for (int c = 0; c < t.nclusters; ++c) {
+            if (t.crep[c] != c) continue;
+            if (b < 0 || cweight[c] > cweight[b] || (cweight[c] == cweight[b] && hdb::cluster_before(t, c, b))) b = c;
+        }
+        S.best = b;
+        hdr[1] = nsel;
+        hdr[2] = b;
+        hdr[10] = (int)(wall_clock64() - t0);
+    }
+    __syncthreads();
+    return S.best;
+}
+
 __global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
     const int f = blockIdx.x;
     if (A.depth[f] != A.round) return;
@@ -443,112 +674,70 @@ __global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
     const int hw = A.h * A.w;
     uint8_t *map = A.maps + (size_t)f * hw;
     extern __shared__ uint8_t sm_fin[];
-    uint8_t *m0 = sm_fin;                            // [hw]
-    uint8_t *m1 = sm_fin + (hw + 15) / 16 * 16;      // [hw]
-    __shared__ int hist[64], run[64];
-    __shared__ uint16_t wcnt[NW16 * 64];
-    __shared__ int s_nsel, s_best;
-    __shared__ unsigned long long red[3 * NW16];
+    __shared__ FinShared S;
+    unsigned long long *red = S.red;
     const int tid = threadIdx.x;
     const bool clustered = hdr[3] != 0;
-    for (int i = tid; i < hw; i += TB) m0[i] = map[i];
+    long long t0 = 0;
+    if (tid == 0) t0 = wall_clock64();
+    int best = -1;
     if (clustered) {
         hdb::Edge *mst = (hdb::Edge *)(ws + A.L.mst), *ea = (hdb::Edge *)(ws + A.L.ea), *eb = (hdb::Edge *)(ws + A.L.eb);
-        radix_pass(mst, ea, N - 1, 0, hist, run, wcnt);
-        radix_pass(ea, eb, N - 1, 6, hist, run, wcnt);
-        radix_pass(eb, ea, N - 1, 12, hist, run, wcnt);
-        hdb::Tree t;
-        t.sp = (uint16_t *)(ws + A.L.sp); t.ssz = (uint16_t *)(ws + A.L.ssz); t.absc = (uint16_t *)(ws + A.L.absc);
-        t.absw = (uint32_t *)(ws + A.L.absw); t.sdn = (uint32_t *)(ws + A.L.sdn); t.dparent = (uint32_t *)(ws + A.L.dparent);
-        t.evc = (uint16_t *)(ws + A.L.evc); t.evs = (uint32_t *)(ws + A.L.evs); t.evs2 = (uint32_t *)(ws + A.L.evs2);
-        t.cup = (uint16_t *)(ws + A.L.cup); t.ctp = (int32_t *)(ws + A.L.ctp); t.cleft = (int32_t *)(ws + A.L.cleft);
-        t.cright = (int32_t *)(ws + A.L.cright); t.cbirthw = (uint32_t *)(ws + A.L.cbirthw);
-        t.cminw = (uint32_t *)(ws + A.L.cminw); t.csize = (uint32_t *)(ws + A.L.csize);
-        t.cdn = (uint32_t *)(ws + A.L.cdn); t.csplit = (uint32_t *)(ws + A.L.csplit); t.cacc = (double *)(ws + A.L.cacc);
-        t.csel = (uint8_t *)(ws + A.L.csel); t.crep = (int32_t *)(ws + A.L.crep);
-        t.nclusters = 0; t.n = N;
-        {
-            const int per = (N + TB - 1) / TB;
-            hdb::init_points(t, min(N, tid * per), min(N, tid * per + per));
-        }
-        __syncthreads();
-        uint32_t *cweight = (uint32_t *)(ws + A.L.cweight);
-        if (tid == 0) {
-            hdb::build(t, ea, N, A.mcs);
-            s_nsel = hdb::select(t, ea);
-            hdr[4] = t.nclusters;
-            for (int c = 0; c < t.nclusters; ++c) cweight[c] = 0;
-        }
-        __syncthreads();
-        t.nclusters = hdr[4];
-        const int nsel = s_nsel;
+        radix_pass(mst, ea, N - 1, 0, S.hist, S.run, S.wcnt);
+        radix_pass(ea, eb, N - 1, 6, S.hist, S.run, S.wcnt);
+        radix_pass(eb, ea, N - 1, 12, S.hist, S.run, S.wcnt);
+        if (tid == 0) hdr[8] = (int)(wall_clock64() - t0);
+        best = -2;
+        if (N <= TREE_LDS_CAP && !(A.variant & 2)) best = cluster_phase<true>(A, ws, sm_fin, S, hdr, N, t0);
+        if (best == -2) best = cluster_phase<false>(A, ws, sm_fin, S, hdr, N, t0);
+    }
+    // ---- map phase: the LDS buffer now holds the map (the hierarchy state is no longer needed)
+    uint8_t *m0 = sm_fin;                            // [hw]
+    uint8_t *m1 = sm_fin + (hw + 15) / 16 * 16;      // [hw]
+    for (int i = tid; i < hw; i += TB) m0[i] = map[i];
+    __syncthreads();
+    if (best >= 0) {
         const uint32_t *pts = (const uint32_t *)(ws + A.L.pts);
-        int32_t *labels = (int32_t *)(ws + A.L.labels);
-        for (int p = tid; p < N; p += TB) {
-            const int c = hdb::point_cluster(t, (uint32_t)p, nsel);
-            labels[p] = c;
-            if (c >= 0) {
-                const uint32_t val = pts[p] >> 16;
-                if (A.select_sum == 1) atomicAdd(&cweight[c], val); else atomicMax(&cweight[c], val);
+        const int32_t *labels = (const int32_t *)(ws + A.L.labels);
+        for (int p = tid; p < N; p += TB)
+            if (labels[p] != best) {
+                const uint32_t v = pts[p];
+                m0[(v & 255) * A.w + ((v >> 8) & 255)] = 0;
             }
-        }
-        __threadfence_block();
         __syncthreads();
-        if (tid == 0) {
-            int best = -1;
-            for (int c = 0; c < t.nclusters; ++c) {
-                if (t.crep[c] != c) continue;
-                if (best < 0 || cweight[c] > cweight[best] ||
-                    (cweight[c] == cweight[best] && hdb::cluster_before(t, c, best)))
-                    best = c;
+        if (A.op_close) {
+            // grey CLOSE with a 5x5 rectangle = separable max (dilate) then separable min (erode);
+            // out-of-image samples are ignored
+            for (int i = tid; i < hw; i += TB) {
+                const int r = i / A.w, c = i - r * A.w;
+                int v = 0;
+                for (int d = -2; d <= 2; ++d) { int cc = c + d; if ((unsigned)cc < (unsigned)A.w) v = max(v, (int)m0[r * A.w + cc]); }
+                m1[i] = (uint8_t)v;
             }
-            s_best = best;
-            hdr[1] = nsel;
-            hdr[2] = best;
-        }
-        __syncthreads();
-        const int best = s_best;
-        if (best >= 0) {
-            for (int p = tid; p < N; p += TB)
-                if (labels[p] != best) {
-                    const uint32_t v = pts[p];
-                    m0[(v & 255) * A.w + ((v >> 8) & 255)] = 0;
-                }
             __syncthreads();
-            if (A.op_close) {
-                // grey CLOSE with a 5x5 rectangle = separable max (dilate) then separable min (erode);
-                // out-of-image samples are ignored
-                for (int i = tid; i < hw; i += TB) {
-                    const int r = i / A.w, c = i - r * A.w;
-                    int v = 0;
-                    for (int d = -2; d <= 2; ++d) { int cc = c + d; if ((unsigned)cc < (unsigned)A.w) v = max(v, (int)m0[r * A.w + cc]); }
-                    m1[i] = (uint8_t)v;
-                }
-                __syncthreads();
-                for (int i = tid; i < hw; i += TB) {
-                    const int r = i / A.w, c = i - r * A.w;
-                    int v = 0;
-                    for (int d = -2; d <= 2; ++d) { int rr = r + d; if ((unsigned)rr < (unsigned)A.h) v = max(v, (int)m1[rr * A.w + c]); }
-                    m0[i] = (uint8_t)v;
-                }
-                __syncthreads();
-                for (int i = tid; i < hw; i += TB) {
-                    const int r = i / A.w, c = i - r * A.w;
-                    int v = 255;
-                    for (int d = -2; d <= 2; ++d) { int cc = c + d; if ((unsigned)cc < (unsigned)A.w) v = min(v, (int)m0[r * A.w + cc]); }
-                    m1[i] = (uint8_t)v;
-                }
-                __syncthreads();
-                for (int i = tid; i < hw; i += TB) {
-                    const int r = i / A.w, c = i - r * A.w;
-                    int v = 255;
-                    for (int d = -2; d <= 2; ++d) { int rr = r + d; if ((unsigned)rr < (unsigned)A.h) v = min(v, (int)m1[rr * A.w + c]); }
-                    m0[i] = (uint8_t)v;
-                }
-                __syncthreads();
+            for (int i = tid; i < hw; i += TB) {
+                const int r = i / A.w, c = i - r * A.w;
+                int v = 0;
+                for (int d = -2; d <= 2; ++d) { int rr = r + d; if ((unsigned)rr < (unsigned)A.h) v = max(v, (int)m1[rr * A.w + c]); }
+                m0[i] = (uint8_t)v;
             }
-            for (int i = tid; i < hw; i += TB) map[i] = m0[i];
+            __syncthreads();
+            for (int i = tid; i < hw; i += TB) {
+                const int r = i / A.w, c = i - r * A.w;
+                int v = 255;
+                for (int d = -2; d <= 2; ++d) { int cc = c + d; if ((unsigned)cc < (unsigned)A.w) v = min(v, (int)m0[r * A.w + cc]); }
+                m1[i] = (uint8_t)v;
+            }
+            __syncthreads();
+            for (int i = tid; i < hw; i += TB) {
+                const int r = i / A.w, c = i - r * A.w;
+                int v = 255;
+                for (int d = -2; d <= 2; ++d) { int rr = r + d; if ((unsigned)rr < (unsigned)A.h) v = min(v, (int)m1[rr * A.w + c]); }
+                m0[i] = (uint8_t)v;
+            }
+            __syncthreads();
         }
+        for (int i = tid; i < hw; i += TB) map[i] = m0[i];
     }
     __syncthreads();
     // centroid of the non-zero pixels of the final map
@@ -574,6 +763,7 @@ __global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
             A.stats[4 * f + 2] = clustered ? hdr[2] : -1;
             A.stats[4 * f + 3] = (int)cnt;
         }
+        hdr[11] = (int)(wall_clock64() - t0);
     }
 }
 
@@ -612,6 +802,8 @@ static int ensure_ring(SvcHandle *h) {
     if (rc) return rc;
     SVC_HIP(hipMemcpy(h->tail_offsets.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
     h->tail_n_offsets = (int)v.size();
+    h->tail_n_offsets1 = 0;
+    for (uint32_t x : v) h->tail_n_offsets1 += (int)((x >> 16) <= RING_R1 * RING_R1);
     return SVC_OK;
 }
 
@@ -644,29 +836,33 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
             depth[i] = depth[i - 1] + 1;
             maxd = std::max(maxd, (int)depth[i]);
         }
-    if ((rc = h->tail_ws.ensure((size_t)L.total * n + (size_t)n))) return rc;
-    uint8_t *depth_dev = (uint8_t *)h->tail_ws.p + (size_t)L.total * n;
-    // make sure earlier work that still reads the depth array has drained before it is overwritten
-    SVC_HIP(hipStreamSynchronize(s));
-    SVC_HIP(hipMemcpyAsync(depth_dev, depth.data(), n, hipMemcpyHostToDevice, s));
-    SVC_HIP(hipStreamSynchronize(s));
+    if ((rc = h->tail_ws.ensure((size_t)L.total * n + 8 * (size_t)DEPTH_SLOT))) return rc;
+    if (n > DEPTH_SLOT) { svc_set_error("svc_cluster_center: more than %d maps per call", DEPTH_SLOT); return SVC_E_INVALID; }
+    // the per-map round numbers travel through a small ring of pinned host slots so that the upload is
+    // asynchronous (up to 8 calls may be in flight on the stream before a slot is reused)
+    if (!h->depth_pinned) SVC_HIP(hipHostMalloc((void **)&h->depth_pinned, 8 * (size_t)DEPTH_SLOT, hipHostMallocDefault));
+    const int slot = h->depth_slot++ & 7;
+    uint8_t *depth_dev = (uint8_t *)h->tail_ws.p + (size_t)L.total * n + (size_t)slot * DEPTH_SLOT;
+    memcpy(h->depth_pinned + (size_t)slot * DEPTH_SLOT, depth.data(), n);
+    SVC_HIP(hipMemcpyAsync(depth_dev, h->depth_pinned + (size_t)slot * DEPTH_SLOT, n, hipMemcpyHostToDevice, s));
     h->tail_frames = n; h->tail_h = height; h->tail_w = width; h->tail_frame_stride = L.total;
     TailArgs A;
     A.maps = maps; A.ws = (uint8_t *)h->tail_ws.p; A.ws_stride = L.total; A.depth = depth_dev; A.round = 0;
     A.n = n; A.h = height; A.w = width;
     A.mcs = params->hdbscan_min; A.min_samples = params->hdbscan_min_samples; A.select_sum = params->select_sum;
     A.op_close = params->op_close; A.clust_filt = params->clust_filt;
-    A.ring = (const uint32_t *)h->tail_offsets.p; A.n_ring = h->tail_n_offsets;
+    { const char *ev = getenv("SVC_VARIANT"); A.variant = ev ? atoi(ev) : 0; }
+    A.ring = (const uint32_t *)h->tail_offsets.p; A.n_ring = h->tail_n_offsets; A.n_ring1 = h->tail_n_offsets1;
     A.xy = xy; A.stats = stats; A.L = L;
     const int hw = height * width;
     const size_t lds_core = (size_t)(hw + 15) / 16 * 16 + (size_t)h->tail_n_offsets * 4;
     const size_t lds_prim = 2 * NW16 * 8 + (size_t)hw * 2;
-    const size_t lds_fin = 2 * ((size_t)(hw + 15) / 16 * 16);
+    const size_t lds_fin = std::max<size_t>(2 * ((size_t)(hw + 15) / 16 * 16), FIN_LDS_BYTES);
     static bool attr_done = false;
     if (!attr_done) {
         SVC_HIP(hipFuncSetAttribute((const void *)k_core, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_prim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-        SVC_HIP(hipFuncSetAttribute((const void *)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16 * 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
         attr_done = true;
     }
     for (int r = 0; r <= maxd; ++r) {
@@ -698,7 +894,7 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
 }
 
 extern "C" int svc_debug_cluster_state(SvcHandle *h, int frame, int cap, uint32_t *pts_host, uint32_t *core_host,
-                                       uint32_t *mst_host, int32_t *labels_host) {
+                                       uint32_t *mst_host, int32_t *labels_host, int32_t *hdr_host) {
     if (!h || !h->tail_ws.p || frame < 0 || frame >= h->tail_frames) {
         svc_set_error("svc_debug_cluster_state: no such frame");
         return SVC_E_INVALID;
@@ -712,6 +908,7 @@ extern "C" int svc_debug_cluster_state(SvcHandle *h, int frame, int cap, uint32_
     SVC_HIP(hipMemcpy(hdr, ws + L.hdr, sizeof hdr, hipMemcpyDeviceToHost));
     const int N = hdr[0];
     const int m = std::min(N, cap);
+    if (hdr_host) memcpy(hdr_host, hdr, sizeof hdr);
     if (pts_host) SVC_HIP(hipMemcpy(pts_host, ws + L.pts, (size_t)m * 4, hipMemcpyDeviceToHost));
     if (hdr[3]) {
         if (core_host) SVC_HIP(hipMemcpy(core_host, ws + L.core, (size_t)m * 4, hipMemcpyDeviceToHost));

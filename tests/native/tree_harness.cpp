@@ -10,16 +10,17 @@ extern "C" int tree_labels(const uint16_t *a, const uint16_t *b, const uint32_t 
     std::vector<Edge> edges(n - 1);
     for (int i = 0; i < n - 1; ++i) edges[i] = Edge{a[i], b[i], w[i]};
     const int mc = max_clusters(n, mcs);
-    std::vector<uint16_t> sp(n), ssz(n), absc(n), cup(mc), evc(n);
-    std::vector<uint32_t> absw(n), sdn(n), evs(n), evs2(n), dparent(2 * n), cbirthw(mc), cminw(mc), csize(mc), cdn(mc), csplit(mc);
+    std::vector<uint16_t> sp(n), ssz(n), absc(n), cup(mc), evc(n), evs(n);
+    std::vector<uint32_t> absw(n), sdn(n), dparent(2 * n), cbirthw(mc), cminw(mc), csize(mc), cdn(mc), csplit(mc), cspa(mc), cspb(mc);
     std::vector<int32_t> ctp(mc), cleft(mc), cright(mc), crep(mc);
     std::vector<double> cacc(mc);
     std::vector<uint8_t> csel(mc);
-    Tree t{sp.data(), ssz.data(), absc.data(), absw.data(), sdn.data(), evc.data(), evs.data(), evs2.data(),
+    Tree t{sp.data(), ssz.data(), absc.data(), absw.data(), sdn.data(), evc.data(), evs.data(),
            dparent.data(), cup.data(), ctp.data(), cleft.data(), cright.data(), cbirthw.data(), cminw.data(),
-           csize.data(), cdn.data(), csplit.data(), cacc.data(), csel.data(), crep.data(), 0, n};
+           csize.data(), cdn.data(), csplit.data(), cspa.data(), cspb.data(), cacc.data(), csel.data(), crep.data(),
+           0, n, mc};
     init_points(t, 0, n);
-    build(t, edges.data(), n, mcs);
+    if (!build(t, edges.data(), n, mcs)) return -1;
     const int nsel = select(t, edges.data());
     std::vector<int> sel;
     for (int c = 0; c < t.nclusters; ++c) if (t.crep[c] == c) sel.push_back(c);

@@ -102,7 +102,8 @@ try:
             k = H.effective_min_samples(len(X), CP['hdbscan_min'], CP['hdbscan_min_samples'])
             core = H.core_distances(X, k)
             u, v, w = H.prim_mst(X, core)
-            print('    core mismatch %d  mst mismatch %d' % ((core != st['core']).sum(), (np.stack([u, v, w], 1) != st['mst']).sum()))
+            print('    core mismatch %d  mst mismatch %d  finish stamps (us) %s prim %.1f us nclusters %d' % (
+                (core != st['core']).sum(), (np.stack([u, v, w], 1) != st['mst']).sum(), (st['hdr'][8:12] / 100.0).tolist(), st['hdr'][12] / 100.0, st['hdr'][4]))
 except Exception:
     traceback.print_exc(); ok = False
 
@@ -121,6 +122,12 @@ except Exception:
 try:
     section('timing')
     fr = torch.from_numpy(synth.blob_frames(32, 360, 640, seed=0)).cuda()
+    for k in eng.KERNEL_CLASSES:
+        eng.profile_enable(k)
+        small = eng.resize_frames(fr, 140, 250); maps = eng.saliency(small); eng.threshold_(maps, 120)
+        eng.cluster_center_(maps, None, CP)
+        print('  class %-10s %8.3f ms in %d launches' % ((k,) + eng.profile_read()))
+    eng.profile_enable(None)
     for it in range(3):
         torch.cuda.synchronize(); t0 = time.time()
         small = eng.resize_frames(fr, 140, 250)

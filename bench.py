@@ -104,7 +104,7 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32)
-    ap.add_argument('--pipeline', type=int, default=4, help='batches in flight per GPU (engines / HIP streams)')
+    ap.add_argument('--pipeline', type=int, default=6, help='batches in flight per GPU (engines / HIP streams)')
     ap.add_argument('--cpu-sample', type=int, default=12, help='frames of the CPU baseline sample (0 = skip)')
     args = ap.parse_args()
 

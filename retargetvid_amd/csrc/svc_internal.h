@@ -83,6 +83,8 @@ struct SvcHandle {
     uint8_t *depth_pinned = nullptr;   // pinned staging ring for the per-map round numbers
     unsigned depth_slot = 0;
     int chunk = 32;                    // frames per network pass
+    int pw_pf = 4;                     // k_pw operand prefetch depth selector (SVC_PW_PF: 1, 2, 4)
+    int fuse_max = 7;                  // backbone blocks 1..fuse_max run as the fused inverted-residual kernel (SVC_FUSE_MAX, 0..13)
     // per-kernel-class event log (svc_profile_*)
     int prof_class = -1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_stem(const float *__restrict__ X, const
 // s-th MFMA of an 8-deep K chunk: both operands come from one float4 per lane, read
 // straight from global memory (the k order inside a chunk is a consistent permutation).
 // --------------------------------------------------------------------------------------
-template <int TN>
+template <int TN, int PF>
 __global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx, const float *__restrict__ Wt,
                                             const float *__restrict__ bias, const float *__restrict__ R, int ldr,
                                             float *__restrict__ Y, int ldy, int M, int N, int Npad, int K,
@@ -287,16 +287,38 @@ __global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx
     for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-#pragma unroll 2
-    for (int k = 0; k < K; k += 8) {
-        const float4 a = *(const float4 *)(xp + k);
+    // software pipeline: the operands of PF k-steps (8 deep each) are in flight ahead of the MFMAs
+    const int nsteps = K >> 3;
+    float4 A[PF], B[PF][TN];
 #pragma unroll
-        for (int t = 0; t < TN; ++t) {
-            const float4 b = *(const float4 *)(wp[t] + k);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+    for (int p = 0; p < PF; ++p)
+        if (p < nsteps) {
+            A[p] = *(const float4 *)(xp + 8 * p);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) B[p][t] = *(const float4 *)(wp[t] + 8 * p);
+        }
+    for (int s0 = 0; s0 < nsteps; s0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int st = s0 + p;
+            if (st < nsteps) {
+                const float4 a = A[p];
+                float4 b[TN];
+#pragma unroll
+                for (int t = 0; t < TN; ++t) b[t] = B[p][t];
+                if (st + PF < nsteps) {
+                    A[p] = *(const float4 *)(xp + 8 * (st + PF));
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) B[p][t] = *(const float4 *)(wp[t] + 8 * (st + PF));
+                }
+#pragma unroll
+                for (int t = 0; t < TN; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+                }
+            }
         }
     }
 #pragma unroll
@@ -661,10 +683,15 @@ static int launch_pw(SvcHandle *h, hipStream_t s, const float *X, int ldx, const
     dim3 grid(rb, ceil_div(tiles, TN));
 #define PW_ARGS X, ldx, L.w.dev, L.b.dev, R, ldr, Y, ldy, M, N, Npad, K, L.relu6
     switch (TN) {
-        case 4: k_pw<4><<<grid, 256, 0, s>>>(PW_ARGS); break;
-        case 3: k_pw<3><<<grid, 256, 0, s>>>(PW_ARGS); break;
-        case 2: k_pw<2><<<grid, 256, 0, s>>>(PW_ARGS); break;
-        default: k_pw<1><<<grid, 256, 0, s>>>(PW_ARGS); break;
+#define PW_CASE(TN_, PFA_, PFB_, PFC_)                                                  \
+    if (h->pw_pf == 1) k_pw<TN_, PFA_><<<grid, 256, 0, s>>>(PW_ARGS);                    \
+    else if (h->pw_pf == 2) k_pw<TN_, PFB_><<<grid, 256, 0, s>>>(PW_ARGS);               \
+    else k_pw<TN_, PFC_><<<grid, 256, 0, s>>>(PW_ARGS)
+        case 4: PW_CASE(4, 1, 2, 2); break;
+        case 3: PW_CASE(3, 1, 2, 2); break;
+        case 2: PW_CASE(2, 1, 2, 4); break;
+        default: PW_CASE(1, 1, 2, 4); break;
+#undef PW_CASE
     }
 #undef PW_ARGS
     SVC_CHECK_LAUNCH();
@@ -680,6 +707,188 @@ static int launch_dw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer
         k_dw<2><<<blocks256(total), 256, 0, s>>>(X, L.w.dev, L.b.dev, Y, n, H, W, C, OH, OW);
     else
         k_dw<1><<<blocks256(total), 256, 0, s>>>(X, L.w.dev, L.b.dev, Y, n, H, W, C, OH, OW);
+    SVC_CHECK_LAUNCH();
+    return SVC_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// Fused inverted-residual block (MobileNetV2.py:26-83): 1x1 expand + ReLU6 -> 3x3 depthwise
+// + ReLU6 -> 1x1 project (+ residual) for one tile of TOH x TOW output pixels.  The 6x
+// expanded tensor and the depthwise output never leave the CU: per 32-channel chunk of the
+// expansion the workgroup (4 waves) computes
+//   E  = relu6(Xs . We^T + be)   for the (TOH-1)S+3 x (TOW-1)S+3 input halo   (f32 MFMA, A from LDS)
+//   D  = relu6(dw3x3(E) + bd)                                                 (VALU, float4 over channels)
+//   acc += D . Wp^T                                                           (f32 MFMA, A from LDS)
+// with the same k order and tap order as k_pw / k_dw, so results are bit-identical to the
+// un-fused kernels.  Out-of-image halo pixels hold E = 0 (the depthwise conv pads E, not X).
+// EXPAND = false is the t=1 block (features.1): E is the input itself.
+// --------------------------------------------------------------------------------------
+#define IRB_ES 36      // LDS row stride (floats) of E and D: 32 channels + 4 pad (conflict-free float4 rows)
+
+template <int S, int TOH, int TOW, bool EXPAND>
+__global__ __launch_bounds__(256) void k_irb(const float *__restrict__ X, int H, int W, int Cin,
+                                             const float *__restrict__ We, const float *__restrict__ be, int Ce,
+                                             const float *__restrict__ Wd, const float *__restrict__ bd,
+                                             const float *__restrict__ Wp, const float *__restrict__ bp, int Cout,
+                                             int CoutP, const float *__restrict__ R, float *__restrict__ Y, int ldy,
+                                             int OH, int OW, int tiles_x, int tiles_y) {
+    constexpr int IH = (TOH - 1) * S + 3, IW = (TOW - 1) * S + 3, NPX = IH * IW, MT = (NPX + 31) / 32, MROWS = MT * 32;
+    constexpr int NOUT = TOH * TOW, MP = NOUT / 32, NG = 4 / MP;
+    extern __shared__ float sm_irb[];
+    const int XS = Cin + 4;
+    float *Xs = sm_irb;                                     // [MROWS][XS]
+    float *E = EXPAND ? Xs + MROWS * XS : Xs;               // [MROWS][IRB_ES]   (t=1: XS == IRB_ES, E is Xs)
+    float *D = E + MROWS * IRB_ES;                          // [NOUT][IRB_ES]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y, f = bid / tiles_y;
+    const int oy0 = ty * TOH, ox0 = tx * TOW, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    // 1. input halo -> LDS (zeros outside the image)
+    {
+        const int c4n = Cin >> 2;
+        const float *xf = X + (size_t)f * H * W * Cin;
+        for (int idx = tid; idx < MROWS * c4n; idx += 256) {
+            const int row = idx / c4n, c4 = idx - row * c4n;
+            const int hy = row / IW, hx = row - hy * IW;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < NPX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                v = *(const float4 *)(xf + ((size_t)iy * W + ix) * Cin + c4 * 4);
+            *(float4 *)(Xs + row * XS + c4 * 4) = v;
+        }
+    }
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    const int nchunks = (Ce + 31) >> 5;
+    const int pm = wave % MP, pn0 = wave / MP;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (EXPAND) {
+            for (int mt = wave; mt < MT; mt += 4) {
+                f32x16 e;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) e[i] = 0.f;
+                const float *ap = Xs + (mt * 32 + r) * XS + 4 * hh;
+                const float *bq = We + (size_t)(ch * 32 + r) * Cin + 4 * hh;
+                for (int k = 0; k < Cin; k += 8) {
+                    const float4 a = *(const float4 *)(ap + k);
+                    const float4 b = *(const float4 *)(bq + k);
+                    e = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, e, 0, 0, 0);
+                    e = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, e, 0, 0, 0);
+                    e = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, e, 0, 0, 0);
+                    e = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, e, 0, 0, 0);
+                }
+                const int c = ch * 32 + r;
+                const float bv = c < Ce ? be[c] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int rr = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    const int hy = rr / IW, hx = rr - hy * IW;
+                    const bool valid = rr < NPX && c < Ce && (unsigned)(iy0 + hy) < (unsigned)H &&
+                                       (unsigned)(ix0 + hx) < (unsigned)W;
+                    E[rr * IRB_ES + r] = valid ? fminf(fmaxf(e[i] + bv, 0.f), 6.f) : 0.f;
+                }
+            }
+            __syncthreads();
+        }
+        // depthwise 3x3 on the chunk: one thread = one output pixel x 4 channels
+        for (int idx = tid; idx < NOUT * 8; idx += 256) {
+            const int px = idx >> 3, c4 = idx & 7;
+            const int oy = px / TOW, ox = px - oy * TOW;
+            const int c = ch * 32 + c4 * 4;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < Ce) {
+                float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float4 x = *(const float4 *)(E + ((oy * S + ky) * IW + ox * S + kx) * IRB_ES + c4 * 4);
+                        const float4 w = *(const float4 *)(Wd + (size_t)(ky * 3 + kx) * Ce + c);
+                        a4.x = fmaf(x.x, w.x, a4.x);
+                        a4.y = fmaf(x.y, w.y, a4.y);
+                        a4.z = fmaf(x.z, w.z, a4.z);
+                        a4.w = fmaf(x.w, w.w, a4.w);
+                    }
+                const float4 b = *(const float4 *)(bd + c);
+                o.x = fminf(fmaxf(a4.x + b.x, 0.f), 6.f);
+                o.y = fminf(fmaxf(a4.y + b.y, 0.f), 6.f);
+                o.z = fminf(fmaxf(a4.z + b.z, 0.f), 6.f);
+                o.w = fminf(fmaxf(a4.w + b.w, 0.f), 6.f);
+            }
+            *(float4 *)(D + px * IRB_ES + c4 * 4) = o;
+        }
+        __syncthreads();
+        // project: acc[pm rows][n tile] += D . Wp^T over this chunk's channels
+        const int kend = min(32, Ce - ch * 32);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nt = pn0 + j * NG;
+            if (nt * 32 < CoutP) {
+                const float *ap = D + (pm * 32 + r) * IRB_ES + 4 * hh;
+                const float *bq = Wp + (size_t)(nt * 32 + r) * Ce + ch * 32 + 4 * hh;
+                for (int k = 0; k < kend; k += 8) {
+                    const float4 a = *(const float4 *)(ap + k);
+                    const float4 b = *(const float4 *)(bq + k);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[j], 0, 0, 0);
+                }
+            }
+        }
+        if (!EXPAND) __syncthreads();
+    }
+    // epilogue: bias (+ residual) and store
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = (pn0 + j * NG) * 32 + r;
+        if (col >= Cout) continue;
+        const float bv = bp[col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int px = pm * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const int oy = oy0 + px / TOW, ox = ox0 + px % TOW;
+            if (oy < OH && ox < OW) {
+                const size_t pix = ((size_t)f * OH + oy) * OW + ox;
+                float v = acc[j][i] + bv;
+                if (R) v += R[pix * Cout + col];
+                Y[pix * ldy + col] = v;
+            }
+        }
+    }
+}
+
+static int launch_irb(SvcHandle *h, hipStream_t s, const float *X, int n, int H, int W, int Cin, const SvcLayer *Le,
+                      const SvcLayer &Ld, const SvcLayer &Lp, int stride, const float *R, float *Y) {
+    ProfScope ps(h, SVC_K_PW, s);
+    const int Ce = Ld.cout, Cout = Lp.cout, CoutP = (Cout + 31) / 32 * 32;
+    const int OH = H / stride, OW = W / stride;
+    static bool attr_done = false;
+    if (!attr_done) {        // tiles of the 96-channel blocks need more than the default 64 KB of dynamic LDS
+        SVC_HIP(hipFuncSetAttribute((const void *)k_irb<1, 8, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_irb<2, 4, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_irb<1, 8, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+        attr_done = true;
+    }
+#define IRB_LAUNCH(S_, TOH_, TOW_, EXP_)                                                                             \
+    do {                                                                                                             \
+        constexpr int IH = (TOH_ - 1) * S_ + 3, IW = (TOW_ - 1) * S_ + 3, MROWS = (IH * IW + 31) / 32 * 32;           \
+        const int tx = ceil_div(OW, TOW_), ty = ceil_div(OH, TOH_);                                                  \
+        const size_t lds = ((size_t)MROWS * (Cin + 4) + (EXP_ ? (size_t)MROWS * IRB_ES : 0) + (size_t)TOH_ * TOW_ * IRB_ES) * 4; \
+        k_irb<S_, TOH_, TOW_, EXP_><<<dim3((unsigned)(n * tx * ty)), 256, lds, s>>>(                                  \
+            X, H, W, Cin, EXP_ ? Le->w.dev : nullptr, EXP_ ? Le->b.dev : nullptr, Ce, Ld.w.dev, Ld.b.dev, Lp.w.dev,   \
+            Lp.b.dev, Cout, CoutP, R, Y, Cout, OH, OW, tx, ty);                                                      \
+    } while (0)
+    if (!Le) IRB_LAUNCH(1, 8, 8, false);
+    else if (stride == 2) IRB_LAUNCH(2, 4, 8, true);
+    else IRB_LAUNCH(1, 8, 8, true);
+#undef IRB_LAUNCH
     SVC_CHECK_LAUNCH();
     return SVC_OK;
 }
@@ -723,16 +932,24 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
             const bool tap = (idx == 7 || idx == 14);             // full-resolution output feeds a skip
             const int dws = (stride == 2 && !tap) ? 2 : 1;        // stride-2 dw == stride-1 dw + ::2 sub-sampling
             const float *x = P[cur];
-            const float *dwin = x;
-            if (t != 1) {
-                RC(launch_pw(h, s, x, inp, next(), nullptr, 0, E0, inp * t, n * H * W));
-                dwin = E0;
-            }
-            const SvcLayer &Ld = next();
-            RC(launch_dw(h, s, dwin, Ld, E1, n, H, W, dws));
             int OH = H / dws, OW = W / dws;
             float *y = tap ? p->buf(idx == 7 ? B_F4X : B_F2X) : P[cur ^ 1];
-            RC(launch_pw(h, s, E1, inp * t, next(), res ? x : nullptr, oup, y, oup, n * OH * OW));
+            // the first fuse_max blocks (of 1..13: Cin <= 96, Cout <= 128) run as one fused kernel; the rest un-fused
+            if (idx <= h->fuse_max && (t != 1 || inp == 32)) {
+                const SvcLayer *Le = (t != 1) ? &next() : nullptr;
+                const SvcLayer &Ld = next();
+                const SvcLayer &Lp = next();
+                RC(launch_irb(h, s, x, n, H, W, inp, Le, Ld, Lp, dws, res ? x : nullptr, y));
+            } else {
+                const float *dwin = x;
+                if (t != 1) {
+                    RC(launch_pw(h, s, x, inp, next(), nullptr, 0, E0, inp * t, n * H * W));
+                    dwin = E0;
+                }
+                const SvcLayer &Ld = next();
+                RC(launch_dw(h, s, dwin, Ld, E1, n, H, W, dws));
+                RC(launch_pw(h, s, E1, inp * t, next(), res ? x : nullptr, oup, y, oup, n * OH * OW));
+            }
             if (tap) {
                 ProfScope ps(h, SVC_K_RESAMPLE, s);
                 k_subsample<<<blocks256((size_t)n * (OH / 2) * (OW / 2) * (oup / 4)), 256, 0, s>>>(y, P[cur ^ 1], n, OH,
@@ -899,6 +1116,10 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     h->device = device;
     const char *env = getenv("SVC_CHUNK");
     if (env && atoi(env) > 0) h->chunk = atoi(env);
+    env = getenv("SVC_PW_PF");
+    if (env) h->pw_pf = atoi(env);
+    env = getenv("SVC_FUSE_MAX");
+    if (env) h->fuse_max = std::min(13, std::max(0, atoi(env)));
     int rc = h->blob.ensure(n_bytes);
     if (rc) { delete h; return rc; }
     if (hipMemcpy(h->blob.p, blob_host, n_bytes, hipMemcpyHostToDevice) != hipSuccess) {

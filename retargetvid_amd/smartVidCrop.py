@@ -193,7 +193,7 @@ def ingest_frames(video, crop_params, engine=None, verbose=False):
     engine = engine or get_engine()
     t = time.perf_counter()
     fr, frame_count, w, h = video['fr'], int(video['frame_count']), int(video['w']), int(video['h'])
-    frames = video['frames']
+    frames = video['frames']              # ndarray / CUDA tensor [n,h,w,3] u8 RGB, or an object with __len__ and .select(idx)
     n_frames = len(frames)
     dsr = float(max(w, h)) / crop_params['max_input_d']
     sal_h, sal_w = int(h / dsr), int(w / dsr)
@@ -208,7 +208,9 @@ def ingest_frames(video, crop_params, engine=None, verbose=False):
     for first, cnt in batches:
         if cnt > 1:
             idx = true_inds[first:first + cnt - 1]
-            if torch.is_tensor(frames):
+            if hasattr(frames, 'select'):
+                sel = frames.select(idx).to(dev)
+            elif torch.is_tensor(frames):
                 sel = frames[torch.as_tensor(idx, device=frames.device)].to(dev)
             else:
                 sel = torch.from_numpy(np.ascontiguousarray(np.asarray(frames)[idx])).to(dev)
@@ -366,6 +368,36 @@ def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn=''
 
 
 smartVidCrop = smart_vid_crop      # BASELINE.json's spelling of the entry point
+
+
+def smart_vid_crop_ratios(video_path, CP, ratios, engine=None, verbose=False):
+    """Several target aspect ratios for one video with the saliency / clustering work done once
+    (the reference's driver re-runs the whole pipeline per ratio, smartVidCrop.py:2722-2775, or
+    re-uses its pickled feature cache :2244-2256).  -> {ratio: (VD, smart_crop_results)}; results
+    are identical to calling smart_vid_crop once per ratio, because nothing before
+    sc_calc_dest_size depends on out_ratio."""
+    import copy
+    out = {}
+    base = None
+    for ratio in ratios:
+        cp = dict(CP, out_ratio=ratio)
+        if base is None:
+            VD, res = smart_vid_crop(video_path, cp, save_vid=False, engine=engine, verbose=verbose)
+            base = (VD, res)
+        else:
+            VD = _LazySmaps({k: (copy.copy(v) if isinstance(v, list) else v) for k, v in base[0].items()})
+            res = dict(base[1])
+            VD = sc_calc_dest_size(VD, cp)
+            VD['dxs'], VD['dys'] = temporal.smoothing(VD['dxi'], VD['dyi'], VD['segmentation'], VD['fr'], cp)
+            VD = sc_compute_bb(VD, cp)
+            if cp['shift_time'] > 0:
+                temporal.shift_time(VD['bbs'], cp['shift_time'])
+            res['params'] = ''.join(' %-18s : %s\n' % (k, str(v)) for k, v in cp.items())
+            res['info'] = ' (%dx%d)->(%dx%d)->(%dx%d)->(%dx%d)\n' % (
+                VD['h_orig'], VD['w_orig'], VD['h_process'], VD['w_process'], VD['h_final'], VD['w_final'],
+                VD['fbb_h'], VD['fbb_w'])
+        out[ratio] = (VD, res)
+    return out
 
 
 def write_results(results_out, vid_fn, out_ratio, vid_data, info_dict):

@@ -30,3 +30,41 @@ def blob_frames(n, h=360, w=640, seed=0, n_blobs=None, dtype=np.uint8):
             img += g[:, :, None] * col[b][None, None, :]
         out[i] = np.clip(img, 0, 255).astype(dtype)
     return out
+
+
+class LazyBlobVideo:
+    """A synthetic video whose frames are generated on demand on the GPU (torch), so a
+    RetargetVid-sized run (122 684 frames of 640x360) never materialises 85 GB of pixels.
+    ``len(v)`` = frame count, ``v.select(idx)`` -> uint8 CUDA tensor [len(idx),h,w,3].
+    Deterministic for a given seed and device type."""
+
+    def __init__(self, n, h=360, w=640, seed=0, device='cuda'):
+        import torch
+        self.n, self.h, self.w, self.seed, self.device = n, h, w, seed, torch.device(device)
+        rng = np.random.RandomState(seed)
+        nb = int(rng.randint(1, 4))
+        s = max(h, w) / 640.0
+        self.p = dict(cx=rng.uniform(0.15 * w, 0.85 * w, nb), cy=rng.uniform(0.2 * h, 0.8 * h, nb),
+                      vx=rng.uniform(-3, 3, nb) * s, vy=rng.uniform(-2, 2, nb) * s,
+                      sig=rng.uniform(20, 60, nb) * s, amp=rng.uniform(150, 200, nb),
+                      col=rng.uniform(0.7, 1.0, (nb, 3)))
+
+    def __len__(self):
+        return self.n
+
+    def select(self, idx):
+        import torch
+        dev = self.device
+        t = torch.as_tensor(list(idx), dtype=torch.float32, device=dev).view(-1, 1, 1)
+        ys = torch.arange(self.h, dtype=torch.float32, device=dev).view(1, -1, 1)
+        xs = torch.arange(self.w, dtype=torch.float32, device=dev).view(1, 1, -1)
+        # deterministic low-amplitude texture (a hash of position and frame) instead of a host RNG stream
+        tex = torch.frac(torch.sin(xs * 12.9898 + ys * 78.233 + t * 37.719 + self.seed) * 43758.5453) * 30.0 + 10.0
+        img = tex.unsqueeze(-1).expand(-1, -1, -1, 3).clone()
+        p = self.p
+        for b in range(len(p['cx'])):
+            x0 = torch.remainder(p['cx'][b] + p['vx'][b] * t, self.w)
+            y0 = torch.remainder(p['cy'][b] + p['vy'][b] * t, self.h)
+            g = p['amp'][b] * torch.exp(-((xs - x0) ** 2 + (ys - y0) ** 2) / (2 * p['sig'][b] ** 2))
+            img += g.unsqueeze(-1) * torch.as_tensor(p['col'][b], dtype=torch.float32, device=dev).view(1, 1, 1, 3)
+        return img.clamp_(0, 255).to(torch.uint8).contiguous()

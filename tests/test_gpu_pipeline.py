@@ -81,3 +81,20 @@ def test_evaluator_on_gpu_reproduces_published_numbers(golden_dir, tmp_path):
     assert all(abs(a - b) < 1e-3 for a, b in zip(scores['1-3'], ref13))      # README.md:57-62
     assert all(abs(a - b) < 1e-3 for a, b in zip(scores['3-1'], ref31))
     assert ',48.639,50.855,49.935,' in open(str(tmp_path / 'eval_current.txt')).read()
+
+
+def test_multi_ratio_run_equals_separate_calls_and_lazy_frames(engine):
+    video = dict(fr=30.0, frame_count=120, w=640, h=360, frames=synth.LazyBlobVideo(120, seed=21),
+                 trans_inds=[0, 55, 120])
+    CP = S.sc_init_crop_params()
+    both = S.smart_vid_crop_ratios(video, CP, ('1:3', '3:1'), engine=engine)
+    for ratio in ('1:3', '3:1'):
+        VD, _ = S.smart_vid_crop(video, dict(CP, out_ratio=ratio), save_vid=False, engine=engine)
+        assert VD['bbs'] == both[ratio][0]['bbs'] and len(VD['bbs']) == 120
+    b13, b31 = np.array(both['1:3'][0]['bbs']), np.array(both['3:1'][0]['bbs'])
+    assert (b13[:, 2] - b13[:, 0] == 120).all() and (b13[:, 1] == 0).all() and (b13[:, 3] == 360).all()
+    assert (b31[:, 3] - b31[:, 1] == 213).all() and (b31[:, 0] == 0).all() and (b31[:, 2] == 640).all()
+    # the lazy generator is deterministic and indexable in any order
+    a = video['frames'].select([5, 17])
+    b = video['frames'].select([17])
+    assert torch.equal(a[1], b[0]) and a.shape == (2, 360, 640, 3) and a.dtype == torch.uint8

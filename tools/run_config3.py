@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""BASELINE config 3: a RetargetVid-shaped run — 200 synthetic 640x360 videos with the real
+frame counts (read from the annotation fixtures), targets 1:3 and 3:1 (saliency once, boxes
+twice), videos sharded over the ranks, boxes all_gathered, rank 0 writes
+results/<run>/<vid>_<w>-<h>.txt (+ _info.txt) and scores them with the evaluator counterpart.
+
+  python tools/run_config3.py [--videos 200] [--max-frames 0] [--out gpurun_out/config3]
+  python -m torch.distributed.run --nproc-per-node N tools/run_config3.py ...
+
+The IoU numbers are meaningless (synthetic pixels against human annotations); the run checks
+plumbing, sharding determinism and throughput."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from retargetvid_amd import dist as D, evaluate as E, ops, smartVidCrop as S, synth   # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--videos', type=int, default=200)
+    ap.add_argument('--max-frames', type=int, default=0, help='truncate every video (0 = real length)')
+    ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'config3'))
+    ap.add_argument('--annotations', default=os.path.join(ROOT, 'tests', 'golden', 'retargetvid'))
+    args = ap.parse_args()
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+    annots = E.load_annotations(args.annotations)
+    vids = E.VID_INDS[:args.videos]
+    counts = [len(annots[0]['1-3'][v]) for v in vids]
+    if args.max_frames:
+        counts = [min(c, args.max_frames) for c in counts]
+    mine = D.shard_videos(counts, world)[rank]
+    eng = ops.Engine(seed=0)
+    CP = S.sc_init_crop_params()
+    ratios = ('1:3', '3:1')
+    local_boxes = {r: {} for r in ratios}
+    infos = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_sal = 0
+    for i in mine:
+        n = counts[i]
+        rng = np.random.RandomState(vids[i])
+        cuts = sorted(set([0] + [int(c) for c in rng.randint(20, max(21, n - 20), rng.randint(0, 4))]))
+        video = dict(fr=30.0, frame_count=n, w=640, h=360, frames=synth.LazyBlobVideo(n, seed=vids[i]),
+                     trans_inds=cuts + [n])
+        res = S.smart_vid_crop_ratios(video, CP, ratios, engine=eng)
+        for r in ratios:
+            local_boxes[r][i] = np.asarray(res[r][0]['bbs'], np.int32)
+        infos[i] = {r: res[r][1] for r in ratios}
+        n_sal += res[ratios[0]][0]['fc_sel']
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    allb = {r: D.gather_boxes(local_boxes[r], counts) for r in ratios}
+    if rank == 0:
+        run_dir = os.path.join(args.out, 'synthetic_default')
+        for i, v in enumerate(vids):
+            for r in ratios:
+                S.write_results(run_dir, '%03d' % v, r, {'bbs': allb[r][i].tolist()}, infos.get(i, {}).get(r, {}))
+        score = None
+        if args.videos == 200 and not args.max_frames:
+            rows, _ = E.evaluate(args.out, args.annotations, out_path=os.path.join(args.out, 'eval_current.txt'))
+            score = {ar: [round(x, 3) for x in s] for ar, s in rows[0][1].items()}
+        total_frames = sum(counts)
+        print(json.dumps(dict(config='RetargetVid-shaped synthetic set', videos=len(vids), world=world,
+                              video_frames=total_frames, saliency_frames_rank0=n_sal, seconds_rank0=round(dt, 2),
+                              video_frames_per_s_rank0=round(sum(counts[i] for i in mine) / dt, 1),
+                              saliency_frames_per_s_rank0=round(n_sal / dt, 1), eval=score)))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -226,6 +226,16 @@ def main():
             gbs = byt * steps / (dom_ms * 1e-3) / 1e9
             roof = dict(bound='hbm', achieved=round(gbs, 3), peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=round(gbs / HBM_PEAK_GBS, 6), traffic=None)
+        # un-pipelined view of the same class (the profiling pass before the timed region) and the PMC traffic
+        iso_ms, iso_n = per_class[dominant]
+        if dominant == 'pw' and iso_ms > 0:
+            roof.update(achieved_isolated=round(work['pw_flops'] / (iso_ms * 1e-3) / 1e12, 3),
+                        frac_isolated=round(work['pw_flops'] / (iso_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 5))
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as fp:
+                roof['traffic'] = json.load(fp)['classes'][dominant]['hbm_bytes_per_launch']
+        except Exception:
+            pass
         roof.update(kernel=dominant, launches=dom_launches, avg_launch_ms=round(ms_per_launch, 4),
                     class_ms_per_step={k: round(v[0], 3) for k, v in per_class.items()})
         cpu = None

@@ -83,7 +83,7 @@ struct SvcHandle {
     uint8_t *depth_pinned = nullptr;   // pinned staging ring for the per-map round numbers
     unsigned depth_slot = 0;
     int chunk = 32;                    // frames per network pass
-    int pw_pf = 4;                     // k_pw operand prefetch depth selector (SVC_PW_PF: 1, 2, 4)
+    bool pw16 = true;                  // 16x16x4 MFMA pointwise kernel for narrow short-K layers (SVC_PW16=0: always 32x32x2)
     int fuse_max = 7;                  // backbone blocks 1..fuse_max run as the fused inverted-residual kernel (SVC_FUSE_MAX, 0..13)
     // per-kernel-class event log (svc_profile_*)
     int prof_class = -1;

@@ -287,7 +287,8 @@ __global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx
     for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    // software pipeline: the operands of PF k-steps (8 deep each) are in flight ahead of the MFMAs
+    // the operands of PF k-steps (8 deep each) are in flight ahead of the MFMAs (PF = 1 measured
+    // fastest on MI355X: these layers are bound by the L1 line rate, not by load latency)
     const int nsteps = K >> 3;
     float4 A[PF], B[PF][TN];
 #pragma unroll
@@ -336,6 +337,72 @@ __global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx
                 Y[(size_t)rr * ldy + col] = v;
             }
         }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// Pointwise conv on v_mfma_f32_16x16x4_f32 (K % 16 == 0): the four 16-lane groups of a wave
+// carry four k slots, so one float4 load instruction covers 16 rows x 64 contiguous bytes
+// (16 cache lines) instead of 32 rows x 32 bytes (32 lines) — these layers are bound by the
+// L1 line rate (SQ_WAIT_ANY ~ 68 % in k_pw).  Wave tile 32 x (32*TN) = 2 x 2TN accumulators
+// of 16x16; lane l (r16 = l&15, q = l>>4) feeds A[r16][k0+4q+j], B[k0+4q+j][r16] in MFMA j.
+// --------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int TN>
+__global__ __launch_bounds__(256) void k_pw16(const float *__restrict__ X, int ldx, const float *__restrict__ Wt,
+                                              const float *__restrict__ bias, const float *__restrict__ R, int ldr,
+                                              float *__restrict__ Y, int ldy, int M, int N, int Npad, int K,
+                                              int relu6) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * 128 + wave * 32;
+    const int n0 = blockIdx.y * (32 * TN);
+    if (m0 >= M) return;
+    const float *xa[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) xa[i] = X + (size_t)min(m0 + 16 * i + r16, M - 1) * ldx + 4 * q;
+    const float *wb[2 * TN];
+#pragma unroll
+    for (int c = 0; c < 2 * TN; ++c) wb[c] = Wt + (size_t)min(n0 + 16 * c + r16, Npad - 1) * K + 4 * q;
+    f32x4 acc[2][2 * TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int c = 0; c < 2 * TN; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][c][e] = 0.f;
+#pragma unroll 2
+    for (int k = 0; k < K; k += 16) {
+        float4 a[2], b[2 * TN];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *(const float4 *)(xa[i] + k);
+#pragma unroll
+        for (int c = 0; c < 2 * TN; ++c) b[c] = *(const float4 *)(wb[c] + k);
+#define PW16_STEP(EL)                                                                                   \
+    _Pragma("unroll") for (int c = 0; c < 2 * TN; ++c) {                                                \
+        acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0].EL, b[c].EL, acc[0][c], 0, 0, 0);        \
+        acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1].EL, b[c].EL, acc[1][c], 0, 0, 0);        \
+    }
+        PW16_STEP(x) PW16_STEP(y) PW16_STEP(z) PW16_STEP(w)
+#undef PW16_STEP
+    }
+#pragma unroll
+    for (int c = 0; c < 2 * TN; ++c) {
+        const int col = n0 + 16 * c + r16;
+        if (col >= N) continue;
+        const float bv = bias[col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int rr = m0 + 16 * i + 4 * q + e;
+                if (rr < M) {
+                    float v = acc[i][c][e] + bv;
+                    if (R) v += R[(size_t)rr * ldr + col];
+                    if (relu6) v = fminf(fmaxf(v, 0.f), 6.f);
+                    Y[(size_t)rr * ldy + col] = v;
+                }
+            }
     }
 }
 
@@ -681,17 +748,26 @@ static int launch_pw(SvcHandle *h, hipStream_t s, const float *X, int ldx, const
     int TN = 4;
     while (TN > 1 && (TN > tiles || rb * ceil_div(tiles, TN) < 512)) --TN;
     dim3 grid(rb, ceil_div(tiles, TN));
+    // measured on MI355X: the 16x16x4 form wins for single-N-tile layers with a short K (the
+    // high-resolution project layers), the 32x32x2 form everywhere else
+    if (h->pw16 && TN == 1 && K % 16 == 0 && K >= 64 && K <= 192) {
+#define PW16_ARGS X, ldx, L.w.dev, L.b.dev, R, ldr, Y, ldy, M, N, Npad, K, L.relu6
+        switch (TN) {
+            case 4: k_pw16<4><<<grid, 256, 0, s>>>(PW16_ARGS); break;
+            case 3: k_pw16<3><<<grid, 256, 0, s>>>(PW16_ARGS); break;
+            case 2: k_pw16<2><<<grid, 256, 0, s>>>(PW16_ARGS); break;
+            default: k_pw16<1><<<grid, 256, 0, s>>>(PW16_ARGS); break;
+        }
+#undef PW16_ARGS
+        SVC_CHECK_LAUNCH();
+        return SVC_OK;
+    }
 #define PW_ARGS X, ldx, L.w.dev, L.b.dev, R, ldr, Y, ldy, M, N, Npad, K, L.relu6
     switch (TN) {
-#define PW_CASE(TN_, PFA_, PFB_, PFC_)                                                  \
-    if (h->pw_pf == 1) k_pw<TN_, PFA_><<<grid, 256, 0, s>>>(PW_ARGS);                    \
-    else if (h->pw_pf == 2) k_pw<TN_, PFB_><<<grid, 256, 0, s>>>(PW_ARGS);               \
-    else k_pw<TN_, PFC_><<<grid, 256, 0, s>>>(PW_ARGS)
-        case 4: PW_CASE(4, 1, 2, 2); break;
-        case 3: PW_CASE(3, 1, 2, 2); break;
-        case 2: PW_CASE(2, 1, 2, 4); break;
-        default: PW_CASE(1, 1, 2, 4); break;
-#undef PW_CASE
+        case 4: k_pw<4, 1><<<grid, 256, 0, s>>>(PW_ARGS); break;
+        case 3: k_pw<3, 1><<<grid, 256, 0, s>>>(PW_ARGS); break;
+        case 2: k_pw<2, 1><<<grid, 256, 0, s>>>(PW_ARGS); break;
+        default: k_pw<1, 1><<<grid, 256, 0, s>>>(PW_ARGS); break;
     }
 #undef PW_ARGS
     SVC_CHECK_LAUNCH();
@@ -1116,8 +1192,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     h->device = device;
     const char *env = getenv("SVC_CHUNK");
     if (env && atoi(env) > 0) h->chunk = atoi(env);
-    env = getenv("SVC_PW_PF");
-    if (env) h->pw_pf = atoi(env);
+    env = getenv("SVC_PW16");
+    if (env) h->pw16 = atoi(env) != 0;
     env = getenv("SVC_FUSE_MAX");
     if (env) h->fuse_max = std::min(13, std::max(0, atoi(env)));
     int rc = h->blob.ensure(n_bytes);

@@ -139,6 +139,10 @@ try:
         torch.cuda.synchronize(); t3 = time.time()
         print('B=32: resize %.2f ms, saliency %.2f ms, tail %.2f ms  (N mean %.0f)' % (
             (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, stats[:, 0].float().mean().item()))
+    for i in range(0, 32, 4):
+        st = eng.cluster_state(i, 35000)
+        print('  warm frame %2d: N=%5d nclusters %3d  finish stamps (us): sorted %.1f hierarchy %.1f chosen %.1f done %.1f | prim %.1f us' % (
+            i, st['n'], st['hdr'][4], st['hdr'][8] / 100.0, st['hdr'][9] / 100.0, st['hdr'][10] / 100.0, st['hdr'][11] / 100.0, st['hdr'][12] / 100.0))
 except Exception:
     traceback.print_exc(); ok = False
 

@@ -51,6 +51,9 @@ typedef struct SvcParams {
     int32_t select_sum;           /* CP['select_sum']: 1 = cluster sum, else cluster max */
     int32_t op_close;             /* CP['op_close']                                    */
     int32_t clust_filt;           /* CP['clust_filt']: 0 skips filtering, centres only */
+    int32_t resize_factor;        /* CP['resize_factor'] (integer, 1 = off): cluster on the map shrunk by this
+                                     factor (INTER_LINEAR down, then up again) and take the centre of the
+                                     INTER_NEAREST-shrunk map, smartVidCrop.py:1078-1084, :1158, :1184 */
 } SvcParams;
 
 /* Per-call diagnostics written by svc_cluster_center when `stats` is non-NULL:

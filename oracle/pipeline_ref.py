@@ -6,8 +6,9 @@ modules, what smartVidCrop.py does for a video handed over as decoded RGB frames
 (sc_init_crop_params, :132-209), then smart_vid_crop (:2218-2614): destination size,
 threshold, cluster loop with cut blend, centres, empty-centre fill, interpolation,
 smoothing, boxes.  Parameter-gated branches that both published parameter sets leave
-off (border detection, mean-saliency / coverage gates, rendering) are not restated;
-focus stability (best settings only) is not restated yet.
+off (border detection, mean-saliency / coverage gates, rendering) are not restated.
+The best-settings branch (resize_factor=4 around the cluster filter and the centre, sum-weighted
+cluster choice, focus stability, Savitzky-Golay instead of LOESS) is restated too.
 
 Quirks reproduced on purpose: the off-by-one that leaves the last
 selected frame of every read batch with an all-zero map (:696-709), the batch-local
@@ -112,6 +113,9 @@ def crop_from_maps(VD, CP, stage=None):
     if stage is not None:
         stage['centres_raw'] = (list(dx), list(dy))
     VD['dx'], VD['dy'] = temporal_ref.handle_empty_centers(dx, dy, VD['segmentation_sel'])
+    if CP['focus_stability']:
+        VD['dx'], VD['dy'], VD['jumps'], VD['jumps_inds'] = temporal_ref.focus_stability(
+            VD['dx'], VD['dy'], VD['smaps'], VD['fr'], CP)
     VD['dxi'], VD['dyi'] = temporal_ref.interpolate_centres(VD['dx'], VD['dy'], VD['segmentation'],
                                                             VD['segmentation_sel'], VD['true_inds'])
     VD['dxs'], VD['dys'] = temporal_ref.smoothing(VD['dxi'], VD['dyi'], VD['segmentation'], VD['fr'], CP)

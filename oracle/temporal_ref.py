@@ -180,3 +180,75 @@ def shift_time(bbs, shift):
         for i in range(len(bbs) - shift):
             bbs[i] = bbs[i + shift]
     return bbs
+
+
+# ---- focus stability (best settings only): smartVidCrop.py:1337-1455, :2425-2473 -------------
+def points_on_line(p1x, p1y, p2x, p2y, image_w, image_h, min_d=1):
+    """smartVidCrop.py:1337-1393 (a form of Bresenham between two float centres).  The reference
+    casts with the removed ``np.int``; the intended truncation (astype(int)) is restated."""
+    dX, dY = p2x - p1x, p2y - p1y
+    dXa, dYa = np.abs(dX), np.abs(dY)
+    if dXa < min_d and dYa < min_d:
+        return None
+    buf = np.empty(shape=(int(math.ceil(np.maximum(dYa, dXa))), 2), dtype=np.float32)
+    buf.fill(np.nan)
+    negY, negX = p1y > p2y, p1x > p2x
+    if p1x == p2x:
+        buf[:, 0] = p1x
+        buf[:, 1] = np.arange(p1y - 1, p1y - dYa - 1, -1) if negY else np.arange(p1y + 1, p1y + dYa + 1)
+    elif p1y == p2y:
+        buf[:, 1] = p1y
+        buf[:, 0] = np.arange(p1x - 1, p1x - dXa - 1, -1) if negX else np.arange(p1x + 1, p1x + dXa + 1)
+    else:
+        try:
+            if dYa > dXa:
+                slope = np.float32(dX) / np.float32(dY)
+                buf[:, 1] = np.arange(p1y - 1, p1y - dYa - 1, -1) if negY else np.arange(p1y + 1, p1y + dYa + 1)
+                buf[:, 0] = (slope * (buf[:, 1] - p1y)).astype(int) + p1x
+            else:
+                slope = np.float32(dY) / np.float32(dX)
+                buf[:, 0] = np.arange(p1x - 1, p1x - dXa - 1, -1) if negX else np.arange(p1x + 1, p1x + dXa + 1)
+                buf[:, 1] = (slope * (buf[:, 0] - p1x)).astype(int) + p1y
+        except Exception:
+            return None
+    cx, cy = buf[:, 0], buf[:, 1]
+    return buf[(cx >= 0) & (cy >= 0) & (cx < image_w) & (cy < image_h)]
+
+
+def mean_saliency_on_jump(sal_img, prev_x, prev_y, cur_x, cur_y, min_d):
+    """sc_check_for_extra_cuts, smartVidCrop.py:1395-1455."""
+    h, w = sal_img.shape
+    try:
+        pts = points_on_line(prev_x, prev_y, cur_x, cur_y, w, h, min_d=min_d)
+    except Exception:
+        pts = None
+    if pts is None:
+        return 255
+    total, n = 0.0, 0
+    for i in range(pts.shape[0]):
+        if np.isnan(pts[i, 0]):
+            continue
+        n += 1
+        total += sal_img[math.floor(pts[i, 1]), math.floor(pts[i, 0])]
+    return float(total) / float(n) if n > 0 else 255
+
+
+def focus_stability(dx, dy, smaps_hwn, fr, CP):
+    """smartVidCrop.py:2425-2473 -> (dx, dy, jumps, jumps_inds)."""
+    dx, dy = list(dx), list(dy)
+    n = len(dx)
+    jumps, inds = [255] * n, []
+    for i in range(1, n):
+        m = mean_saliency_on_jump(smaps_hwn[:, :, i], dx[i - 1], dy[i - 1], dx[i], dy[i], CP['min_d_jump'])
+        jumps[i] = m
+        if m < CP['foces_stab_t']:
+            inds.append(i)
+    for i in range(0, len(inds) - 1):
+        start = max(inds[i] - 1, 0)
+        end = min(inds[i + 1] + 1, n - 1)
+        dur = ((end - start) * CP['skip']) / fr
+        if dur <= CP['foces_stab_s']:
+            for j in range(end - start):
+                dx[start + j] = dx[start]
+                dy[start + j] = dy[start]
+    return dx, dy, jumps, inds

@@ -16,7 +16,8 @@ EXPORTS = ('svc_last_error', 'svc_create', 'svc_destroy', 'svc_resize_frames_u8'
 
 class SvcParams(ctypes.Structure):
     _fields_ = [('hdbscan_min', ctypes.c_int32), ('hdbscan_min_samples', ctypes.c_int32),
-                ('select_sum', ctypes.c_int32), ('op_close', ctypes.c_int32), ('clust_filt', ctypes.c_int32)]
+                ('select_sum', ctypes.c_int32), ('op_close', ctypes.c_int32), ('clust_filt', ctypes.c_int32),
+                ('resize_factor', ctypes.c_int32)]
 
 
 class SvcError(RuntimeError):

@@ -80,6 +80,8 @@ struct SvcHandle {
     int tail_n_offsets = 0, tail_n_offsets1 = 0;
     int tail_frames = 0, tail_h = 0, tail_w = 0;
     size_t tail_frame_stride = 0;      // bytes of per-frame tail workspace
+    DevBuf rs_maps, rs_down, rs_up;    // resize_factor != 1: shrunk maps and the two INTER_LINEAR tables
+    int rs_h = 0, rs_w = 0, rs_factor = 0;
     uint8_t *depth_pinned = nullptr;   // pinned staging ring for the per-map round numbers
     unsigned depth_slot = 0;
     int chunk = 32;                    // frames per network pass

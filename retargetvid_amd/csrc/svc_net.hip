@@ -1284,6 +1284,7 @@ extern "C" int svc_destroy(SvcHandle *h) {
     svc_net_release(h);
     h->tail_ws.release();
     h->tail_offsets.release();
+    h->rs_maps.release(); h->rs_down.release(); h->rs_up.release();
     if (h->depth_pinned) (void)hipHostFree(h->depth_pinned);
     h->blob.release();
     delete h;

@@ -168,6 +168,66 @@ __global__ __launch_bounds__(256) void k_iou(const int4 *__restrict__ a, const i
 }
 
 // --------------------------------------------------------------------------------------
+// resize_factor != 1 (best settings): OpenCV INTER_LINEAR on single-channel u8 maps for the maps of
+// the current round, and the centre of the INTER_NEAREST-shrunk map.
+// tab (int32): xofs[ow] | xa[ow][2] | yofs[oh] | ya[oh][2] | xmax
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_map_resize(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                    const int *__restrict__ tab, const uint8_t *__restrict__ depth,
+                                                    int round, int h, int w, int oh, int ow) {
+    const int f = blockIdx.y;
+    if (depth[f] != round) return;
+    const int *xofs = tab, *xa = tab + ow, *yofs = tab + 3 * ow, *ya = tab + 3 * ow + oh;
+    const int xmax = tab[3 * ow + 3 * oh];
+    const uint8_t *src = in + (size_t)f * h * w;
+    uint8_t *dst = out + (size_t)f * oh * ow;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < oh * ow; i += gridDim.x * 256) {
+        const int oy = i / ow, ox = i - oy * ow;
+        const int sy = yofs[oy];
+        const uint8_t *r0 = src + (size_t)min(max(sy, 0), h - 1) * w, *r1 = src + (size_t)min(max(sy + 1, 0), h - 1) * w;
+        const int sx = xofs[ox], sx1 = min(sx + 1, w - 1);
+        int h0, h1;
+        if (ox < xmax) {
+            h0 = r0[sx] * xa[2 * ox] + r0[sx1] * xa[2 * ox + 1];
+            h1 = r1[sx] * xa[2 * ox] + r1[sx1] * xa[2 * ox + 1];
+        } else {
+            h0 = r0[sx] * 2048;
+            h1 = r1[sx] * 2048;
+        }
+        const int v = (((ya[2 * oy] * (h0 >> 4)) >> 16) + ((ya[2 * oy + 1] * (h1 >> 4)) >> 16) + 2) >> 2;
+        dst[i] = (uint8_t)min(max(v, 0), 255);
+    }
+}
+
+// centre of the non-zero samples of the nearest-neighbour shrunk map (sx = min(floor(x*factor), w-1)), times factor
+__global__ __launch_bounds__(256) void k_centre_nearest(const uint8_t *__restrict__ maps, int h, int w, int sh, int sw,
+                                                        int factor, double *__restrict__ xy) {
+    const int f = blockIdx.x;
+    const uint8_t *m = maps + (size_t)f * h * w;
+    __shared__ unsigned long long red[3 * 4];
+    unsigned long long cnt = 0, sr = 0, sc = 0;
+    for (int i = threadIdx.x; i < sh * sw; i += 256) {
+        const int r = i / sw, c = i - r * sw;
+        if (m[(size_t)min(r * factor, h - 1) * w + min(c * factor, w - 1)]) { ++cnt; sr += r; sc += c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o); sr += __shfl_xor(sr, o); sc += __shfl_xor(sc, o); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = cnt; red[4 + (threadIdx.x >> 6)] = sr; red[8 + (threadIdx.x >> 6)] = sc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt = red[0] + red[1] + red[2] + red[3];
+        sr = red[4] + red[5] + red[6] + red[7];
+        sc = red[8] + red[9] + red[10] + red[11];
+        if (cnt) {
+            xy[2 * f] = (double)sc / (double)cnt * (double)factor;
+            xy[2 * f + 1] = (double)sr / (double)cnt * (double)factor;
+        } else {
+            xy[2 * f] = xy[2 * f + 1] = __longlong_as_double(0x7FF8000000000000LL);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
 // k_compact: non-zero pixels in raster order
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TB) void k_compact(TailArgs A) {
@@ -788,6 +848,39 @@ extern "C" int svc_iou_i32(const int32_t *a, const int32_t *b, size_t n, double 
     return SVC_OK;
 }
 
+// OpenCV INTER_LINEAR tables for one axis with an explicit scale (see svc_net.hip for the frame version)
+static void cv_tab_axis(int src, int dst, double scale, bool horizontal, int *ofs, int *a, int *xmax_out) {
+    int xmax = dst;
+    for (int d = 0; d < dst; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        if (horizontal) {
+            if (s < 0) { f = 0.f; s = 0; }
+            if (s + 1 >= src) {
+                xmax = std::min(xmax, d);
+                if (s >= src - 1) { f = 0.f; s = src - 1; }
+            }
+        }
+        ofs[d] = s;
+        a[2 * d] = (int)std::min(std::max(lrintf((1.f - f) * 2048.f), -32768L), 32767L);
+        a[2 * d + 1] = (int)std::min(std::max(lrintf(f * 2048.f), -32768L), 32767L);
+    }
+    if (xmax_out) *xmax_out = xmax;
+}
+
+static int upload_map_tab(DevBuf &buf, int h, int w, int oh, int ow, double sy, double sx) {
+    std::vector<int> tab(3 * ow + 3 * oh + 1);
+    int xmax = ow;
+    cv_tab_axis(w, ow, sx, true, tab.data(), tab.data() + ow, &xmax);
+    cv_tab_axis(h, oh, sy, false, tab.data() + 3 * ow, tab.data() + 3 * ow + oh, nullptr);
+    tab[3 * ow + 3 * oh] = xmax;
+    int rc = buf.ensure(tab.size() * 4);
+    if (rc) return rc;
+    SVC_HIP(hipMemcpy(buf.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    return SVC_OK;
+}
+
 static int ensure_ring(SvcHandle *h) {
     if (h->tail_n_offsets) return SVC_OK;
     std::vector<uint32_t> v;
@@ -819,11 +912,28 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
         return SVC_E_INVALID;
     }
     if (params->hdbscan_min < 2) { svc_set_error("svc_cluster_center: hdbscan_min must be >= 2"); return SVC_E_INVALID; }
+    if (params->resize_factor < 1 || params->resize_factor > 16) { svc_set_error("svc_cluster_center: resize_factor must be an integer in 1..16"); return SVC_E_INVALID; }
     if (n == 0) return SVC_OK;
     SVC_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     int rc = ensure_ring(h);
     if (rc) return rc;
+    // best settings: the cluster filter runs on maps shrunk by resize_factor (cvRound sizes, scale = factor)
+    const int factor = params->clust_filt ? params->resize_factor : 1;
+    const int full_h = height, full_w = width;
+    uint8_t *full_maps = maps;
+    if (factor > 1) {
+        height = (int)lrint((double)full_h * (1.0 / factor));
+        width = (int)lrint((double)full_w * (1.0 / factor));
+        if (height < 1 || width < 1) { svc_set_error("svc_cluster_center: map too small for resize_factor"); return SVC_E_INVALID; }
+        if (h->rs_h != full_h || h->rs_w != full_w || h->rs_factor != factor) {
+            if ((rc = upload_map_tab(h->rs_down, full_h, full_w, height, width, (double)factor, (double)factor))) return rc;
+            if ((rc = upload_map_tab(h->rs_up, height, width, full_h, full_w, (double)height / full_h, (double)width / full_w))) return rc;
+            h->rs_h = full_h; h->rs_w = full_w; h->rs_factor = factor;
+        }
+        if ((rc = h->rs_maps.ensure((size_t)n * height * width))) return rc;
+        maps = (uint8_t *)h->rs_maps.p;
+    }
     const int cap = height * width;
     const int mc = hdb::max_clusters(cap, params->hdbscan_min);
     FrameWS L = make_layout(cap, mc);
@@ -868,7 +978,12 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
     for (int r = 0; r <= maxd; ++r) {
         A.round = r;
         if (r > 0) {
-            k_blend<<<dim3(8, n), 256, 0, s>>>(maps, depth_dev, r, hw);
+            k_blend<<<dim3(8, n), 256, 0, s>>>(full_maps, depth_dev, r, full_h * full_w);
+            SVC_CHECK_LAUNCH();
+        }
+        if (factor > 1) {
+            k_map_resize<<<dim3(8, n), 256, 0, s>>>(full_maps, maps, (const int *)h->rs_down.p, depth_dev, r, full_h, full_w,
+                                                    height, width);
             SVC_CHECK_LAUNCH();
         }
         {
@@ -886,8 +1001,21 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
             k_prim<<<n, TB, lds_prim, s>>>(A);
             SVC_CHECK_LAUNCH();
         }
-        ProfScope ps(h, SVC_K_FINISH, s);
-        k_finish<<<n, TB, lds_fin, s>>>(A);
+        {
+            ProfScope ps(h, SVC_K_FINISH, s);
+            k_finish<<<n, TB, lds_fin, s>>>(A);
+            SVC_CHECK_LAUNCH();
+        }
+        if (factor > 1) {
+            k_map_resize<<<dim3(16, n), 256, 0, s>>>(maps, full_maps, (const int *)h->rs_up.p, depth_dev, r, height, width,
+                                                     full_h, full_w);
+            SVC_CHECK_LAUNCH();
+        }
+    }
+    if (params->resize_factor > 1) {       // centre of the nearest-neighbour shrunk final map (also when clust_filt is off)
+        const int f2 = params->resize_factor;
+        k_centre_nearest<<<n, 256, 0, s>>>(full_maps, full_h, full_w, (int)lrint((double)full_h * (1.0 / f2)),
+                                           (int)lrint((double)full_w * (1.0 / f2)), f2, xy);
         SVC_CHECK_LAUNCH();
     }
     return SVC_OK;

@@ -274,9 +274,9 @@ def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn=''
     if CP['exit_on_spread_sal'] or CP['exit_on_low_cvrg'] or CP['t_border'] != -1:
         raise NotImplementedError('mean-saliency / coverage gates and border detection are disabled in both '
                                   'published parameter sets and are not part of this path')
-    if CP['resize_factor'] != 1.0 or CP['focus_stability'] or not CP['com_km']:
-        raise NotImplementedError('resize_factor != 1, focus_stability and com_km=False (use_best_settings) '
-                                  'are not implemented on the device path yet (SURVEY.md §8(f)-3)')
+    if not CP['com_km']:
+        raise NotImplementedError('com_km=False (centre = arg-max pixel, smartVidCrop.py:1165-1178) is not part of '
+                                  'either published parameter set and is not implemented')
     if save_vid and (final_vid_fn or demo_fn):
         raise NotImplementedError('video rendering is outside the saliency-to-crop path; pass save_vid=False')
     engine = engine or get_engine()
@@ -330,6 +330,11 @@ def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn=''
     VD['jumps'] = [255] * len(VD['dx'])
     VD['jumps_inds'] = []
     VD['dxnf'], VD['dynf'] = list(VD['dx']), list(VD['dy'])
+    t = time.perf_counter()
+    if CP['focus_stability']:            # best settings: hold the focus across short low-saliency jumps (host)
+        VD['dx'], VD['dy'], VD['jumps'], VD['jumps_inds'] = temporal.focus_stability(
+            VD['dx'], VD['dy'], VD['smaps'], VD['fr'], CP)
+    sc_register_time(t, '_focus_stability')
 
     t = time.perf_counter()
     VD['dxi'], VD['dyi'] = temporal.interpolate(VD['dx'], VD['dy'], VD['segmentation'], VD['segmentation_sel'],

@@ -12,6 +12,7 @@ Reference (smartVidCrop.py unless noted):
   butter_lowpass         sc_butter_lowpass_filter           :1599-1627
   loess / loess_handler  loess_handler :1629-1646 and 3rd_party_libs/loess/pyloess.py:13-95
   smoothing              sc_smoothing                       :1648-1734
+  focus_stability        sc_check_for_extra_cuts + focus hold :1337-1455, :2425-2473
   shift_time             sc_shift_time                      :1740-1746
 """
 import numpy as np
@@ -130,6 +131,60 @@ def smoothing(dxi, dyi, segmentation, fr, CP):
             dl = butter_lowpass(d, CP['lp_cutoff'], fr, CP['lp_order']) if CP['lp_filt'] else d
             out += loess_handler(dl, CP['loess_filt'], win, CP['loess_degree'])
     return dxs, dys
+
+
+def _points_on_line(p1x, p1y, p2x, p2y, w, h, min_d):
+    """get_points_on_line (smartVidCrop.py:1337-1393): integer-stepped samples strictly after p1 up
+    to p2 along the dominant axis; the reference's removed ``np.int`` cast is the intended
+    truncation.  -> float32 [m,2] (x, y) inside the image, or None for a jump below min_d."""
+    dX, dY = p2x - p1x, p2y - p1y
+    dXa, dYa = abs(dX), abs(dY)
+    if dXa < min_d and dYa < min_d:
+        return None
+    m = int(np.ceil(max(dYa, dXa)))
+    buf = np.full((m, 2), np.nan, np.float32)
+    sy = np.arange(p1y - 1, p1y - dYa - 1, -1) if p1y > p2y else np.arange(p1y + 1, p1y + dYa + 1)
+    sx = np.arange(p1x - 1, p1x - dXa - 1, -1) if p1x > p2x else np.arange(p1x + 1, p1x + dXa + 1)
+    try:
+        if p1x == p2x:
+            buf[:, 0], buf[:, 1] = p1x, sy
+        elif p1y == p2y:
+            buf[:, 1], buf[:, 0] = p1y, sx
+        elif dYa > dXa:
+            buf[:, 1] = sy
+            buf[:, 0] = (np.float32(dX) / np.float32(dY) * (buf[:, 1] - p1y)).astype(int) + p1x
+        else:
+            buf[:, 0] = sx
+            buf[:, 1] = (np.float32(dY) / np.float32(dX) * (buf[:, 0] - p1x)).astype(int) + p1y
+    except Exception:
+        return None
+    keep = (buf[:, 0] >= 0) & (buf[:, 1] >= 0) & (buf[:, 0] < w) & (buf[:, 1] < h)
+    return buf[keep]
+
+
+def focus_stability(dx, dy, smaps_hwn, fr, CP):
+    """Jump statistics + focus hold (smartVidCrop.py:1395-1455, :2425-2473).  smaps_hwn: the
+    filtered maps in the reference's [H,W,n] layout.  -> (dx, dy, jumps, jumps_inds)."""
+    dx, dy = list(dx), list(dy)
+    n = len(dx)
+    h, w = smaps_hwn.shape[:2]
+    jumps, inds = [255] * n, []
+    for i in range(1, n):
+        pts = _points_on_line(dx[i - 1], dy[i - 1], dx[i], dy[i], w, h, CP['min_d_jump'])
+        if pts is not None:
+            ok = ~np.isnan(pts[:, 0])
+            if ok.any():
+                xs = np.floor(pts[ok, 0]).astype(np.int64)
+                ys = np.floor(pts[ok, 1]).astype(np.int64)
+                jumps[i] = float(smaps_hwn[ys, xs, i].astype(np.float64).sum()) / float(ok.sum())
+        if jumps[i] < CP['foces_stab_t']:
+            inds.append(i)
+    for a, b in zip(inds[:-1], inds[1:]):
+        start, end = max(a - 1, 0), min(b + 1, n - 1)
+        if ((end - start) * CP['skip']) / fr <= CP['foces_stab_s']:
+            for j in range(end - start):
+                dx[start + j], dy[start + j] = dx[start], dy[start]
+    return dx, dy, jumps, inds
 
 
 def shift_time(bbs, shift):

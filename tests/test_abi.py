@@ -26,8 +26,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layout_matches_header():
-    assert ctypes.sizeof(_lib.SvcParams) == 20
-    assert [f[0] for f in _lib.SvcParams._fields_] == ['hdbscan_min', 'hdbscan_min_samples', 'select_sum', 'op_close', 'clust_filt']
+    assert ctypes.sizeof(_lib.SvcParams) == 24
+    assert [f[0] for f in _lib.SvcParams._fields_] == ['hdbscan_min', 'hdbscan_min_samples', 'select_sum', 'op_close',
+                                                       'clust_filt', 'resize_factor']
 
 
 def test_create_reports_errors():

@@ -131,6 +131,10 @@ def test_tail_bit_exact_other_parameters(engine):
     maps = np.stack(maps)
     best = dict(P.init_crop_params(), t_threshold=90, hdbscan_min=5, hdbscan_min_samples=3, select_sum=1)
     _check_tail(engine, maps, None, best)
+    # the published best-settings set: cluster on maps shrunk by 4 (INTER_LINEAR down and up), nearest-shrunk centre
+    _check_tail(engine, maps, np.array([1, 1, 0, 0, 1, 0], np.uint8), P.init_crop_params(True))
+    _check_tail(engine, maps, None, dict(P.init_crop_params(), resize_factor=2))
+    _check_tail(engine, maps, None, dict(P.init_crop_params(True), clust_filt=False))
     _check_tail(engine, maps, np.array([1, 0, 1, 1, 0, 0], np.uint8), dict(P.init_crop_params(), op_close=False))
     _check_tail(engine, maps, None, dict(P.init_crop_params(), clust_filt=False))
     _check_tail(engine, maps, None, dict(P.init_crop_params(), hdbscan_min=40, hdbscan_min_samples=10))

@@ -58,7 +58,22 @@ def test_pickle_door_and_error_conventions(engine, tmp_path):
     with pytest.raises(NotImplementedError):
         S.smart_vid_crop('clip.mp4', CP, save_vid=False, engine=engine)
     with pytest.raises(NotImplementedError):
-        S.smart_vid_crop(video, S.sc_init_crop_params(use_best_settings=True), save_vid=False, engine=engine)
+        S.smart_vid_crop(video, dict(CP, com_km=False), save_vid=False, engine=engine)
+
+
+def test_best_settings_match_oracle(engine, synthetic_sd):
+    """use_best_settings=True (ISM'21 set): threshold 90, HDBSCAN 5/3 on maps shrunk by 4, sum-weighted cluster
+    choice, nearest-shrunk centres, focus stability, Savitzky-Golay smoothing."""
+    torch.set_num_threads(8)
+    video = _video(90, 8, [0, 50, 90])
+    CP = S.sc_init_crop_params(use_best_settings=True)
+    CP['out_ratio'] = '1:3'
+    VD, res = S.smart_vid_crop(video, CP, save_vid=False, engine=engine)
+    ref = P.smart_vid_crop(video, dict(P.init_crop_params(True), out_ratio='1:3'), synthetic_sd)
+    got, exp = np.array(VD['bbs']), np.array(ref['bbs'])
+    assert got.shape == exp.shape == (90, 4) and np.abs(got - exp).max() <= 1
+    assert VD['jumps_inds'] == ref['jumps_inds']
+    assert 't__focus_stability' in res
 
 
 def test_operator_boundary_layout(engine, synthetic_sd):

@@ -74,7 +74,6 @@ struct TailArgs {
     int round;
     int n, h, w;
     int mcs, min_samples, select_sum, op_close, clust_filt;
-    int variant;            // diagnostic switches (SVC_VARIANT env): 1 = 64-bit Prim keys, 2 = hierarchy state in global memory
     const uint32_t *ring;   // sorted neighbour offsets
     int n_ring, n_ring1;    // all offsets within RING_R / the prefix within RING_R1
     double *xy;
@@ -386,57 +385,6 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 }
 
 template <int PT>
-__device__ __forceinline__ void prim_regs64(const uint32_t *__restrict__ core_g, hdb::Edge *__restrict__ mst, int N,
-                                            const uint16_t *rc16, unsigned long long *slots) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t reach[PT], corev[PT];
-    unsigned long long alive = 0;
-#pragma unroll
-    for (int i = 0; i < PT; ++i) {
-        const int p = tid + i * TB;
-        reach[i] = REACH_INF;
-        corev[i] = 0;
-        if (p < N) { corev[i] = core_g[p]; alive |= 1ull << i; }
-    }
-    uint32_t cur = 0;
-    uint32_t cv = rc16[0];
-    int cr = cv & 255, cc = cv >> 8;
-    uint32_t ccore = core_g[0];
-    if (tid == 0) alive &= ~1ull;
-    for (int step = 0; step < N - 1; ++step) {
-        unsigned long long best = ~0ull;
-#pragma unroll
-        for (int i = 0; i < PT; ++i) {
-            if ((alive >> i) & 1ull) {
-                const int p = tid + i * TB;
-                const uint32_t v = rc16[p];
-                const int dr = (int)(v & 255) - cr, dc = (int)(v >> 8) - cc;
-                uint32_t m = (uint32_t)(dr * dr + dc * dc);
-                m = max(max(m, corev[i]), ccore);
-                if (m < reach[i]) reach[i] = m;
-                const unsigned long long key =
-                    ((unsigned long long)reach[i] << 33) | ((unsigned long long)p << 17) | corev[i];
-                best = key < best ? key : best;
-            }
-        }
-        best = wave_min_u64(best);
-        unsigned long long *sl = slots + (step & 1) * NW16;
-        if (lane == 0) sl[wave] = best;
-        __syncthreads();
-        unsigned long long w = sl[0];
-#pragma unroll
-        for (int i = 1; i < NW16; ++i) { unsigned long long t = sl[i]; w = t < w ? t : w; }
-        const uint32_t nidx = (uint32_t)(w >> 17) & 0xFFFFu;
-        if (tid == 0) mst[step] = hdb::Edge{(uint16_t)cur, (uint16_t)nidx, (uint32_t)(w >> 33)};
-        if ((int)(nidx & (TB - 1)) == tid) alive &= ~(1ull << (nidx >> 10));
-        ccore = (uint32_t)w & 0x1FFFFu;
-        cv = rc16[nidx];
-        cr = cv & 255; cc = cv >> 8;
-        cur = nidx;
-    }
-}
-
-template <int PT>
 __device__ __forceinline__ void prim_regs32(const uint32_t *__restrict__ core_g, hdb::Edge *__restrict__ mst, int N,
                                             const uint16_t *rc16, uint2 *slots) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -549,11 +497,6 @@ __global__ __launch_bounds__(TB) void k_prim(TailArgs A) {
     const uint32_t *core = (const uint32_t *)(ws + A.L.core);
     hdb::Edge *mst = (hdb::Edge *)(ws + A.L.mst);
     long long t0 = wall_clock64();
-    if (A.variant & 1) {
-        if (N <= 4 * TB) prim_regs64<4>(core, mst, N, rc16, slots);
-        else if (N <= 12 * TB) prim_regs64<12>(core, mst, N, rc16, slots);
-        else prim_global(core, (uint32_t *)(ws + A.L.reach), mst, N, rc16, slots);
-    } else
     if (N <= 2 * TB) prim_regs32<2>(core, mst, N, rc16, (uint2 *)slots);
     else if (N <= 4 * TB) prim_regs32<4>(core, mst, N, rc16, (uint2 *)slots);
     else if (N <= 8 * TB) prim_regs32<8>(core, mst, N, rc16, (uint2 *)slots);
@@ -748,7 +691,7 @@ __global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
         radix_pass(eb, ea, N - 1, 12, S.hist, S.run, S.wcnt);
         if (tid == 0) hdr[8] = (int)(wall_clock64() - t0);
         best = -2;
-        if (N <= TREE_LDS_CAP && !(A.variant & 2)) best = cluster_phase<true>(A, ws, sm_fin, S, hdr, N, t0);
+        if (N <= TREE_LDS_CAP) best = cluster_phase<true>(A, ws, sm_fin, S, hdr, N, t0);
         if (best == -2) best = cluster_phase<false>(A, ws, sm_fin, S, hdr, N, t0);
     }
     // ---- map phase: the LDS buffer now holds the map (the hierarchy state is no longer needed)
@@ -961,7 +904,6 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
     A.n = n; A.h = height; A.w = width;
     A.mcs = params->hdbscan_min; A.min_samples = params->hdbscan_min_samples; A.select_sum = params->select_sum;
     A.op_close = params->op_close; A.clust_filt = params->clust_filt;
-    { const char *ev = getenv("SVC_VARIANT"); A.variant = ev ? atoi(ev) : 0; }
     A.ring = (const uint32_t *)h->tail_offsets.p; A.n_ring = h->tail_n_offsets; A.n_ring1 = h->tail_n_offsets1;
     A.xy = xy; A.stats = stats; A.L = L;
     const int hw = height * width;

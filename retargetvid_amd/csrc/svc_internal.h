@@ -85,6 +85,8 @@ struct SvcHandle {
     uint8_t *depth_pinned = nullptr;   // pinned staging ring for the per-map round numbers
     unsigned depth_slot = 0;
     int chunk = 32;                    // frames per network pass
+    bool pw_sk = true;                 // split-K pointwise kernel for long-K small-M layers (SVC_PW_SK=0 disables)
+    int pw_small = 0;                  // small-M pointwise layers on 16-row wave tiles (SVC_PW_SMALL: 0 off, 1: 16x32, 2: 16x64, 3: 32x32)
     bool pw16 = true;                  // 16x16x4 MFMA pointwise kernel for narrow short-K layers (SVC_PW16=0: always 32x32x2)
     int fuse_max = 7;                  // backbone blocks 1..fuse_max run as the fused inverted-residual kernel (SVC_FUSE_MAX, 0..13)
     // per-kernel-class event log (svc_profile_*)

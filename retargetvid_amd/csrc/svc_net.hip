@@ -348,51 +348,49 @@ __global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx
 // of 16x16; lane l (r16 = l&15, q = l>>4) feeds A[r16][k0+4q+j], B[k0+4q+j][r16] in MFMA j.
 // --------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int TN>
+template <int MT, int NT>     // wave tile = (16*MT) rows x (16*NT) columns; workgroup = 4 waves stacked along M
 __global__ __launch_bounds__(256) void k_pw16(const float *__restrict__ X, int ldx, const float *__restrict__ Wt,
                                               const float *__restrict__ bias, const float *__restrict__ R, int ldr,
                                               float *__restrict__ Y, int ldy, int M, int N, int Npad, int K,
                                               int relu6) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, q = lane >> 4;
-    const int m0 = blockIdx.x * 128 + wave * 32;
-    const int n0 = blockIdx.y * (32 * TN);
+    const int m0 = blockIdx.x * (64 * MT) + wave * (16 * MT);
+    const int n0 = blockIdx.y * (16 * NT);
     if (m0 >= M) return;
-    const float *xa[2];
+    const float *xa[MT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) xa[i] = X + (size_t)min(m0 + 16 * i + r16, M - 1) * ldx + 4 * q;
-    const float *wb[2 * TN];
+    for (int i = 0; i < MT; ++i) xa[i] = X + (size_t)min(m0 + 16 * i + r16, M - 1) * ldx + 4 * q;
+    const float *wb[NT];
 #pragma unroll
-    for (int c = 0; c < 2 * TN; ++c) wb[c] = Wt + (size_t)min(n0 + 16 * c + r16, Npad - 1) * K + 4 * q;
-    f32x4 acc[2][2 * TN];
+    for (int c = 0; c < NT; ++c) wb[c] = Wt + (size_t)min(n0 + 16 * c + r16, Npad - 1) * K + 4 * q;
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int c = 0; c < 2 * TN; ++c)
+        for (int c = 0; c < NT; ++c)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][c][e] = 0.f;
 #pragma unroll 2
     for (int k = 0; k < K; k += 16) {
-        float4 a[2], b[2 * TN];
+        float4 a[MT], b[NT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = *(const float4 *)(xa[i] + k);
+        for (int i = 0; i < MT; ++i) a[i] = *(const float4 *)(xa[i] + k);
 #pragma unroll
-        for (int c = 0; c < 2 * TN; ++c) b[c] = *(const float4 *)(wb[c] + k);
-#define PW16_STEP(EL)                                                                                   \
-    _Pragma("unroll") for (int c = 0; c < 2 * TN; ++c) {                                                \
-        acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0].EL, b[c].EL, acc[0][c], 0, 0, 0);        \
-        acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1].EL, b[c].EL, acc[1][c], 0, 0, 0);        \
-    }
+        for (int c = 0; c < NT; ++c) b[c] = *(const float4 *)(wb[c] + k);
+#define PW16_STEP(EL)                                                                                       \
+    _Pragma("unroll") for (int c = 0; c < NT; ++c) _Pragma("unroll") for (int i = 0; i < MT; ++i)           \
+        acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].EL, b[c].EL, acc[i][c], 0, 0, 0);
         PW16_STEP(x) PW16_STEP(y) PW16_STEP(z) PW16_STEP(w)
 #undef PW16_STEP
     }
 #pragma unroll
-    for (int c = 0; c < 2 * TN; ++c) {
+    for (int c = 0; c < NT; ++c) {
         const int col = n0 + 16 * c + r16;
         if (col >= N) continue;
         const float bv = bias[col];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int rr = m0 + 16 * i + 4 * q + e;
@@ -403,6 +401,69 @@ __global__ __launch_bounds__(256) void k_pw16(const float *__restrict__ X, int l
                     Y[(size_t)rr * ldy + col] = v;
                 }
             }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// Split-K variant for the long-K, small-M layers (8x13 / 16x26 levels at B = 32), where k_pw runs
+// one wave per SIMD through a serial K loop: the workgroup owns 32 rows x (32*TN) columns and its
+// four waves each take a quarter of K; the partial tiles meet in LDS and are summed in a fixed
+// order (deterministic), every wave finishing four of the sixteen accumulator rows.
+// --------------------------------------------------------------------------------------
+template <int TN>
+__global__ __launch_bounds__(256) void k_pw_sk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt,
+                                               const float *__restrict__ bias, const float *__restrict__ R, int ldr,
+                                               float *__restrict__ Y, int ldy, int M, int N, int Npad, int K,
+                                               int relu6) {
+    __shared__ float red[4][TN][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * (32 * TN);
+    const float *xp = X + (size_t)min(m0 + r, M - 1) * ldx + 4 * hh;
+    const float *wp[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) wp[t] = Wt + (size_t)min(n0 + t * 32 + r, Npad - 1) * K + 4 * hh;
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    const int nsteps = K >> 3;
+    const int s_lo = (wave * nsteps) >> 2, s_hi = ((wave + 1) * nsteps) >> 2;
+#pragma unroll 2
+    for (int st = s_lo; st < s_hi; ++st) {
+        const float4 a = *(const float4 *)(xp + 8 * st);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const float4 b = *(const float4 *)(wp[t] + 8 * st);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave][t][i][lane] = acc[t][i];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int col = n0 + t * 32 + r;
+        if (col >= N) continue;
+        const float bv = bias[col];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = 4 * wave + ii;
+            const int rr = m0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            if (rr < M) {
+                float v = ((red[0][t][i][lane] + red[1][t][i][lane]) + red[2][t][i][lane]) + red[3][t][i][lane];
+                v += bv;
+                if (R) v += R[(size_t)rr * ldr + col];
+                if (relu6) v = fminf(fmaxf(v, 0.f), 6.f);
+                Y[(size_t)rr * ldy + col] = v;
+            }
+        }
     }
 }
 
@@ -741,27 +802,48 @@ int svc_net_release(SvcHandle *h) {
 static inline unsigned blocks256(size_t total) { return (unsigned)((total + 255) / 256); }
 
 static int launch_pw(SvcHandle *h, hipStream_t s, const float *X, int ldx, const SvcLayer &L, const float *R, int ldr,
-                     float *Y, int ldy, int M) {
+                     float *Y, int ldy, int M, int n) {
     ProfScope ps(h, SVC_K_PW, s);
     const int N = L.cout, K = L.cin, Npad = (N + 31) / 32 * 32, tiles = Npad / 32;
     const int rb = ceil_div(M, 128);
     int TN = 4;
     while (TN > 1 && (TN > tiles || rb * ceil_div(tiles, TN) < 512)) --TN;
     dim3 grid(rb, ceil_div(tiles, TN));
-    // measured on MI355X: the 16x16x4 form wins for single-N-tile layers with a short K (the
-    // high-resolution project layers), the 32x32x2 form everywhere else
-    if (h->pw16 && TN == 1 && K % 16 == 0 && K >= 64 && K <= 192) {
+    // Which kernel FAMILY runs (and with it the order of the K sum) depends only on the layer shape,
+    // judged at a nominal batch of 32 frames, never on the batch actually passed: a frame's map
+    // must not depend on its batch.  The tile shape (TN) may follow the real M, it does not change
+    // any sum order.
+    const int rb_nom = ceil_div((M / n) * 32, 128);
 #define PW16_ARGS X, ldx, L.w.dev, L.b.dev, R, ldr, Y, ldy, M, N, Npad, K, L.relu6
-        switch (TN) {
-            case 4: k_pw16<4><<<grid, 256, 0, s>>>(PW16_ARGS); break;
-            case 3: k_pw16<3><<<grid, 256, 0, s>>>(PW16_ARGS); break;
-            case 2: k_pw16<2><<<grid, 256, 0, s>>>(PW16_ARGS); break;
-            default: k_pw16<1><<<grid, 256, 0, s>>>(PW16_ARGS); break;
-        }
-#undef PW16_ARGS
+    if (h->pw_sk && K >= 256 && rb_nom * tiles <= 1024) {   // long K, few workgroups: split K over the four waves
+        const int tn = (tiles % 2 == 0) ? 2 : 1;
+        dim3 g(ceil_div(M, 32), ceil_div(tiles, tn));
+        if (tn == 2) k_pw_sk<2><<<g, 256, 0, s>>>(PW16_ARGS);
+        else k_pw_sk<1><<<g, 256, 0, s>>>(PW16_ARGS);
         SVC_CHECK_LAUNCH();
         return SVC_OK;
     }
+    // small-M layers (8x13 and 16x26 levels at B = 32) leave most SIMDs idle with 32x32 wave tiles:
+    // 16x32 wave tiles (SVC_PW_SMALL selects the shape) give 2-4x more waves
+    if (h->pw_small && K % 16 == 0 && K >= 64 && rb_nom * tiles < 1024) {
+        if (h->pw_small == 1) {
+            k_pw16<1, 2><<<dim3(ceil_div(M, 64), tiles), 256, 0, s>>>(PW16_ARGS);
+        } else if (h->pw_small == 2) {
+            k_pw16<1, 4><<<dim3(ceil_div(M, 64), ceil_div(tiles, 2)), 256, 0, s>>>(PW16_ARGS);
+        } else {
+            k_pw16<2, 2><<<dim3(ceil_div(M, 128), tiles), 256, 0, s>>>(PW16_ARGS);
+        }
+        SVC_CHECK_LAUNCH();
+        return SVC_OK;
+    }
+    // measured on MI355X: the 16x16x4 form wins for single-N-tile layers with a short K (the
+    // high-resolution project layers), the 32x32x2 form everywhere else
+    if (h->pw16 && tiles == 1 && K % 16 == 0 && K >= 64 && K <= 192) {
+        k_pw16<2, 2><<<dim3(rb, 1), 256, 0, s>>>(PW16_ARGS);
+        SVC_CHECK_LAUNCH();
+        return SVC_OK;
+    }
+#undef PW16_ARGS
 #define PW_ARGS X, ldx, L.w.dev, L.b.dev, R, ldr, Y, ldy, M, N, Npad, K, L.relu6
     switch (TN) {
         case 4: k_pw<4, 1><<<grid, 256, 0, s>>>(PW_ARGS); break;
@@ -1019,12 +1101,12 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
             } else {
                 const float *dwin = x;
                 if (t != 1) {
-                    RC(launch_pw(h, s, x, inp, next(), nullptr, 0, E0, inp * t, n * H * W));
+                    RC(launch_pw(h, s, x, inp, next(), nullptr, 0, E0, inp * t, n * H * W, n));
                     dwin = E0;
                 }
                 const SvcLayer &Ld = next();
                 RC(launch_dw(h, s, dwin, Ld, E1, n, H, W, dws));
-                RC(launch_pw(h, s, E1, inp * t, next(), res ? x : nullptr, oup, y, oup, n * OH * OW));
+                RC(launch_pw(h, s, E1, inp * t, next(), res ? x : nullptr, oup, y, oup, n * OH * OW, n));
             }
             if (tap) {
                 ProfScope ps(h, SVC_K_RESAMPLE, s);
@@ -1040,13 +1122,13 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     // features.18 -> CAT1[:, 0:1280], Gaussian maps -> CAT1[:, 1280:1296]
     const int H5 = H, W5 = W, H4 = 2 * H5, W4 = 2 * W5, H3 = 4 * H5, W3 = 4 * W5;
     float *CAT1 = p->buf(B_CAT1);
-    RC(launch_pw(h, s, P[cur], 320, next(), nullptr, 0, CAT1, 1296, n * H5 * W5));
+    RC(launch_pw(h, s, P[cur], 320, next(), nullptr, 0, CAT1, 1296, n * H5 * W5, n));
     // skips (model.py:443-444)
     float *CAT2 = p->buf(B_CAT2), *CAT3 = p->buf(B_CAT3);
-    RC(launch_pw(h, s, p->buf(B_F2X), 160, next(), nullptr, 0, p->buf(B_S2E), 320, n * H4 * W4));
-    RC(launch_pw(h, s, p->buf(B_S2E), 320, next(), nullptr, 0, CAT2 + 256, 384, n * H4 * W4));
-    RC(launch_pw(h, s, p->buf(B_F4X), 64, next(), nullptr, 0, p->buf(B_S4E), 128, n * H3 * W3));
-    RC(launch_pw(h, s, p->buf(B_S4E), 128, next(), nullptr, 0, CAT3 + 128, 192, n * H3 * W3));
+    RC(launch_pw(h, s, p->buf(B_F2X), 160, next(), nullptr, 0, p->buf(B_S2E), 320, n * H4 * W4, n));
+    RC(launch_pw(h, s, p->buf(B_S2E), 320, next(), nullptr, 0, CAT2 + 256, 384, n * H4 * W4, n));
+    RC(launch_pw(h, s, p->buf(B_F4X), 64, next(), nullptr, 0, p->buf(B_S4E), 128, n * H3 * W3, n));
+    RC(launch_pw(h, s, p->buf(B_S4E), 128, next(), nullptr, 0, CAT3 + 128, 192, n * H3 * W3, n));
     next();   // GAUSS placeholder layer (raw parameters; maps live in plan->gauss)
     {
         ProfScope ps(h, SVC_K_RESAMPLE, s);
@@ -1056,24 +1138,24 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     }
     // post_cnn
     RC(launch_dw(h, s, CAT1, next(), p->buf(B_PCD), n, H5, W5, 1));
-    RC(launch_pw(h, s, p->buf(B_PCD), 1296, next(), nullptr, 0, p->buf(B_PC), 256, n * H5 * W5));
+    RC(launch_pw(h, s, p->buf(B_PCD), 1296, next(), nullptr, 0, p->buf(B_PC), 256, n * H5 * W5, n));
     // US1 + concat, US2 block
     {
         ProfScope ps(h, SVC_K_RESAMPLE, s);
         k_upsample2x<<<blocks256((size_t)n * H4 * W4 * 64), 256, 0, s>>>(p->buf(B_PC), CAT2, n, H5, W5, 256, 384);
         SVC_CHECK_LAUNCH();
     }
-    RC(launch_pw(h, s, CAT2, 384, next(), nullptr, 0, p->buf(B_U2E), 768, n * H4 * W4));
+    RC(launch_pw(h, s, CAT2, 384, next(), nullptr, 0, p->buf(B_U2E), 768, n * H4 * W4, n));
     RC(launch_dw(h, s, p->buf(B_U2E), next(), p->buf(B_U2D), n, H4, W4, 1));
-    RC(launch_pw(h, s, p->buf(B_U2D), 768, next(), nullptr, 0, p->buf(B_U2), 128, n * H4 * W4));
+    RC(launch_pw(h, s, p->buf(B_U2D), 768, next(), nullptr, 0, p->buf(B_U2), 128, n * H4 * W4, n));
     {
         ProfScope ps(h, SVC_K_RESAMPLE, s);
         k_upsample2x<<<blocks256((size_t)n * H3 * W3 * 32), 256, 0, s>>>(p->buf(B_U2), CAT3, n, H4, W4, 128, 192);
         SVC_CHECK_LAUNCH();
     }
-    RC(launch_pw(h, s, CAT3, 192, next(), nullptr, 0, p->buf(B_P3E), 384, n * H3 * W3));
+    RC(launch_pw(h, s, CAT3, 192, next(), nullptr, 0, p->buf(B_P3E), 384, n * H3 * W3, n));
     RC(launch_dw(h, s, p->buf(B_P3E), next(), p->buf(B_P3D), n, H3, W3, 1));
-    RC(launch_pw(h, s, p->buf(B_P3D), 384, next(), nullptr, 0, p->buf(B_DEC), 64, n * H3 * W3));
+    RC(launch_pw(h, s, p->buf(B_P3D), 384, next(), nullptr, 0, p->buf(B_DEC), 64, n * H3 * W3, n));
     // adaptation, smoothing, resize, quantise
     const SvcLayer &La = next();
     {
@@ -1192,6 +1274,10 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     h->device = device;
     const char *env = getenv("SVC_CHUNK");
     if (env && atoi(env) > 0) h->chunk = atoi(env);
+    env = getenv("SVC_PW_SK");
+    if (env) h->pw_sk = atoi(env) != 0;
+    env = getenv("SVC_PW_SMALL");
+    if (env) h->pw_small = atoi(env);
     env = getenv("SVC_PW16");
     if (env) h->pw16 = atoi(env) != 0;
     env = getenv("SVC_FUSE_MAX");

@@ -15,6 +15,32 @@
 
 void svc_set_error(const char *fmt, ...);
 
+// Division of a 31-bit index by a launch-invariant divisor as multiply + shift (a runtime integer
+// division costs ~40 VALU instructions on gfx950, more than the arithmetic of most element-wise
+// kernels here).  Exact for n < 2^31, 1 <= d < 2^16.
+struct FDiv {
+    uint64_t m;
+    uint32_t d;
+    int s;
+};
+static inline FDiv make_fdiv(uint32_t d) {
+    FDiv f;
+    f.d = d;
+    int l = 0;
+    while ((1u << l) < d) ++l;
+    f.s = 32 + l;
+    f.m = (((uint64_t)1 << f.s) + d - 1) / d;
+    return f;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FDiv &f) { return (uint32_t)(((uint64_t)n * f.m) >> f.s); }
+__device__ __forceinline__ uint32_t fdivmod(uint32_t n, const FDiv &f, uint32_t &rem) {
+    const uint32_t q = fdiv(n, f);
+    rem = n - q * f.d;
+    return q;
+}
+#endif
+
 #define SVC_HIP(call)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (call);                                                                \
@@ -85,6 +111,7 @@ struct SvcHandle {
     uint8_t *depth_pinned = nullptr;   // pinned staging ring for the per-map round numbers
     unsigned depth_slot = 0;
     int chunk = 32;                    // frames per network pass
+    int pw_min_wg = 1024;              // k_pw narrows its column tile until the grid has this many workgroups (SVC_PW_MIN_WG)
     bool pw_sk = true;                 // split-K pointwise kernel for long-K small-M layers (SVC_PW_SK=0 disables)
     int pw_small = 0;                  // small-M pointwise layers on 16-row wave tiles (SVC_PW_SMALL: 0 off, 1: 16x32, 2: 16x64, 3: 32x32)
     bool pw16 = true;                  // 16x16x4 MFMA pointwise kernel for narrow short-K layers (SVC_PW16=0: always 32x32x2)

@@ -132,39 +132,55 @@ extern "C" int svc_resize_frames_u8(SvcHandle *h, const uint8_t *frames, int n, 
 // K0: Pillow LANCZOS (two 8-bit fixed-point passes) + /255 + normalise (via LUT) -> NHWC fp32
 // --------------------------------------------------------------------------------------
 #define LZ_PREC 22
+// One workgroup = one frame x rows_per_block output rows.  The input rows it needs, the horizontal
+// coefficients and the normalisation LUT are staged in LDS first (coalesced), so both passes run
+// out of LDS.  LDS layout: in_s[in_cap][w*3] u8 | tile[tile_cap][NW*3] u8 | hk[NW][hks] i32 | lut[768] f32
 __global__ __launch_bounds__(256) void k_lanczos_norm(
     const uint8_t *__restrict__ in, float *__restrict__ out, int h, int w, int NH, int NW,
     const int *__restrict__ hb, const int *__restrict__ hk, int hks, const int *__restrict__ vb,
     const int *__restrict__ vk, int vks, const float *__restrict__ lut, int rows_per_block, int tile_cap) {
-    extern __shared__ uint8_t tile[];          // [tile_cap][NW][3] horizontal-pass rows
+    extern __shared__ uint8_t sm_lz[];
+    const int in_bytes = (tile_cap * w * 3 + 15) / 16 * 16, tile_bytes = (tile_cap * NW * 3 + 15) / 16 * 16;
+    uint8_t *in_s = sm_lz;
+    uint8_t *tile = sm_lz + in_bytes;
+    int *hk_s = (int *)(sm_lz + in_bytes + tile_bytes);
+    float *lut_s = (float *)(hk_s + NW * hks);
     const int f = blockIdx.y;
     const int y0 = blockIdx.x * rows_per_block;
     const int y1 = min(NH, y0 + rows_per_block);
     const int r_lo = vb[2 * y0];
     const int r_hi = vb[2 * (y1 - 1)] + vb[2 * (y1 - 1) + 1];
     const int nr = min(r_hi - r_lo, tile_cap);
-    const uint8_t *src = in + (size_t)f * h * w * 3;
-    for (int idx = threadIdx.x; idx < nr * NW * 3; idx += 256) {
-        int c = idx % 3, x = (idx / 3) % NW, r = idx / (3 * NW);
-        int xmin = hb[2 * x], cnt = hb[2 * x + 1];
-        const uint8_t *p = src + ((size_t)(r_lo + r) * w + xmin) * 3 + c;
-        const int *k = hk + x * hks;
-        int acc = 1 << (LZ_PREC - 1);
-        for (int j = 0; j < cnt; ++j) acc += (int)p[j * 3] * k[j];
-        tile[idx] = (uint8_t)min(max(acc >> LZ_PREC, 0), 255);
+    const uint8_t *src = in + ((size_t)f * h + r_lo) * w * 3;
+    for (int i = threadIdx.x; i < nr * w * 3; i += 256) in_s[i] = src[i];
+    for (int i = threadIdx.x; i < NW * hks; i += 256) hk_s[i] = hk[i];
+    for (int i = threadIdx.x; i < 768; i += 256) lut_s[i] = lut[i];
+    __syncthreads();
+    const int rowlen = NW * 3;
+    for (int i = threadIdx.x; i < rowlen; i += 256) {           // horizontal pass, one output column per thread
+        const int x = i / 3, c = i - 3 * x;
+        const int xmin = hb[2 * x], cnt = hb[2 * x + 1];
+        const int *k = hk_s + x * hks;
+        const uint8_t *p = in_s + xmin * 3 + c;
+        for (int r = 0; r < nr; ++r, p += w * 3) {
+            int acc = 1 << (LZ_PREC - 1);
+            for (int j = 0; j < cnt; ++j) acc += (int)p[j * 3] * k[j];
+            tile[r * rowlen + i] = (uint8_t)min(max(acc >> LZ_PREC, 0), 255);
+        }
     }
     __syncthreads();
-    float *dst = out + ((size_t)f * NH + y0) * NW * 3;
-    for (int idx = threadIdx.x; idx < (y1 - y0) * NW * 3; idx += 256) {
-        int c = idx % 3, x = (idx / 3) % NW, yy = idx / (3 * NW);
-        int y = y0 + yy;
-        int ymin = vb[2 * y], cnt = vb[2 * y + 1];
-        const int *k = vk + y * vks;
-        const uint8_t *p = tile + ((ymin - r_lo) * NW + x) * 3 + c;
-        int acc = 1 << (LZ_PREC - 1);
-        for (int j = 0; j < cnt; ++j) acc += (int)p[j * NW * 3] * k[j];
-        int v = min(max(acc >> LZ_PREC, 0), 255);
-        dst[idx] = lut[c * 256 + v];
+    float *dst = out + ((size_t)f * NH + y0) * rowlen;
+    for (int i = threadIdx.x; i < rowlen; i += 256) {           // vertical pass + normalisation
+        const int c = i - 3 * (i / 3);
+        const float *lc = lut_s + c * 256;
+        for (int y = y0; y < y1; ++y) {
+            const int ymin = vb[2 * y], cnt = vb[2 * y + 1];
+            const int *k = vk + y * vks;
+            const uint8_t *p = tile + (ymin - r_lo) * rowlen + i;
+            int acc = 1 << (LZ_PREC - 1);
+            for (int j = 0; j < cnt; ++j) acc += (int)p[j * rowlen] * k[j];
+            dst[(size_t)(y - y0) * rowlen + i] = lc[min(max(acc >> LZ_PREC, 0), 255)];
+        }
     }
 }
 
@@ -216,7 +232,7 @@ static void lanczos_tab(int in_size, int out_size, std::vector<int> &bounds, std
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_stem(const float *__restrict__ X, const float *__restrict__ Wt,
                                               const float *__restrict__ bias, float *__restrict__ Y, int n,
-                                              int H, int W, int OH, int OW) {
+                                              int H, int W, int OH, int OW, FDiv dOW, FDiv dOH) {
     __shared__ float ws[27 * 32 + 32];
     for (int i = threadIdx.x; i < 27 * 32; i += 256) ws[i] = Wt[i];
     if (threadIdx.x < 32) ws[27 * 32 + threadIdx.x] = bias[threadIdx.x];
@@ -225,8 +241,8 @@ __global__ __launch_bounds__(256) void k_stem(const float *__restrict__ X, const
     size_t total = (size_t)n * OH * OW * 8;
     if (gid >= total) return;
     int c4 = gid & 7;
-    size_t pix = gid >> 3;
-    int ox = pix % OW, oy = (pix / OW) % OH, f = pix / ((size_t)OW * OH);
+    uint32_t ox, oy;
+    const uint32_t f = fdivmod(fdivmod((uint32_t)(gid >> 3), dOW, ox), dOH, oy);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const float *xf = X + (size_t)f * H * W * 3;
 #pragma unroll
@@ -474,14 +490,14 @@ __global__ __launch_bounds__(256) void k_pw_sk(const float *__restrict__ X, int 
 template <int S>
 __global__ __launch_bounds__(256) void k_dw(const float *__restrict__ X, const float *__restrict__ Wt,
                                             const float *__restrict__ bias, float *__restrict__ Y, int n, int H,
-                                            int W, int C, int OH, int OW) {
+                                            int W, int C, int OH, int OW, FDiv dC4, FDiv dOW, FDiv dOH) {
     const int C4 = C >> 2;
-    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    size_t total = (size_t)n * OH * OW * C4;
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t total = (uint32_t)n * OH * OW * C4;
     if (gid >= total) return;
-    int c4 = gid % C4;
-    size_t pix = gid / C4;
-    int ox = pix % OW, oy = (pix / OW) % OH, f = pix / ((size_t)OW * OH);
+    uint32_t c4, ox, oy;
+    const uint32_t pix = fdivmod(gid, dC4, c4);
+    const uint32_t f = fdivmod(fdivmod(pix, dOW, ox), dOH, oy);
     const float *xf = X + (size_t)f * H * W * C + c4 * 4;
     const float *wf = Wt + c4 * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -506,7 +522,7 @@ __global__ __launch_bounds__(256) void k_dw(const float *__restrict__ X, const f
     acc.y = fminf(fmaxf(acc.y + b.y, 0.f), 6.f);
     acc.z = fminf(fmaxf(acc.z + b.z, 0.f), 6.f);
     acc.w = fminf(fmaxf(acc.w + b.w, 0.f), 6.f);
-    *(float4 *)(Y + gid * 4) = acc;
+    *(float4 *)(Y + (size_t)gid * 4) = acc;
 }
 
 __global__ __launch_bounds__(256) void k_subsample(const float *__restrict__ X, float *__restrict__ Y, int n, int H,
@@ -535,14 +551,14 @@ __global__ __launch_bounds__(256) void k_gauss_fill(const float *__restrict__ G,
 
 // bilinear x2 (align_corners=False): X[n][H][W][C] -> Y[n][2H][2W][ldy] channels 0..C-1
 __global__ __launch_bounds__(256) void k_upsample2x(const float *__restrict__ X, float *__restrict__ Y, int n,
-                                                    int H, int W, int C, int ldy) {
+                                                    int H, int W, int C, int ldy, FDiv dC4, FDiv dOW, FDiv dOH) {
     const int C4 = C >> 2, OH = 2 * H, OW = 2 * W;
-    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    size_t total = (size_t)n * OH * OW * C4;
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t total = (uint32_t)n * OH * OW * C4;
     if (gid >= total) return;
-    int c4 = gid % C4;
-    size_t pix = gid / C4;
-    int ox = pix % OW, oy = (pix / OW) % OH, f = pix / ((size_t)OW * OH);
+    uint32_t c4, ox, oy;
+    const uint32_t pix = fdivmod(gid, dC4, c4);
+    const uint32_t f = fdivmod(fdivmod(pix, dOW, ox), dOH, oy);
     float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ox + 0.5f) - 0.5f, 0.f);
     int y0 = (int)sy, x0 = (int)sx;
     int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
@@ -557,7 +573,7 @@ __global__ __launch_bounds__(256) void k_upsample2x(const float *__restrict__ X,
     o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
     o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
     o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
-    *(float4 *)(Y + pix * ldy + c4 * 4) = o;
+    *(float4 *)(Y + (size_t)pix * ldy + c4 * 4) = o;
 }
 
 // adaptation: logit[p] = sum_c X[p][c] * w[c] + b, C = 64
@@ -593,7 +609,7 @@ __device__ __forceinline__ float dec_f32(unsigned u) {
 __global__ __launch_bounds__(256) void k_smooth_down(const float *__restrict__ logit, const float *__restrict__ phase,
                                                      float *__restrict__ pre, unsigned *__restrict__ fmax, int LH,
                                                      int LW, int NH, int NW, int h, int w, int rows_per_block,
-                                                     int tile_cap) {
+                                                     int tile_cap, FDiv dNW, FDiv dw) {
     extern __shared__ float sm[];
     float *L = sm, *ph = sm + LH * LW, *tile = ph + 64 * 49;
     __shared__ unsigned wmax[4];
@@ -607,7 +623,8 @@ __global__ __launch_bounds__(256) void k_smooth_down(const float *__restrict__ l
     for (int i = threadIdx.x; i < 64 * 49; i += 256) ph[i] = phase[i];
     __syncthreads();
     for (int idx = threadIdx.x; idx < nrows * NW; idx += 256) {
-        int ry = idx / NW, x = idx - ry * NW;
+        uint32_t x;
+        const int ry = (int)fdivmod((uint32_t)idx, dNW, x);
         int y = ylo + ry;
         int cy = y >> 3, py = y & 7, cx = x >> 3, px = x & 7;
         const float *p = ph + (py * 8 + px) * 49;
@@ -626,7 +643,8 @@ __global__ __launch_bounds__(256) void k_smooth_down(const float *__restrict__ l
     __syncthreads();
     float lmax = -INFINITY;
     for (int idx = threadIdx.x; idx < (oy1 - oy0) * w; idx += 256) {
-        int oy = oy0 + idx / w, ox = idx % w;
+        uint32_t ox;
+        const int oy = oy0 + (int)fdivmod((uint32_t)idx, dw, ox);
         float sy = fmaxf(scy * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(scx * (ox + 0.5f) - 0.5f, 0.f);
         int y0 = (int)sy, x0 = (int)sx;
         int y1 = y0 + (y0 < NH - 1 ? 1 : 0), x1 = x0 + (x0 < NW - 1 ? 1 : 0);
@@ -644,11 +662,11 @@ __global__ __launch_bounds__(256) void k_smooth_down(const float *__restrict__ l
 
 // u8 = trunc(255 * exp(x - max x)): the softmax normaliser cancels in p / max p.
 __global__ __launch_bounds__(256) void k_quantise(const float *__restrict__ pre, const unsigned *__restrict__ fmax,
-                                                  uint8_t *__restrict__ out, int n, int hw) {
-    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    size_t total = (size_t)n * hw;
+                                                  uint8_t *__restrict__ out, int n, int hw, FDiv dhw) {
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t total = (uint32_t)n * hw;
     if (gid >= total) return;
-    float m = dec_f32(fmax[gid / hw]);
+    float m = dec_f32(fmax[fdiv(gid, dhw)]);
     float e = expf(pre[gid] - m);
     out[gid] = (uint8_t)(e * 255.0f);
 }
@@ -807,7 +825,7 @@ static int launch_pw(SvcHandle *h, hipStream_t s, const float *X, int ldx, const
     const int N = L.cout, K = L.cin, Npad = (N + 31) / 32 * 32, tiles = Npad / 32;
     const int rb = ceil_div(M, 128);
     int TN = 4;
-    while (TN > 1 && (TN > tiles || rb * ceil_div(tiles, TN) < 512)) --TN;
+    while (TN > 1 && (TN > tiles || rb * ceil_div(tiles, TN) < h->pw_min_wg)) --TN;
     dim3 grid(rb, ceil_div(tiles, TN));
     // Which kernel FAMILY runs (and with it the order of the K sum) depends only on the layer shape,
     // judged at a nominal batch of 32 frames, never on the batch actually passed: a frame's map
@@ -862,9 +880,11 @@ static int launch_dw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer
     const int C = L.cout, OH = stride == 2 ? H / 2 : H, OW = stride == 2 ? W / 2 : W;
     size_t total = (size_t)n * OH * OW * (C / 4);
     if (stride == 2)
-        k_dw<2><<<blocks256(total), 256, 0, s>>>(X, L.w.dev, L.b.dev, Y, n, H, W, C, OH, OW);
+        k_dw<2><<<blocks256(total), 256, 0, s>>>(X, L.w.dev, L.b.dev, Y, n, H, W, C, OH, OW, make_fdiv(C / 4), make_fdiv(OW),
+                                                 make_fdiv(OH));
     else
-        k_dw<1><<<blocks256(total), 256, 0, s>>>(X, L.w.dev, L.b.dev, Y, n, H, W, C, OH, OW);
+        k_dw<1><<<blocks256(total), 256, 0, s>>>(X, L.w.dev, L.b.dev, Y, n, H, W, C, OH, OW, make_fdiv(C / 4), make_fdiv(OW),
+                                                 make_fdiv(OH));
     SVC_CHECK_LAUNCH();
     return SVC_OK;
 }
@@ -1065,7 +1085,8 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     {
         ProfScope ps(h, SVC_K_LANCZOS, s);
         dim3 grid(ceil_div(NH, p->lz_rows), n);
-        size_t lds = (size_t)p->lz_tile_cap * NW * 3;
+        size_t lds = ((size_t)p->lz_tile_cap * p->w * 3 + 15) / 16 * 16 + ((size_t)p->lz_tile_cap * NW * 3 + 15) / 16 * 16 +
+                     (size_t)NW * p->hks * 4 + 768 * 4;
         k_lanczos_norm<<<grid, 256, lds, s>>>(frames, IN, p->h, p->w, NH, NW, (const int *)p->hb.p, (const int *)p->hk.p,
                                              p->hks, (const int *)p->vb.p, (const int *)p->vk.p, p->vks,
                                              (const float *)p->lut.p, p->lz_rows, p->lz_tile_cap);
@@ -1075,7 +1096,8 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     {
         ProfScope ps(h, SVC_K_STEM, s);
         const SvcLayer &L = next();
-        k_stem<<<blocks256((size_t)n * H * W * 8), 256, 0, s>>>(IN, L.w.dev, L.b.dev, P[0], n, NH, NW, H, W);
+        k_stem<<<blocks256((size_t)n * H * W * 8), 256, 0, s>>>(IN, L.w.dev, L.b.dev, P[0], n, NH, NW, H, W, make_fdiv(W),
+                                                                make_fdiv(H));
         SVC_CHECK_LAUNCH();
     }
     int cur = 0;
@@ -1142,7 +1164,8 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     // US1 + concat, US2 block
     {
         ProfScope ps(h, SVC_K_RESAMPLE, s);
-        k_upsample2x<<<blocks256((size_t)n * H4 * W4 * 64), 256, 0, s>>>(p->buf(B_PC), CAT2, n, H5, W5, 256, 384);
+        k_upsample2x<<<blocks256((size_t)n * H4 * W4 * 64), 256, 0, s>>>(p->buf(B_PC), CAT2, n, H5, W5, 256, 384, make_fdiv(64),
+                                                                         make_fdiv(W4), make_fdiv(H4));
         SVC_CHECK_LAUNCH();
     }
     RC(launch_pw(h, s, CAT2, 384, next(), nullptr, 0, p->buf(B_U2E), 768, n * H4 * W4, n));
@@ -1150,7 +1173,8 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     RC(launch_pw(h, s, p->buf(B_U2D), 768, next(), nullptr, 0, p->buf(B_U2), 128, n * H4 * W4, n));
     {
         ProfScope ps(h, SVC_K_RESAMPLE, s);
-        k_upsample2x<<<blocks256((size_t)n * H3 * W3 * 32), 256, 0, s>>>(p->buf(B_U2), CAT3, n, H4, W4, 128, 192);
+        k_upsample2x<<<blocks256((size_t)n * H3 * W3 * 32), 256, 0, s>>>(p->buf(B_U2), CAT3, n, H4, W4, 128, 192, make_fdiv(32),
+                                                                         make_fdiv(W3), make_fdiv(H3));
         SVC_CHECK_LAUNCH();
     }
     RC(launch_pw(h, s, CAT3, 192, next(), nullptr, 0, p->buf(B_P3E), 384, n * H3 * W3, n));
@@ -1172,11 +1196,11 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
         dim3 grid(ceil_div(p->h, p->sd_rows), n);
         size_t lds = ((size_t)H3 * W3 + 64 * 49 + (size_t)p->sd_tile_cap * NW) * sizeof(float);
         k_smooth_down<<<grid, 256, lds, s>>>(p->buf(B_LOGIT), Ls.w.dev, p->buf(B_PRE), (unsigned *)p->fmax.p, H3, W3, NH,
-                                             NW, p->h, p->w, p->sd_rows, p->sd_tile_cap);
+                                             NW, p->h, p->w, p->sd_rows, p->sd_tile_cap, make_fdiv(NW), make_fdiv(p->w));
         SVC_CHECK_LAUNCH();
     }
     k_quantise<<<blocks256((size_t)n * p->h * p->w), 256, 0, s>>>(p->buf(B_PRE), (const unsigned *)p->fmax.p, maps, n,
-                                                                 p->h * p->w);
+                                                                 p->h * p->w, make_fdiv(p->h * p->w));
     SVC_CHECK_LAUNCH();
     p->last_n = n;
     return SVC_OK;
@@ -1274,6 +1298,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     h->device = device;
     const char *env = getenv("SVC_CHUNK");
     if (env && atoi(env) > 0) h->chunk = atoi(env);
+    env = getenv("SVC_PW_MIN_WG");
+    if (env && atoi(env) > 0) h->pw_min_wg = atoi(env);
     env = getenv("SVC_PW_SK");
     if (env) h->pw_sk = atoi(env) != 0;
     env = getenv("SVC_PW_SMALL");

@@ -73,6 +73,7 @@ struct TailArgs {
     const uint8_t *depth;   // [n] round in which each frame runs
     int round;
     int n, h, w;
+    FDiv dW;                // division by w
     int mcs, min_samples, select_sum, op_close, clust_filt;
     const uint32_t *ring;   // sorted neighbour offsets
     int n_ring, n_ring1;    // all offsets within RING_R / the prefix within RING_R1
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(TB) void k_compact(TailArgs A) {
     for (int i = lo; i < hi; ++i) {
         uint32_t v = map[i];
         if (v) {
-            uint32_t r = i / A.w, c = i - r * A.w;
+            uint32_t c; const uint32_t r = fdivmod((uint32_t)i, A.dW, c);
             pts[pos++] = r | (c << 8) | (v << 16);
         }
     }
@@ -712,28 +713,28 @@ __global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
             // grey CLOSE with a 5x5 rectangle = separable max (dilate) then separable min (erode);
             // out-of-image samples are ignored
             for (int i = tid; i < hw; i += TB) {
-                const int r = i / A.w, c = i - r * A.w;
+                uint32_t cu; const int r = (int)fdivmod((uint32_t)i, A.dW, cu); const int c = (int)cu;
                 int v = 0;
                 for (int d = -2; d <= 2; ++d) { int cc = c + d; if ((unsigned)cc < (unsigned)A.w) v = max(v, (int)m0[r * A.w + cc]); }
                 m1[i] = (uint8_t)v;
             }
             __syncthreads();
             for (int i = tid; i < hw; i += TB) {
-                const int r = i / A.w, c = i - r * A.w;
+                uint32_t cu; const int r = (int)fdivmod((uint32_t)i, A.dW, cu); const int c = (int)cu;
                 int v = 0;
                 for (int d = -2; d <= 2; ++d) { int rr = r + d; if ((unsigned)rr < (unsigned)A.h) v = max(v, (int)m1[rr * A.w + c]); }
                 m0[i] = (uint8_t)v;
             }
             __syncthreads();
             for (int i = tid; i < hw; i += TB) {
-                const int r = i / A.w, c = i - r * A.w;
+                uint32_t cu; const int r = (int)fdivmod((uint32_t)i, A.dW, cu); const int c = (int)cu;
                 int v = 255;
                 for (int d = -2; d <= 2; ++d) { int cc = c + d; if ((unsigned)cc < (unsigned)A.w) v = min(v, (int)m0[r * A.w + cc]); }
                 m1[i] = (uint8_t)v;
             }
             __syncthreads();
             for (int i = tid; i < hw; i += TB) {
-                const int r = i / A.w, c = i - r * A.w;
+                uint32_t cu; const int r = (int)fdivmod((uint32_t)i, A.dW, cu); const int c = (int)cu;
                 int v = 255;
                 for (int d = -2; d <= 2; ++d) { int rr = r + d; if ((unsigned)rr < (unsigned)A.h) v = min(v, (int)m1[rr * A.w + c]); }
                 m0[i] = (uint8_t)v;
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
     // centroid of the non-zero pixels of the final map
     unsigned long long cnt = 0, sr = 0, sc = 0;
     for (int i = tid; i < hw; i += TB)
-        if (m0[i]) { const int r = i / A.w; ++cnt; sr += r; sc += i - r * A.w; }
+        if (m0[i]) { uint32_t c; const uint32_t r = fdivmod((uint32_t)i, A.dW, c); ++cnt; sr += r; sc += c; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o); sr += __shfl_xor(sr, o); sc += __shfl_xor(sc, o); }
     if ((tid & 63) == 0) { red[tid >> 6] = cnt; red[NW16 + (tid >> 6)] = sr; red[2 * NW16 + (tid >> 6)] = sc; }
@@ -901,7 +902,7 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
     h->tail_frames = n; h->tail_h = height; h->tail_w = width; h->tail_frame_stride = L.total;
     TailArgs A;
     A.maps = maps; A.ws = (uint8_t *)h->tail_ws.p; A.ws_stride = L.total; A.depth = depth_dev; A.round = 0;
-    A.n = n; A.h = height; A.w = width;
+    A.n = n; A.h = height; A.w = width; A.dW = make_fdiv(width);
     A.mcs = params->hdbscan_min; A.min_samples = params->hdbscan_min_samples; A.select_sum = params->select_sum;
     A.op_close = params->op_close; A.clust_filt = params->clust_filt;
     A.ring = (const uint32_t *)h->tail_offsets.p; A.n_ring = h->tail_n_offsets; A.n_ring1 = h->tail_n_offsets1;

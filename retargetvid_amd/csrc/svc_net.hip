@@ -945,9 +945,28 @@ __global__ __launch_bounds__(256) void k_irb(const float *__restrict__ X, int H,
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
     const int nchunks = (Ce + 31) >> 5;
     const int pm = wave % MP, pn0 = wave / MP;
+    // which of this lane's 16 accumulator rows (per expand tile) are real in-image halo pixels:
+    // evaluated once, not per chunk (the epilogue is VALU-bound otherwise)
+    constexpr int MTW = (MT + 3) / 4;                     // expand tiles per wave
+    uint32_t vmask[MTW];
+#pragma unroll
+    for (int u = 0; u < MTW; ++u) {
+        vmask[u] = 0;
+        const int mt = wave + 4 * u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rr = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const int hy = rr / IW, hx = rr - hy * IW;
+            if (mt < MT && rr < NPX && (unsigned)(iy0 + hy) < (unsigned)H && (unsigned)(ix0 + hx) < (unsigned)W)
+                vmask[u] |= 1u << i;
+        }
+    }
     for (int ch = 0; ch < nchunks; ++ch) {
         if (EXPAND) {
-            for (int mt = wave; mt < MT; mt += 4) {
+#pragma unroll
+            for (int u = 0; u < MTW; ++u) {
+                const int mt = wave + 4 * u;
+                if (mt >= MT) break;
                 f32x16 e;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) e[i] = 0.f;
@@ -962,15 +981,12 @@ __global__ __launch_bounds__(256) void k_irb(const float *__restrict__ X, int H,
                     e = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, e, 0, 0, 0);
                 }
                 const int c = ch * 32 + r;
-                const float bv = c < Ce ? be[c] : 0.f;
+                const float bv = c < Ce ? be[c] : 0.f;      // rows of We beyond Ce are zero, so e + bv = 0 there
+                float *ep = E + (mt * 32 + 4 * hh) * IRB_ES + r;
+                const uint32_t vm = vmask[u];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int rr = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                    const int hy = rr / IW, hx = rr - hy * IW;
-                    const bool valid = rr < NPX && c < Ce && (unsigned)(iy0 + hy) < (unsigned)H &&
-                                       (unsigned)(ix0 + hx) < (unsigned)W;
-                    E[rr * IRB_ES + r] = valid ? fminf(fmaxf(e[i] + bv, 0.f), 6.f) : 0.f;
-                }
+                for (int i = 0; i < 16; ++i)
+                    ep[((i & 3) + 8 * (i >> 2)) * IRB_ES] = ((vm >> i) & 1u) ? fminf(fmaxf(e[i] + bv, 0.f), 6.f) : 0.f;
             }
             __syncthreads();
         }

@@ -571,11 +571,8 @@ __device__ __forceinline__ T *carve(uint8_t *&p, size_t count) {
     return r;
 }
 
-struct FinShared {
-    int hist[64], run[64];
-    uint16_t wcnt[NW16 * 64];
+struct TreeShared {
     int nsel, best, ok;
-    unsigned long long red[3 * NW16];
 };
 
 // Hierarchy, labels, cluster weights and the choice of the kept cluster for one map.
@@ -584,9 +581,9 @@ struct FinShared {
 // LDS = false: everything in the per-frame global workspace.  Returns the kept cluster
 // (or -1), or -2 when the LDS cluster tables overflowed and the caller must redo in global.
 template <bool LDS>
-__device__ __forceinline__ int cluster_phase(const TailArgs &A, uint8_t *ws, uint8_t *sm, FinShared &S, int32_t *hdr,
+__device__ __forceinline__ int cluster_phase(const TailArgs &A, uint8_t *ws, uint8_t *sm, TreeShared &S, int32_t *hdr,
                                              int N, long long t0) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const int hw = A.h * A.w;
     hdb::Edge *ea = (hdb::Edge *)(ws + A.L.ea);
     const hdb::Edge *edges = ea;
@@ -609,7 +606,7 @@ __device__ __forceinline__ int cluster_phase(const TailArgs &A, uint8_t *ws, uin
         t.crep = carve<int32_t>(p, TREE_LDS_CLUSTERS); t.cup = carve<uint16_t>(p, TREE_LDS_CLUSTERS);
         t.csel = carve<uint8_t>(p, TREE_LDS_CLUSTERS);
         t.cap_clusters = TREE_LDS_CLUSTERS;
-        for (int i = tid; i < N - 1; i += TB) el[i] = ea[i];
+        for (int i = tid; i < N - 1; i += nthr) el[i] = ea[i];
         edges = el;
     } else {
         t.sp = (uint16_t *)(ws + A.L.sp); t.ssz = (uint16_t *)(ws + A.L.ssz); t.absc = (uint16_t *)(ws + A.L.absc);
@@ -624,7 +621,7 @@ __device__ __forceinline__ int cluster_phase(const TailArgs &A, uint8_t *ws, uin
         t.cap_clusters = hdb::max_clusters(hw, A.mcs);
     }
     {
-        const int per = (N + TB - 1) / TB;
+        const int per = (N + nthr - 1) / nthr;
         hdb::init_points(t, min(N, tid * per), min(N, tid * per + per));
     }
     __syncthreads();
@@ -640,11 +637,11 @@ __device__ __forceinline__ int cluster_phase(const TailArgs &A, uint8_t *ws, uin
     t.nclusters = hdr[4];
     const int nsel = S.nsel;
     uint32_t *cweight = (uint32_t *)(ws + A.L.cweight);
-    for (int c = tid; c < t.nclusters; c += TB) cweight[c] = 0;
+    for (int c = tid; c < t.nclusters; c += nthr) cweight[c] = 0;
     __syncthreads();
     const uint32_t *pts = (const uint32_t *)(ws + A.L.pts);
     int32_t *labels = (int32_t *)(ws + A.L.labels);
-    for (int p = tid; p < N; p += TB) {
+    for (int p = tid; p < N; p += nthr) {
         const int c = hdb::point_cluster(t, (uint32_t)p, nsel);
         labels[p] = c;
         if (c >= 0) {
@@ -669,6 +666,43 @@ __device__ __forceinline__ int cluster_phase(const TailArgs &A, uint8_t *ws, uin
     return S.best;
 }
 
+// k_sort: stable sort of the MST edges by weight (three 6-bit passes), 1024 threads per map
+__global__ __launch_bounds__(TB) void k_sort(TailArgs A) {
+    const int f = blockIdx.x;
+    if (A.depth[f] != A.round) return;
+    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
+    int32_t *hdr = (int32_t *)(ws + A.L.hdr);
+    if (!hdr[3]) return;
+    const int N = hdr[0];
+    __shared__ int hist[64], run[64];
+    __shared__ uint16_t wcnt[NW16 * 64];
+    const long long t0 = wall_clock64();
+    hdb::Edge *mst = (hdb::Edge *)(ws + A.L.mst), *ea = (hdb::Edge *)(ws + A.L.ea), *eb = (hdb::Edge *)(ws + A.L.eb);
+    radix_pass(mst, ea, N - 1, 0, hist, run, wcnt);
+    radix_pass(ea, eb, N - 1, 6, hist, run, wcnt);
+    radix_pass(eb, ea, N - 1, 12, hist, run, wcnt);
+    if (threadIdx.x == 0) hdr[8] = (int)(wall_clock64() - t0);
+}
+
+// k_tree: hierarchy + excess of mass + labels + cluster weights + the kept cluster.  The build is a
+// serial union-find pass, so the map gets ONE wavefront (64 threads): the other SIMDs and wave slots of
+// the CU stay free for the network kernels of the next batch (which use no LDS).
+__global__ __launch_bounds__(64) void k_tree(TailArgs A) {
+    const int f = blockIdx.x;
+    if (A.depth[f] != A.round) return;
+    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
+    int32_t *hdr = (int32_t *)(ws + A.L.hdr);
+    if (!hdr[3]) return;
+    const int N = hdr[0];
+    extern __shared__ uint8_t sm_tree[];
+    __shared__ TreeShared S;
+    const long long t0 = wall_clock64();
+    int best = -2;
+    if (N <= TREE_LDS_CAP) best = cluster_phase<true>(A, ws, sm_tree, S, hdr, N, t0);
+    if (best == -2) best = cluster_phase<false>(A, ws, sm_tree, S, hdr, N, t0);
+}
+
+// k_finish: zero everything outside the kept cluster, CLOSE 5x5, write the map back, centroid
 __global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
     const int f = blockIdx.x;
     if (A.depth[f] != A.round) return;
@@ -678,23 +712,12 @@ __global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
     const int hw = A.h * A.w;
     uint8_t *map = A.maps + (size_t)f * hw;
     extern __shared__ uint8_t sm_fin[];
-    __shared__ FinShared S;
-    unsigned long long *red = S.red;
+    __shared__ unsigned long long red[3 * NW16];
     const int tid = threadIdx.x;
     const bool clustered = hdr[3] != 0;
     long long t0 = 0;
     if (tid == 0) t0 = wall_clock64();
-    int best = -1;
-    if (clustered) {
-        hdb::Edge *mst = (hdb::Edge *)(ws + A.L.mst), *ea = (hdb::Edge *)(ws + A.L.ea), *eb = (hdb::Edge *)(ws + A.L.eb);
-        radix_pass(mst, ea, N - 1, 0, S.hist, S.run, S.wcnt);
-        radix_pass(ea, eb, N - 1, 6, S.hist, S.run, S.wcnt);
-        radix_pass(eb, ea, N - 1, 12, S.hist, S.run, S.wcnt);
-        if (tid == 0) hdr[8] = (int)(wall_clock64() - t0);
-        best = -2;
-        if (N <= TREE_LDS_CAP) best = cluster_phase<true>(A, ws, sm_fin, S, hdr, N, t0);
-        if (best == -2) best = cluster_phase<false>(A, ws, sm_fin, S, hdr, N, t0);
-    }
+    const int best = clustered ? hdr[2] : -1;
     // ---- map phase: the LDS buffer now holds the map (the hierarchy state is no longer needed)
     uint8_t *m0 = sm_fin;                            // [hw]
     uint8_t *m1 = sm_fin + (hw + 15) / 16 * 16;      // [hw]
@@ -910,12 +933,13 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
     const int hw = height * width;
     const size_t lds_core = (size_t)(hw + 15) / 16 * 16 + (size_t)h->tail_n_offsets * 4;
     const size_t lds_prim = 2 * NW16 * 8 + (size_t)hw * 2;
-    const size_t lds_fin = std::max<size_t>(2 * ((size_t)(hw + 15) / 16 * 16), FIN_LDS_BYTES);
+    const size_t lds_fin = 2 * ((size_t)(hw + 15) / 16 * 16);
     static bool attr_done = false;
     if (!attr_done) {
         SVC_HIP(hipFuncSetAttribute((const void *)k_core, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_prim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_tree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
         attr_done = true;
     }
     for (int r = 0; r <= maxd; ++r) {
@@ -946,6 +970,12 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
         }
         {
             ProfScope ps(h, SVC_K_FINISH, s);
+            if (params->clust_filt) {
+                k_sort<<<n, TB, 0, s>>>(A);
+                SVC_CHECK_LAUNCH();
+                k_tree<<<n, 64, FIN_LDS_BYTES, s>>>(A);
+                SVC_CHECK_LAUNCH();
+            }
             k_finish<<<n, TB, lds_fin, s>>>(A);
             SVC_CHECK_LAUNCH();
         }

@@ -133,6 +133,88 @@ SVC_HD void init_points(Tree &t, int lo, int hi) {      // callable by many thre
     }
 }
 
+// Roots / tops of both endpoints of one edge.  c* = top condensed cluster of the component, or
+// NONE16 while the component is still smaller than min_cluster_size.
+struct Resolved {
+    uint32_t ra, rb;
+    uint32_t ca, cb;
+    uint32_t sa, sb;      // resolve_ro only: size / dendrogram node of a side that is still a small component
+    uint32_t na, nb;
+};
+
+// read-only resolution (no path compression): safe to run for many edges in parallel
+SVC_HD Resolved resolve_ro(const Tree &t, const Edge &e) {
+    Resolved r;
+    r.ra = find_small_ro(t, e.a);
+    r.rb = find_small_ro(t, e.b);
+    uint32_t c = t.absc[r.ra];
+    if (c != NONE16) { while (t.cup[c] != c) c = t.cup[c]; }
+    r.ca = c;
+    c = t.absc[r.rb];
+    if (c != NONE16) { while (t.cup[c] != c) c = t.cup[c]; }
+    r.cb = c;
+    r.sa = t.ssz[r.ra]; r.na = t.sdn[r.ra];
+    r.sb = t.ssz[r.rb]; r.nb = t.sdn[r.rb];
+    return r;
+}
+
+SVC_HD Resolved resolve(Tree &t, const Edge &e) {
+    Resolved r;
+    r.ra = find_small(t, e.a);
+    r.rb = find_small(t, e.b);
+    r.ca = t.absc[r.ra] != NONE16 ? find_top(t, t.absc[r.ra]) : NONE16;
+    r.cb = t.absc[r.rb] != NONE16 ? find_top(t, t.absc[r.rb]) : NONE16;
+    r.sa = r.sb = r.na = r.nb = 0;
+    return r;
+}
+
+// Apply edge i given its (current) roots and tops.  Returns false if the cluster tables are full.
+SVC_HD bool merge(Tree &t, int i, int n, int mcs, uint32_t w, const Resolved &q) {
+    const uint32_t ra = q.ra, rb = q.rb, ca = q.ca, cb = q.cb;
+    const bool abig = ca != NONE16, bbig = cb != NONE16;
+    uint32_t sa, sb, na, nb;
+    if (abig) { sa = t.csize[ca]; na = t.cdn[ca]; }
+    else      { sa = t.ssz[ra]; na = t.sdn[ra]; }
+    if (bbig) { sb = t.csize[cb]; nb = t.cdn[cb]; }
+    else      { sb = t.ssz[rb]; nb = t.sdn[rb]; }
+    const uint32_t node = (uint32_t)(n + i);
+    t.dparent[na] = node << 1;                     // the a side is the left child of the new node
+    t.dparent[nb] = (node << 1) | 1u;
+    t.evc[i] = (uint16_t)NONE16;
+    t.evs[i] = 0;
+    if (!abig && !bbig) {
+        const uint32_t s = sa + sb;
+        if ((int)s < mcs) {
+            uint32_t big = ra, small = rb;
+            if (sb > sa) { big = rb; small = ra; }
+            t.sp[small] = (uint16_t)big;
+            t.ssz[big] = (uint16_t)s;
+            t.sdn[big] = node;
+        } else {                                   // a condensed cluster is born bottom-up
+            if (t.nclusters >= t.cap_clusters) return false;
+            int32_t c = new_cluster(t, w, s, node, -1, -1);
+            t.evc[i] = (uint16_t)c; t.evs[i] = (uint16_t)s;
+            t.absc[ra] = (uint16_t)c; t.absw[ra] = w;
+            t.absc[rb] = (uint16_t)c; t.absw[rb] = w;
+        }
+    } else if (abig && bbig) {                     // true split: both sides >= mcs
+        if (t.nclusters >= t.cap_clusters) return false;
+        int32_t p = new_cluster(t, w, sa + sb, node, (int32_t)ca, (int32_t)cb);
+        t.evc[i] = (uint16_t)p; t.evs[i] = 0;
+        t.cspa[p] = sa; t.cspb[p] = sb;
+        t.cup[ca] = (uint16_t)p; t.cup[cb] = (uint16_t)p;
+        t.ctp[ca] = p; t.ctp[cb] = p;
+        t.cbirthw[ca] = w; t.cbirthw[cb] = w;
+    } else {                                       // small side falls out of the big side's cluster
+        uint32_t c = abig ? ca : cb, r = abig ? rb : ra, s = abig ? sb : sa;
+        t.absc[r] = (uint16_t)c; t.absw[r] = w;
+        t.evc[i] = (uint16_t)c; t.evs[i] = (uint16_t)s;
+        t.csize[c] += s;
+        t.cdn[c] = node;
+    }
+    return true;
+}
+
 // The sequential pass.  edges must be sorted by w (stable w.r.t. Prim order).
 // Returns false if the per-cluster arrays (cap_clusters) are too small.
 SVC_HD bool build(Tree &t, const Edge *edges, int n, int mcs) {
@@ -140,64 +222,92 @@ SVC_HD bool build(Tree &t, const Edge *edges, int n, int mcs) {
     t.nclusters = 0;
     for (int i = 0; i < n - 1; ++i) {
         const Edge e = edges[i];
-        const uint32_t w = e.w;
-        uint32_t ra = find_small(t, e.a), rb = find_small(t, e.b);
-        const bool abig = t.absc[ra] != NONE16, bbig = t.absc[rb] != NONE16;
-        uint32_t ca = 0, cb = 0, sa, sb, na, nb;
-        if (abig) { ca = find_top(t, t.absc[ra]); sa = t.csize[ca]; na = t.cdn[ca]; }
-        else      { sa = t.ssz[ra]; na = t.sdn[ra]; }
-        if (bbig) { cb = find_top(t, t.absc[rb]); sb = t.csize[cb]; nb = t.cdn[cb]; }
-        else      { sb = t.ssz[rb]; nb = t.sdn[rb]; }
-        const uint32_t node = (uint32_t)(n + i);
-        t.dparent[na] = node << 1;
-        t.dparent[nb] = (node << 1) | 1u;
-        t.evc[i] = (uint16_t)NONE16;
-        t.evs[i] = 0;
-        if (!abig && !bbig) {
-            const uint32_t s = sa + sb;
-            if ((int)s < mcs) {
-                uint32_t big = ra, small = rb;
-                if (sb > sa) { big = rb; small = ra; }
-                t.sp[small] = (uint16_t)big;
-                t.ssz[big] = (uint16_t)s;
-                t.sdn[big] = node;
-            } else {                                   // a condensed cluster is born bottom-up
-                if (t.nclusters >= t.cap_clusters) return false;
-                int32_t c = new_cluster(t, w, s, node, -1, -1);
-                t.evc[i] = (uint16_t)c; t.evs[i] = (uint16_t)s;
-                t.absc[ra] = (uint16_t)c; t.absw[ra] = w;
-                t.absc[rb] = (uint16_t)c; t.absw[rb] = w;
-            }
-        } else if (abig && bbig) {                     // true split: both sides >= mcs
-            if (t.nclusters >= t.cap_clusters) return false;
-            int32_t p = new_cluster(t, w, sa + sb, node, (int32_t)ca, (int32_t)cb);
-            t.evc[i] = (uint16_t)p; t.evs[i] = 0;
-            t.cspa[p] = sa; t.cspb[p] = sb;
-            t.cup[ca] = (uint16_t)p; t.cup[cb] = (uint16_t)p;
-            t.ctp[ca] = p; t.ctp[cb] = p;
-            t.cbirthw[ca] = w; t.cbirthw[cb] = w;
-        } else {                                       // small side falls out of the big side's cluster
-            uint32_t c = abig ? ca : cb, r = abig ? rb : ra, s = abig ? sb : sa;
-            t.absc[r] = (uint16_t)c; t.absw[r] = w;
-            t.evc[i] = (uint16_t)c; t.evs[i] = (uint16_t)s;
-            t.csize[c] += s;
-            t.cdn[c] = node;
-        }
+        const Resolved q = resolve(t, e);
+        if (!merge(t, i, n, mcs, e.w, q)) return false;
     }
     t.dparent[2 * n - 2] = 0xFFFFFFFFu;               // root of the dendrogram
     return true;
 }
 
-// Stability, excess-of-mass selection (root allowed) and nearest-selected-ancestor map.
-// Returns the number of selected clusters.
-SVC_HD int select(Tree &t, const Edge *edges) {
-    const int nc = t.nclusters;
-    // stabilities: the library's row loop, rows in its condensed-tree order (see header)
+// The same pass the way the device runs it (svc_tail.hip: build_wave), kept here in plain C++ with
+// the lanes as array slots so the CPU harness checks the batching logic against the oracle.
+//
+// Almost every edge of a real map is an ABSORPTION: a small component (usually one pixel) falls into
+// an existing big cluster.  A batch of up to B edges is resolved up front (device: one lane per edge,
+// read-only).  A scan in edge order then patches chains inside the batch -- a side whose root was
+// absorbed by an earlier edge of the batch now belongs to that edge's cluster -- and finds the longest
+// prefix of the batch that consists of absorptions only.  That prefix is applied at once: absorptions
+// touch disjoint small roots, and the only thing they share, the cluster's size and its chain of
+// dendrogram nodes, follows from the edge positions.  The edge that ends the prefix (two small
+// components, a cluster birth or a true split) is applied alone by merge() -- its resolved values are
+// still exact, because absorptions do not change roots or small-component sizes -- and the next batch
+// starts behind it.
+template <int B>
+inline bool build_batched(Tree &t, const Edge *edges, int n, int mcs) {
+    t.n = n;
+    t.nclusters = 0;
+    Resolved pre[B];
+    int i0 = 0;
+    while (i0 < n - 1) {
+        const int m = (n - 1 - i0) < B ? (n - 1 - i0) : B;
+        for (int j = 0; j < m; ++j) pre[j] = resolve_ro(t, edges[i0 + j]);
+        int P = m;
+        for (int k = 0; k < m; ++k) {
+            const bool abig = pre[k].ca != NONE16, bbig = pre[k].cb != NONE16;
+            if (abig == bbig) { P = k; break; }
+            const uint32_t ck = abig ? pre[k].ca : pre[k].cb, rk = abig ? pre[k].rb : pre[k].ra;
+            for (int j = k + 1; j < m; ++j) {
+                if (pre[j].ra == rk) pre[j].ca = ck;
+                if (pre[j].rb == rk) pre[j].cb = ck;
+            }
+        }
+        for (int j = 0; j < P; ++j) {                  // independent per j on the device
+            const Resolved &q = pre[j];
+            const bool abig = q.ca != NONE16;
+            const uint32_t c = abig ? q.ca : q.cb, r = abig ? q.rb : q.ra;
+            const uint32_t s = abig ? q.sb : q.sa, ns = abig ? q.nb : q.na;
+            uint32_t prev = t.cdn[c];                  // node of the cluster before the batch ...
+            for (int k = 0; k < j; ++k) {              // ... or of the previous absorption into it
+                const uint32_t ckk = pre[k].ca != NONE16 ? pre[k].ca : pre[k].cb;
+                if (ckk == c) prev = (uint32_t)(n + i0 + k);
+            }
+            const uint32_t node = (uint32_t)(n + i0 + j);
+            t.dparent[abig ? prev : ns] = node << 1;
+            t.dparent[abig ? ns : prev] = (node << 1) | 1u;
+            t.absc[r] = (uint16_t)c; t.absw[r] = edges[i0 + j].w;
+            t.evc[i0 + j] = (uint16_t)c; t.evs[i0 + j] = (uint16_t)s;
+        }
+        for (int j = 0; j < P; ++j) {                  // after all reads of cdn above
+            const Resolved &q = pre[j];
+            const bool abig = q.ca != NONE16;
+            const uint32_t c = abig ? q.ca : q.cb;
+            t.csize[c] += abig ? q.sb : q.sa;
+            t.cdn[c] = (uint32_t)(n + i0 + j);
+        }
+        i0 += P;
+        if (P < m) {
+            if (!merge(t, i0, n, mcs, edges[i0].w, pre[P])) return false;
+            ++i0;
+        }
+    }
+    t.dparent[2 * n - 2] = 0xFFFFFFFFu;
+    return true;
+}
+
+// Stabilities: the library's row loop, rows in its condensed-tree order (see header).
+// (svc_tail.hip: accumulate_wave is the same loop with the per-row terms computed 64 rows at a time.)
+SVC_HD void accumulate(Tree &t, const Edge *edges) {
+    uint32_t w_prev = 0, c_prev = NONE16;
+    double lam = 0.0, birth = 0.0;
     for (int i = t.n - 2; i >= 0; --i) {
         const uint16_t c = t.evc[i];
         if (c == NONE16) continue;
-        const double lam = 1.0 / (double)edges[i].w;
-        const double birth = t.cbirthw[c] ? 1.0 / (double)t.cbirthw[c] : 0.0;
+        const uint32_t w = edges[i].w;
+        if (w != w_prev) { lam = 1.0 / (double)w; w_prev = w; }      // weights and clusters repeat in runs:
+        if (c != c_prev) {                                            // divide once per run, not per row
+            birth = t.cbirthw[c] ? 1.0 / (double)t.cbirthw[c] : 0.0;
+            c_prev = c;
+        }
         double acc = t.cacc[c];
         if (t.evs[i] == 0) {                            // the two cluster rows of a split, left first
             acc += (lam - birth) * (double)t.cspa[c];
@@ -208,6 +318,12 @@ SVC_HD int select(Tree &t, const Edge *edges) {
         }
         t.cacc[c] = acc;
     }
+}
+
+// Excess-of-mass selection (root allowed) and nearest-selected-ancestor map, from the stabilities.
+// Returns the number of selected clusters.
+SVC_HD int choose(Tree &t) {
+    const int nc = t.nclusters;
     for (int c = 0; c < nc; ++c) {                      // creation order: children before parents
         double stab = t.cacc[c];
         double sub = 0.0;
@@ -234,6 +350,11 @@ SVC_HD int select(Tree &t, const Edge *edges) {
         }
     }
     return nsel;
+}
+
+SVC_HD int select(Tree &t, const Edge *edges) {
+    accumulate(t, edges);
+    return choose(t);
 }
 
 // Label of point p as a cluster index (creation order), -1 = noise.

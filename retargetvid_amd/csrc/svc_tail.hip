@@ -575,6 +575,140 @@ struct TreeShared {
     int nsel, best, ok;
 };
 
+// hdb::build_batched<64> on one wavefront (see the comment there): lane j resolves edge j of the batch;
+// a scan in edge order patches absorption chains and finds the prefix of pure absorptions, which all
+// lanes then apply at once; the edge that ends the prefix is applied by lane 0 through hdb::merge.
+__device__ __forceinline__ bool build_wave(hdb::Tree &t, const hdb::Edge *edges, int n, int mcs) {
+    const int lane = threadIdx.x & 63;
+    t.n = n;
+    t.nclusters = 0;
+    int i0 = 0;
+    while (i0 < n - 1) {
+        const int m = min(64, n - 1 - i0);
+        hdb::Edge e = hdb::Edge{0, 0, 1};
+        hdb::Resolved pre = hdb::Resolved{0, 0, hdb::NONE16, hdb::NONE16, 0, 0, 0, 0};
+        if (lane < m) {
+            e = edges[i0 + lane];
+            pre = hdb::resolve_ro(t, e);
+        }
+        const uint32_t v_r = pre.ra | (pre.rb << 16);
+        uint32_t v_c = pre.ca | (pre.cb << 16);
+        int P = m;
+        for (int k = 0; k < m; ++k) {
+            const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)v_c, k);
+            const bool abig = (cc & 0xFFFFu) != hdb::NONE16, bbig = (cc >> 16) != hdb::NONE16;
+            if (abig == bbig) { P = k; break; }
+            const uint32_t rr = (uint32_t)__builtin_amdgcn_readlane((int)v_r, k);
+            const uint32_t ck = abig ? (cc & 0xFFFFu) : (cc >> 16);
+            const uint32_t rk = abig ? (rr >> 16) : (rr & 0xFFFFu);
+            if (lane > k) {                              // sides rooted at rk belong to ck from here on
+                if ((v_r & 0xFFFFu) == rk) v_c = (v_c & 0xFFFF0000u) | ck;
+                if ((v_r >> 16) == rk) v_c = (v_c & 0xFFFFu) | (ck << 16);
+            }
+        }
+        if (P > 0) {
+            const bool act = lane < P;
+            const uint32_t ca = v_c & 0xFFFFu, cb = v_c >> 16;
+            const bool abig = ca != hdb::NONE16;
+            const uint32_t c = abig ? ca : cb, r = abig ? pre.rb : pre.ra;
+            const uint32_t s = abig ? pre.sb : pre.sa, ns = abig ? pre.nb : pre.na;
+            const uint32_t node = (uint32_t)(n + i0 + lane);
+            uint32_t prev = 0;
+            unsigned long long todo = P == 64 ? ~0ull : ((1ull << P) - 1ull);
+            while (todo) {                               // once per distinct cluster (nearly always one)
+                const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c, __builtin_ctzll(todo));
+                const unsigned long long grp = __ballot(act && c == c0);
+                const uint32_t before = t.cdn[c0];
+                if (act && c == c0) {
+                    const unsigned long long lower = grp & ((1ull << lane) - 1ull);
+                    prev = lower ? (uint32_t)(n + i0 + 63 - __builtin_clzll(lower)) : before;
+                }
+                if (lane == 0) t.cdn[c0] = (uint32_t)(n + i0 + 63 - __builtin_clzll(grp));
+                todo &= ~grp;
+            }
+            if (act) {
+                t.dparent[abig ? prev : ns] = node << 1;
+                t.dparent[abig ? ns : prev] = (node << 1) | 1u;
+                t.absc[r] = (uint16_t)c; t.absw[r] = e.w;
+                t.evc[i0 + lane] = (uint16_t)c; t.evs[i0 + lane] = (uint16_t)s;
+                atomicAdd(&t.csize[c], s);
+            }
+            i0 += P;
+        }
+        if (P < m) {
+            hdb::Resolved q;
+            const uint32_t rr = (uint32_t)__builtin_amdgcn_readlane((int)v_r, P);
+            const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)v_c, P);
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)e.w, P);
+            q.ra = rr & 0xFFFFu; q.rb = rr >> 16;
+            q.ca = cc & 0xFFFFu; q.cb = cc >> 16;
+            q.sa = q.sb = q.na = q.nb = 0;
+            int ok = 1;
+            if (lane == 0) ok = hdb::merge(t, i0, n, mcs, w, q) ? 1 : 0;
+            if (!__builtin_amdgcn_readfirstlane(ok)) return false;
+            ++i0;
+        }
+    }
+    if (lane == 0) t.dparent[2 * n - 2] = 0xFFFFFFFFu;
+    t.nclusters = __builtin_amdgcn_readfirstlane(t.nclusters);
+    return true;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int j) {
+    const long long b = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, j);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), j);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// hdb::accumulate on one wavefront: the reciprocals and the per-row terms of 64 rows are computed
+// by the lanes in parallel; only the float64 additions run in the library's order (one after the
+// other, into a register that is written back when the cluster changes), so the sums are bit-identical.
+__device__ __forceinline__ void accumulate_wave(hdb::Tree &t, const hdb::Edge *edges) {
+    const int lane = threadIdx.x & 63;
+    uint32_t cur = hdb::NONE16;
+    double acc = 0.0;
+    for (int top = t.n - 2; top >= 0; top -= 64) {
+        const int i = top - lane;
+        uint32_t c = hdb::NONE16, s = 0;
+        double term = 0.0, ta = 0.0, tb = 0.0;
+        if (i >= 0) {
+            c = t.evc[i];
+            if (c != hdb::NONE16) {
+                s = t.evs[i];
+                const uint32_t bw = t.cbirthw[c];
+                const double lam = 1.0 / (double)edges[i].w;
+                const double birth = bw ? 1.0 / (double)bw : 0.0;
+                term = (lam - birth) * 1.0;
+                if (s == 0) {
+                    ta = (lam - birth) * (double)t.cspa[c];
+                    tb = (lam - birth) * (double)t.cspb[c];
+                }
+            }
+        }
+        unsigned long long live = __ballot(c != hdb::NONE16);
+        while (live) {
+            const int j = __builtin_ctzll(live);
+            live &= live - 1;
+            const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)c, j);
+            const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)s, j);
+            if (cj != cur) {
+                if (cur != hdb::NONE16 && lane == 0) t.cacc[cur] = acc;
+                cur = cj;
+                acc = t.cacc[cj];
+            }
+            if (sj == 0) {
+                acc += readlane_f64(ta, j);
+                acc += readlane_f64(tb, j);
+            } else {
+                const double tj = readlane_f64(term, j);
+                for (uint32_t k = 0; k < sj; ++k) acc += tj;
+            }
+        }
+    }
+    if (cur != hdb::NONE16 && lane == 0) t.cacc[cur] = acc;
+}
+
 // Hierarchy, labels, cluster weights and the choice of the kept cluster for one map.
 // LDS = true: the hot per-point / per-cluster state lives in the dynamic LDS buffer `sm` (all
 // pointers derive from it, so the compiler emits ds_* instead of flat_* accesses);
@@ -625,9 +759,12 @@ __device__ __forceinline__ int cluster_phase(const TailArgs &A, uint8_t *ws, uin
         hdb::init_points(t, min(N, tid * per), min(N, tid * per + per));
     }
     __syncthreads();
+    const bool built = build_wave(t, edges, N, A.mcs);       // the block is one wavefront (k_tree)
+    if (tid == 0) hdr[13] = (int)(wall_clock64() - t0);
+    if (built) accumulate_wave(t, edges);
     if (tid == 0) {
-        const bool ok = hdb::build(t, edges, N, A.mcs);
-        if (ok) S.nsel = hdb::select(t, edges);
+        const bool ok = built;
+        if (ok) S.nsel = hdb::choose(t);
         S.ok = ok;
         hdr[4] = t.nclusters;
         hdr[9] = (int)(wall_clock64() - t0);
@@ -697,9 +834,11 @@ __global__ __launch_bounds__(64) void k_tree(TailArgs A) {
     extern __shared__ uint8_t sm_tree[];
     __shared__ TreeShared S;
     const long long t0 = wall_clock64();
+    const long long c0 = clock64();
     int best = -2;
     if (N <= TREE_LDS_CAP) best = cluster_phase<true>(A, ws, sm_tree, S, hdr, N, t0);
     if (best == -2) best = cluster_phase<false>(A, ws, sm_tree, S, hdr, N, t0);
+    if (threadIdx.x == 0) { hdr[14] = (int)(clock64() - c0); hdr[15] = (int)(wall_clock64() - t0); }
 }
 
 // k_finish: zero everything outside the kept cluster, CLOSE 5x5, write the map back, centroid

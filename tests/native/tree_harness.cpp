@@ -4,8 +4,20 @@
 #include <vector>
 #include "../../retargetvid_amd/csrc/hdb_tree.h"
 
+static int run(const uint16_t *a, const uint16_t *b, const uint32_t *w, int n, int mcs, int32_t *labels, int batched);
+
 extern "C" int tree_labels(const uint16_t *a, const uint16_t *b, const uint32_t *w, int n, int mcs,
                            int32_t *labels) {
+    return run(a, b, w, n, mcs, labels, 0);
+}
+
+// the batched form of the pass (what the GPU runs): batch of 64 edges resolved up front
+extern "C" int tree_labels_batched(const uint16_t *a, const uint16_t *b, const uint32_t *w, int n, int mcs,
+                                   int32_t *labels) {
+    return run(a, b, w, n, mcs, labels, 1);
+}
+
+static int run(const uint16_t *a, const uint16_t *b, const uint32_t *w, int n, int mcs, int32_t *labels, int batched) {
     using namespace hdb;
     std::vector<Edge> edges(n - 1);
     for (int i = 0; i < n - 1; ++i) edges[i] = Edge{a[i], b[i], w[i]};
@@ -20,7 +32,7 @@ extern "C" int tree_labels(const uint16_t *a, const uint16_t *b, const uint32_t 
            csize.data(), cdn.data(), csplit.data(), cspa.data(), cspb.data(), cacc.data(), csel.data(), crep.data(),
            0, n, mc};
     init_points(t, 0, n);
-    if (!build(t, edges.data(), n, mcs)) return -1;
+    if (!(batched ? build_batched<64>(t, edges.data(), n, mcs) : build(t, edges.data(), n, mcs))) return -1;
     const int nsel = select(t, edges.data());
     std::vector<int> sel;
     for (int c = 0; c < t.nclusters; ++c) if (t.crep[c] == c) sel.push_back(c);

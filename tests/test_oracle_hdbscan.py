@@ -87,7 +87,7 @@ def test_hierarchy_stage_matches_oracle(tree_lib, golden_dir):
         u, v, w = tr['mst']
         o = np.argsort(w, kind='stable')
         a, b, ww = u[o].astype(np.uint16), v[o].astype(np.uint16), w[o].astype(np.uint32)
-        out = np.zeros(n, np.int32)
-        tree_lib.tree_labels(a.ctypes.data_as(vp), b.ctypes.data_as(vp), ww.ctypes.data_as(vp), n, mcs,
-                             out.ctypes.data_as(vp))
-        assert np.array_equal(out, lab)
+        for fn in (tree_lib.tree_labels, tree_lib.tree_labels_batched):      # serial form, and the batched form the GPU runs
+            out = np.zeros(n, np.int32)
+            fn(a.ctypes.data_as(vp), b.ctypes.data_as(vp), ww.ctypes.data_as(vp), n, mcs, out.ctypes.data_as(vp))
+            assert np.array_equal(out, lab)

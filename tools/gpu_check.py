@@ -141,8 +141,8 @@ try:
             (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, stats[:, 0].float().mean().item()))
     for i in range(0, 32, 4):
         st = eng.cluster_state(i, 35000)
-        print('  warm frame %2d: N=%5d nclusters %3d  finish stamps (us): sorted %.1f hierarchy %.1f chosen %.1f done %.1f | prim %.1f us' % (
-            i, st['n'], st['hdr'][4], st['hdr'][8] / 100.0, st['hdr'][9] / 100.0, st['hdr'][10] / 100.0, st['hdr'][11] / 100.0, st['hdr'][12] / 100.0))
+        print('  warm frame %2d: N=%5d nclusters %3d  finish stamps (us): sorted %.1f built %.1f hierarchy %.1f chosen %.1f done %.1f | prim %.1f us | k_tree shader clock %.0f MHz' % (
+            i, st['n'], st['hdr'][4], st['hdr'][8] / 100.0, st['hdr'][13] / 100.0, st['hdr'][9] / 100.0, st['hdr'][10] / 100.0, st['hdr'][11] / 100.0, st['hdr'][12] / 100.0, st['hdr'][14] / max(st['hdr'][15], 1) * 100.0))
 except Exception:
     traceback.print_exc(); ok = False
 

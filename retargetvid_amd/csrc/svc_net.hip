@@ -1324,6 +1324,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->pw16 = atoi(env) != 0;
     env = getenv("SVC_FUSE_MAX");
     if (env) h->fuse_max = std::min(13, std::max(0, atoi(env)));
+    env = getenv("SVC_PRIM_PT");
+    if (env && atoi(env) > 0) h->prim_pt = atoi(env);
     int rc = h->blob.ensure(n_bytes);
     if (rc) { delete h; return rc; }
     if (hipMemcpy(h->blob.p, blob_host, n_bytes, hipMemcpyHostToDevice) != hipSuccess) {

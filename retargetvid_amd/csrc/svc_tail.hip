@@ -75,6 +75,7 @@ struct TailArgs {
     int n, h, w;
     FDiv dW;                // division by w
     int mcs, min_samples, select_sum, op_close, clust_filt;
+    int prim_pt;            // tuning: smallest points-per-thread variant of k_prim
     const uint32_t *ring;   // sorted neighbour offsets
     int n_ring, n_ring1;    // all offsets within RING_R / the prefix within RING_R1
     double *xy;
@@ -387,44 +388,48 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 
 template <int PT>
 __device__ __forceinline__ void prim_regs32(const uint32_t *__restrict__ core_g, hdb::Edge *__restrict__ mst, int N,
-                                            const uint16_t *rc16, uint2 *slots) {
+                                            const uint16_t *rc16, uint4 *slots) {
+    // Thread t owns points t*PT .. t*PT+PT-1 entirely in registers (coordinates, core distance,
+    // reachability); wavefronts that own no point leave, so the barrier spans only ceil(N/(64*PT)) waves.
+    // A point that joined the tree gets core = reach = REACH_INF: its key sorts behind every live one and
+    // no update can lower it, so the inner loop has no liveness test.  The winner's core distance and
+    // coordinates travel with its key, so one step has a single LDS round trip (slot write, barrier, read).
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t reach[PT], corev[PT];
-    uint32_t alive = 0;
+    const int nw = (N + 64 * PT - 1) / (64 * PT);
+    for (int i = tid; i < 2 * NW16; i += TB) slots[i] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+    __syncthreads();
+    if (wave >= nw) return;
+    uint32_t reach[PT], corev[PT], rcv[PT];
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
-        const int p = tid + i * TB;
+        const int p = tid * PT + i;
         reach[i] = REACH_INF;
-        corev[i] = 0;
-        if (p < N) { corev[i] = core_g[p]; alive |= 1u << i; }
+        corev[i] = REACH_INF;
+        rcv[i] = 0;
+        if (p < N) { corev[i] = core_g[p]; rcv[i] = rc16[p]; }
     }
+    if (tid == 0) corev[0] = REACH_INF;                    // point 0 starts the tree
     uint32_t cur = 0;
-    uint32_t cv = rc16[0];
-    int cr = cv & 255, cc = cv >> 8;
+    const uint32_t cv0 = rc16[0];
+    int cr = cv0 & 255, cc = cv0 >> 8;
     uint32_t ccore = core_g[0];
-    if (tid == 0) alive &= ~1u;
     for (int step = 0; step < N - 1; ++step) {
-        uint32_t best = 0xFFFFFFFFu, bcore = 0;
+        uint32_t best = 0xFFFFFFFFu, bcore = 0, brc = 0;
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
-            if ((alive >> i) & 1u) {
-                const int p = tid + i * TB;
-                const uint32_t v = rc16[p];
-                const int dr = (int)(v & 255) - cr, dc = (int)(v >> 8) - cc;
-                uint32_t m = (uint32_t)(dr * dr + dc * dc);
-                m = max(max(m, corev[i]), ccore);
-                if (m < reach[i]) reach[i] = m;
-                const uint32_t key = (reach[i] << 15) | (uint32_t)p;
-                if (key < best) { best = key; bcore = corev[i]; }
-            }
+            const int dr = (int)(rcv[i] & 255) - cr, dc = (int)(rcv[i] >> 8) - cc;
+            const uint32_t m = max(max((uint32_t)(dr * dr + dc * dc), corev[i]), ccore);
+            reach[i] = min(reach[i], m);
+            const uint32_t key = (reach[i] << 15) | (uint32_t)(tid * PT + i);
+            if (key < best) { best = key; bcore = corev[i]; brc = rcv[i]; }
         }
         const uint32_t wmin = wave_min_u32(best);
-        uint2 *sl = slots + (step & 1) * NW16;
-        if (best == wmin) sl[wave] = make_uint2(wmin, bcore);      // one lane (keys are unique) or all-dead wave
+        uint4 *sl = slots + (step & 1) * NW16;
+        if (best == wmin) sl[wave] = make_uint4(wmin, bcore, brc, 0);   // keys are unique: one lane
         __syncthreads();
-        // second level: lanes 0..15 of every row hold one slot each; row minimum by DPP, the
-        // winner's payload by readlane
-        const uint2 t = sl[lane & 15];
+        // second level: lanes 0..15 of every row hold one slot each; row minimum by DPP, the winner's
+        // payload by readlane
+        const uint4 t = sl[lane & 15];
         uint32_t k2 = t.x;
         k2 = dpp_min_u32<0x111, 0xF>(k2);
         k2 = dpp_min_u32<0x112, 0xF>(k2);
@@ -434,9 +439,13 @@ __device__ __forceinline__ void prim_regs32(const uint32_t *__restrict__ core_g,
         const int src = __ffsll((unsigned long long)__ballot(t.x == kmin)) - 1;
         const uint32_t nidx = kmin & 0x7FFFu;
         if (tid == 0) mst[step] = hdb::Edge{(uint16_t)cur, (uint16_t)nidx, kmin >> 15};
-        if ((int)(nidx & (TB - 1)) == tid) alive &= ~(1u << (nidx >> 10));
+        if ((int)(nidx / PT) == tid) {
+#pragma unroll
+            for (int i = 0; i < PT; ++i)
+                if ((int)(nidx % PT) == i) { corev[i] = REACH_INF; reach[i] = REACH_INF; }
+        }
         ccore = (uint32_t)__builtin_amdgcn_readlane((int)t.y, src);
-        cv = rc16[nidx];
+        const uint32_t cv = (uint32_t)__builtin_amdgcn_readlane((int)t.z, src);
         cr = cv & 255; cc = cv >> 8;
         cur = nidx;
     }
@@ -490,19 +499,20 @@ __global__ __launch_bounds__(TB) void k_prim(TailArgs A) {
     if (!hdr[3]) return;
     const int N = hdr[0];
     extern __shared__ uint8_t sm_prim[];
-    unsigned long long *slots = (unsigned long long *)sm_prim;       // [2][NW16] (uint2 or u64)
-    uint16_t *rc16 = (uint16_t *)(sm_prim + 2 * NW16 * 8);           // [N]
+    unsigned long long *slots = (unsigned long long *)sm_prim;       // [2][NW16] (uint4 or u64)
+    uint16_t *rc16 = (uint16_t *)(sm_prim + 2 * NW16 * 16);          // [N]
     const uint32_t *pts = (const uint32_t *)(ws + A.L.pts);
     for (int p = threadIdx.x; p < N; p += TB) rc16[p] = (uint16_t)(pts[p] & 0xFFFFu);
     __syncthreads();
     const uint32_t *core = (const uint32_t *)(ws + A.L.core);
     hdb::Edge *mst = (hdb::Edge *)(ws + A.L.mst);
     long long t0 = wall_clock64();
-    if (N <= 2 * TB) prim_regs32<2>(core, mst, N, rc16, (uint2 *)slots);
-    else if (N <= 4 * TB) prim_regs32<4>(core, mst, N, rc16, (uint2 *)slots);
-    else if (N <= 8 * TB) prim_regs32<8>(core, mst, N, rc16, (uint2 *)slots);
-    else if (N <= 16 * TB) prim_regs32<16>(core, mst, N, rc16, (uint2 *)slots);
-    else if (N <= 32 * TB) prim_regs32<32>(core, mst, N, rc16, (uint2 *)slots);
+    const int pt = A.prim_pt;                                        // smallest points-per-thread to use
+    if (N <= 2 * TB && pt <= 2) prim_regs32<2>(core, mst, N, rc16, (uint4 *)slots);
+    else if (N <= 4 * TB && pt <= 4) prim_regs32<4>(core, mst, N, rc16, (uint4 *)slots);
+    else if (N <= 8 * TB && pt <= 8) prim_regs32<8>(core, mst, N, rc16, (uint4 *)slots);
+    else if (N <= 16 * TB) prim_regs32<16>(core, mst, N, rc16, (uint4 *)slots);
+    else if (N <= 32 * TB) prim_regs32<32>(core, mst, N, rc16, (uint4 *)slots);
     else prim_global(core, (uint32_t *)(ws + A.L.reach), mst, N, rc16, slots);
     if (threadIdx.x == 0) ((int32_t *)(ws + A.L.hdr))[12] = (int)(wall_clock64() - t0);
 }
@@ -1067,11 +1077,12 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
     A.n = n; A.h = height; A.w = width; A.dW = make_fdiv(width);
     A.mcs = params->hdbscan_min; A.min_samples = params->hdbscan_min_samples; A.select_sum = params->select_sum;
     A.op_close = params->op_close; A.clust_filt = params->clust_filt;
+    A.prim_pt = h->prim_pt;
     A.ring = (const uint32_t *)h->tail_offsets.p; A.n_ring = h->tail_n_offsets; A.n_ring1 = h->tail_n_offsets1;
     A.xy = xy; A.stats = stats; A.L = L;
     const int hw = height * width;
     const size_t lds_core = (size_t)(hw + 15) / 16 * 16 + (size_t)h->tail_n_offsets * 4;
-    const size_t lds_prim = 2 * NW16 * 8 + (size_t)hw * 2;
+    const size_t lds_prim = 2 * NW16 * 16 + (size_t)hw * 2;
     const size_t lds_fin = 2 * ((size_t)(hw + 15) / 16 * 16);
     static bool attr_done = false;
     if (!attr_done) {

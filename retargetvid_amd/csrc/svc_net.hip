@@ -525,6 +525,74 @@ __global__ __launch_bounds__(256) void k_dw(const float *__restrict__ X, const f
     *(float4 *)(Y + (size_t)gid * 4) = acc;
 }
 
+// Stride-1 depthwise with a TX x TY register tile of outputs per thread (x 4 channels).  k_dw issues 18
+// vector loads per output (9 taps + 9 weights) and is bound by the CU's vector-memory issue rate, not by
+// HBM; here a thread walks its TY+2 input rows once, keeps one row of TX+2 taps in registers and feeds
+// every output row that uses it: (TY+2)(TX+2)+9 loads for TX*TY outputs (4.1 per output at 4x2).  Per
+// output the taps are still accumulated in the order ky, kx with out-of-image taps contributing nothing,
+// so the result equals k_dw<1>'s.
+template <int TX, int TY>
+__global__ __launch_bounds__(256) void k_dw_tile(const float *__restrict__ X, const float *__restrict__ Wt,
+                                                 const float *__restrict__ bias, float *__restrict__ Y, int n,
+                                                 int H, int W, int C, FDiv dC4, FDiv dGX, FDiv dGY, uint32_t total) {
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    if (gid >= total) return;
+    uint32_t c4, gx, gy;
+    const uint32_t cell = fdivmod(gid, dC4, c4);
+    const uint32_t f = fdivmod(fdivmod(cell, dGX, gx), dGY, gy);
+    const int ox0 = gx * TX, oy0 = gy * TY;
+    const float *xf = X + (size_t)f * H * W * C + c4 * 4;
+    float4 w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t] = *(const float4 *)(Wt + t * C + c4 * 4);
+    float4 acc[TY][TX];
+#pragma unroll
+    for (int ty = 0; ty < TY; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < TX; ++tx) acc[ty][tx] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < TY + 2; ++r) {
+        const int iy = oy0 - 1 + r;
+        if (iy < 0 || iy >= H) continue;
+        float4 row[TX + 2];
+#pragma unroll
+        for (int j = 0; j < TX + 2; ++j) {
+            const int ix = ox0 - 1 + j;
+            row[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ix >= 0 && ix < W) row[j] = *(const float4 *)(xf + ((size_t)iy * W + ix) * C);
+        }
+#pragma unroll
+        for (int ty = 0; ty < TY; ++ty) {
+            const int ky = r - ty;
+            if (ky < 0 || ky > 2) continue;
+#pragma unroll
+            for (int tx = 0; tx < TX; ++tx)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float4 x = row[tx + kx], ww = w[ky * 3 + kx];
+                    acc[ty][tx].x = fmaf(x.x, ww.x, acc[ty][tx].x);
+                    acc[ty][tx].y = fmaf(x.y, ww.y, acc[ty][tx].y);
+                    acc[ty][tx].z = fmaf(x.z, ww.z, acc[ty][tx].z);
+                    acc[ty][tx].w = fmaf(x.w, ww.w, acc[ty][tx].w);
+                }
+        }
+    }
+    const float4 b = *(const float4 *)(bias + c4 * 4);
+    float *yf = Y + (size_t)f * H * W * C + c4 * 4;
+#pragma unroll
+    for (int ty = 0; ty < TY; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < TX; ++tx) {
+            if (oy0 + ty >= H || ox0 + tx >= W) continue;
+            float4 v = acc[ty][tx];
+            v.x = fminf(fmaxf(v.x + b.x, 0.f), 6.f);
+            v.y = fminf(fmaxf(v.y + b.y, 0.f), 6.f);
+            v.z = fminf(fmaxf(v.z + b.z, 0.f), 6.f);
+            v.w = fminf(fmaxf(v.w + b.w, 0.f), 6.f);
+            *(float4 *)(yf + ((size_t)(oy0 + ty) * W + ox0 + tx) * C) = v;
+        }
+}
+
 __global__ __launch_bounds__(256) void k_subsample(const float *__restrict__ X, float *__restrict__ Y, int n, int H,
                                                    int W, int C) {
     const int C4 = C >> 2, OH = H >> 1, OW = W >> 1;
@@ -882,7 +950,22 @@ static int launch_dw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer
     if (stride == 2)
         k_dw<2><<<blocks256(total), 256, 0, s>>>(X, L.w.dev, L.b.dev, Y, n, H, W, C, OH, OW, make_fdiv(C / 4), make_fdiv(OW),
                                                  make_fdiv(OH));
-    else
+    else if (h->dw_tile) {
+        const int tx = h->dw_tile / 10, ty = h->dw_tile % 10;
+        const int GX = (W + tx - 1) / tx, GY = (H + ty - 1) / ty;
+        const size_t cells = (size_t)n * GY * GX * (C / 4);
+#define DW_TILE(TXv, TYv)                                                                                             \
+    k_dw_tile<TXv, TYv><<<blocks256(cells), 256, 0, s>>>(X, L.w.dev, L.b.dev, Y, n, H, W, C, make_fdiv(C / 4),        \
+                                                         make_fdiv(GX), make_fdiv(GY), (uint32_t)cells)
+        switch (h->dw_tile) {
+            case 21: DW_TILE(2, 1); break;
+            case 22: DW_TILE(2, 2); break;
+            case 41: DW_TILE(4, 1); break;
+            case 44: DW_TILE(4, 4); break;
+            default: DW_TILE(4, 2); break;
+        }
+#undef DW_TILE
+    } else
         k_dw<1><<<blocks256(total), 256, 0, s>>>(X, L.w.dev, L.b.dev, Y, n, H, W, C, OH, OW, make_fdiv(C / 4), make_fdiv(OW),
                                                  make_fdiv(OH));
     SVC_CHECK_LAUNCH();
@@ -894,48 +977,95 @@ static int launch_dw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer
 // + ReLU6 -> 1x1 project (+ residual) for one tile of TOH x TOW output pixels.  The 6x
 // expanded tensor and the depthwise output never leave the CU: per 32-channel chunk of the
 // expansion the workgroup (4 waves) computes
-//   E  = relu6(Xs . We^T + be)   for the (TOH-1)S+3 x (TOW-1)S+3 input halo   (f32 MFMA, A from LDS)
+//   E  = relu6(Xs . We^T + be)   for the (TOH-1)S+3 x (TOW-1)S+3 input halo   (f32 MFMA, A and B from LDS)
 //   D  = relu6(dw3x3(E) + bd)                                                 (VALU, float4 over channels)
-//   acc += D . Wp^T                                                           (f32 MFMA, A from LDS)
+//   acc += D . Wp^T                                                           (f32 MFMA, A and B from LDS)
 // with the same k order and tap order as k_pw / k_dw, so results are bit-identical to the
 // un-fused kernels.  Out-of-image halo pixels hold E = 0 (the depthwise conv pads E, not X).
 // EXPAND = false is the t=1 block (features.1): E is the input itself.
+//
+// Weights: the three weight slices of a chunk are a few KB.  They are fetched from global memory (L2)
+// with one coalesced float4 per thread a full phase before they are needed, parked in registers across
+// that phase, and written to LDS behind the barrier that retires their previous readers:
+//   We[ch+1], Wp[ch]  requested before expand(ch), stored after barrier 1 (readers: expand(ch) / project(ch-1))
+//   Wd[ch+1]          requested before expand(ch), stored after barrier 2 (readers: depthwise(ch))
+// so no MFMA k step or depthwise tap ever waits on an L2 round trip, and the register cost is 4 float4.
 // --------------------------------------------------------------------------------------
-#define IRB_ES 36      // LDS row stride (floats) of E and D: 32 channels + 4 pad (conflict-free float4 rows)
+#define IRB_ES 36      // LDS row stride (floats) of E, D and the Wp slice: 32 channels + 4 pad (conflict-free float4 rows)
+
+template <int S, int TOH, int TOW>
+struct IrbGeom {
+    static constexpr int IH = (TOH - 1) * S + 3, IW = (TOW - 1) * S + 3, NPX = IH * IW, MT = (NPX + 31) / 32;
+    static constexpr int NOUT = TOH * TOW;
+    // floats of LDS; rows NPX..MT*32-1 of Xs are never written: the expand MFMA reads whatever lies behind them
+    // (the E array, so still inside the allocation) into accumulator rows that are discarded.  Every byte counts:
+    // three workgroups per CU need <= 53 KB each.
+    static size_t lds_floats(int Cin, int CoutP, bool expand) {
+        const size_t XS = Cin + 4;
+        size_t n = (size_t)NPX * XS + (expand ? (size_t)NPX * IRB_ES : 0) + (size_t)NOUT * IRB_ES;
+        n += (expand ? 32 * XS : 0) + (size_t)CoutP * IRB_ES + 9 * 32;
+        return n;
+    }
+};
 
 template <int S, int TOH, int TOW, bool EXPAND>
-__global__ __launch_bounds__(256) void k_irb(const float *__restrict__ X, int H, int W, int Cin,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_irb(const float *__restrict__ X, int H, int W, int Cin,
                                              const float *__restrict__ We, const float *__restrict__ be, int Ce,
                                              const float *__restrict__ Wd, const float *__restrict__ bd,
                                              const float *__restrict__ Wp, const float *__restrict__ bp, int Cout,
                                              int CoutP, const float *__restrict__ R, float *__restrict__ Y, int ldy,
                                              int OH, int OW, int tiles_x, int tiles_y) {
-    constexpr int IH = (TOH - 1) * S + 3, IW = (TOW - 1) * S + 3, NPX = IH * IW, MT = (NPX + 31) / 32, MROWS = MT * 32;
-    constexpr int NOUT = TOH * TOW, MP = NOUT / 32, NG = 4 / MP;
+    using G = IrbGeom<S, TOH, TOW>;
+    constexpr int IW = G::IW, NPX = G::NPX, MT = G::MT;
+    constexpr int NOUT = G::NOUT, MP = NOUT / 32;
     extern __shared__ float sm_irb[];
     const int XS = Cin + 4;
-    float *Xs = sm_irb;                                     // [MROWS][XS]
-    float *E = EXPAND ? Xs + MROWS * XS : Xs;               // [MROWS][IRB_ES]   (t=1: XS == IRB_ES, E is Xs)
-    float *D = E + MROWS * IRB_ES;                          // [NOUT][IRB_ES]
+    float *Xs = sm_irb;                                     // [NPX][XS]
+    float *E = EXPAND ? Xs + NPX * XS : Xs;                 // [NPX][IRB_ES]   (t=1: XS == IRB_ES, E is Xs)
+    float *D = E + NPX * IRB_ES;                            // [NOUT][IRB_ES]
+    float *Wes = D + NOUT * IRB_ES;                         // [32][XS]        expand weights of the chunk
+    float *Wps = Wes + (EXPAND ? 32 * XS : 0);              // [CoutP][IRB_ES] project weights of the chunk
+    float *Wds = Wps + CoutP * IRB_ES;                      // [9][32]         depthwise weights of the chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     int bid = blockIdx.x;
     const int tx = bid % tiles_x;
     bid /= tiles_x;
     const int ty = bid % tiles_y, f = bid / tiles_y;
     const int oy0 = ty * TOH, ox0 = tx * TOW, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
-    // 1. input halo -> LDS (zeros outside the image)
+    const int c4n = Cin >> 2;
+    const int nchunks = (Ce + 31) >> 5;
+    // weight slices as seen by this thread (one float4 each; the project slice has CoutP*8 float4 <= 4 per thread)
+    const int we_row = tid / c4n, we_c4 = tid - we_row * c4n;             // valid for tid < 32 * c4n
+    const bool we_mine = EXPAND && tid < 32 * c4n;
+    const bool wd_mine = tid < 72;
+    const int wd_t = tid >> 3, wd_c4 = tid & 7;
+    const int wp_n = (CoutP * 8 + 255) >> 8;                                // float4 per thread in the project slice
+    auto load_we = [&](int ch) -> float4 {
+        return we_mine ? *(const float4 *)(We + (size_t)(ch * 32 + we_row) * Cin + we_c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto load_wd = [&](int ch) -> float4 {
+        const int c = ch * 32 + wd_c4 * 4;
+        return (wd_mine && c < Ce) ? *(const float4 *)(Wd + (size_t)wd_t * Ce + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto load_wp = [&](int ch, int q) -> float4 {
+        const int idx = tid + q * 256, row = idx >> 3, k4 = idx & 7;
+        const int k = ch * 32 + k4 * 4;
+        return (q < wp_n && row < CoutP && k < Ce) ? *(const float4 *)(Wp + (size_t)row * Ce + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    // 1. input halo and the first weight slices -> LDS (zeros outside the image)
     {
-        const int c4n = Cin >> 2;
         const float *xf = X + (size_t)f * H * W * Cin;
-        for (int idx = tid; idx < MROWS * c4n; idx += 256) {
+        for (int idx = tid; idx < NPX * c4n; idx += 256) {
             const int row = idx / c4n, c4 = idx - row * c4n;
             const int hy = row / IW, hx = row - hy * IW;
             const int iy = iy0 + hy, ix = ix0 + hx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < NPX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
                 v = *(const float4 *)(xf + ((size_t)iy * W + ix) * Cin + c4 * 4);
             *(float4 *)(Xs + row * XS + c4 * 4) = v;
         }
+        if (we_mine) *(float4 *)(Wes + we_row * XS + we_c4 * 4) = load_we(0);
+        if (wd_mine) *(float4 *)(Wds + wd_t * 32 + wd_c4 * 4) = load_wd(0);
     }
     __syncthreads();
     f32x16 acc[2];
@@ -943,35 +1073,51 @@ __global__ __launch_bounds__(256) void k_irb(const float *__restrict__ X, int H,
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-    const int nchunks = (Ce + 31) >> 5;
-    const int pm = wave % MP, pn0 = wave / MP;
-    // which of this lane's 16 accumulator rows (per expand tile) are real in-image halo pixels:
-    // evaluated once, not per chunk (the epilogue is VALU-bound otherwise)
+    // project: the NOUT x CoutP output is MP x NT tiles of 32 x 32.  With four or more tiles every wave owns one
+    // or two of them over the whole contraction; with fewer (Cout <= 32) the waves also split each chunk's k range
+    // KS ways, keep partial accumulators, and the partials are summed in a fixed order in the epilogue -- otherwise
+    // two or three of the four SIMDs would idle through half of the block's MFMA work.
+    const int NT = CoutP >> 5, ptiles = MP * NT;
+    const int KS = ptiles >= 4 ? 1 : 4 / ptiles, kw = 32 / KS;
+    const int t0 = KS > 1 ? wave % ptiles : wave, ks = KS > 1 ? wave / ptiles : 0;
+    // per expand tile of this wave: which of the lane's 16 accumulator rows are halo pixels at all (rmask)
+    // and which of those lie inside the image (vmask); evaluated once, not per chunk
     constexpr int MTW = (MT + 3) / 4;                     // expand tiles per wave
-    uint32_t vmask[MTW];
+    uint32_t vmask[MTW], rmask[MTW];
 #pragma unroll
     for (int u = 0; u < MTW; ++u) {
-        vmask[u] = 0;
-        const int mt = wave + 4 * u;
+        vmask[u] = 0; rmask[u] = 0;
+        const int mt = (MT == 5 && u == 1) ? 4 : wave + 4 * u;    // MT == 5: the odd tile rotates over the waves
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int rr = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
             const int hy = rr / IW, hx = rr - hy * IW;
-            if (mt < MT && rr < NPX && (unsigned)(iy0 + hy) < (unsigned)H && (unsigned)(ix0 + hx) < (unsigned)W)
-                vmask[u] |= 1u << i;
+            if (mt < MT && rr < NPX) {
+                rmask[u] |= 1u << i;
+                if ((unsigned)(iy0 + hy) < (unsigned)H && (unsigned)(ix0 + hx) < (unsigned)W) vmask[u] |= 1u << i;
+            }
         }
     }
     for (int ch = 0; ch < nchunks; ++ch) {
+        const int kend = min(32, Ce - ch * 32);
+        // requests for the slices needed one phase (Wp) or one chunk (We, Wd) from now
+        float4 s_wp[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_wp[q] = load_wp(ch, q);
+        const bool more = ch + 1 < nchunks;
+        const float4 s_we = more ? load_we(ch + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 s_wd = more ? load_wd(ch + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (EXPAND) {
 #pragma unroll
             for (int u = 0; u < MTW; ++u) {
-                const int mt = wave + 4 * u;
+                int mt = wave + 4 * u;
+                if (MT == 5 && u == 1) mt = (wave == (ch & 3)) ? 4 : MT;
                 if (mt >= MT) break;
                 f32x16 e;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) e[i] = 0.f;
                 const float *ap = Xs + (mt * 32 + r) * XS + 4 * hh;
-                const float *bq = We + (size_t)(ch * 32 + r) * Cin + 4 * hh;
+                const float *bq = Wes + r * XS + 4 * hh;
                 for (int k = 0; k < Cin; k += 8) {
                     const float4 a = *(const float4 *)(ap + k);
                     const float4 b = *(const float4 *)(bq + k);
@@ -983,13 +1129,20 @@ __global__ __launch_bounds__(256) void k_irb(const float *__restrict__ X, int H,
                 const int c = ch * 32 + r;
                 const float bv = c < Ce ? be[c] : 0.f;      // rows of We beyond Ce are zero, so e + bv = 0 there
                 float *ep = E + (mt * 32 + 4 * hh) * IRB_ES + r;
-                const uint32_t vm = vmask[u];
+                const uint32_t vm = vmask[u], rm = rmask[u];
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    ep[((i & 3) + 8 * (i >> 2)) * IRB_ES] = ((vm >> i) & 1u) ? fminf(fmaxf(e[i] + bv, 0.f), 6.f) : 0.f;
+                    if ((rm >> i) & 1u)
+                        ep[((i & 3) + 8 * (i >> 2)) * IRB_ES] = ((vm >> i) & 1u) ? fminf(fmaxf(e[i] + bv, 0.f), 6.f) : 0.f;
             }
-            __syncthreads();
+            __syncthreads();                                // barrier 1: E complete; expand(ch), project(ch-1) retired
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + q * 256;
+            if (q < wp_n && (idx >> 3) < CoutP) *(float4 *)(Wps + (idx >> 3) * IRB_ES + (idx & 7) * 4) = s_wp[q];
+        }
+        if (we_mine && more) *(float4 *)(Wes + we_row * XS + we_c4 * 4) = s_we;
         // depthwise 3x3 on the chunk: one thread = one output pixel x 4 channels
         for (int idx = tid; idx < NOUT * 8; idx += 256) {
             const int px = idx >> 3, c4 = idx & 7;
@@ -1003,7 +1156,7 @@ __global__ __launch_bounds__(256) void k_irb(const float *__restrict__ X, int H,
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const float4 x = *(const float4 *)(E + ((oy * S + ky) * IW + ox * S + kx) * IRB_ES + c4 * 4);
-                        const float4 w = *(const float4 *)(Wd + (size_t)(ky * 3 + kx) * Ce + c);
+                        const float4 w = *(const float4 *)(Wds + (ky * 3 + kx) * 32 + c4 * 4);
                         a4.x = fmaf(x.x, w.x, a4.x);
                         a4.y = fmaf(x.y, w.y, a4.y);
                         a4.z = fmaf(x.z, w.z, a4.z);
@@ -1017,16 +1170,18 @@ __global__ __launch_bounds__(256) void k_irb(const float *__restrict__ X, int H,
             }
             *(float4 *)(D + px * IRB_ES + c4 * 4) = o;
         }
-        __syncthreads();
-        // project: acc[pm rows][n tile] += D . Wp^T over this chunk's channels
-        const int kend = min(32, Ce - ch * 32);
+        __syncthreads();                                    // barrier 2: D and the Wp slice complete; depthwise(ch) retired
+        if (wd_mine && more) *(float4 *)(Wds + wd_t * 32 + wd_c4 * 4) = s_wd;
+        // project: acc[tile] += D . Wp^T over this wave's share of the chunk's channels
+        const int k_lo = ks * kw, k_hi = min(kend, k_lo + kw);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int nt = pn0 + j * NG;
-            if (nt * 32 < CoutP) {
+            const int tile = t0 + 4 * j;
+            if (tile < ptiles && (j == 0 || KS == 1)) {
+                const int pm = tile % MP, nt = tile / MP;
                 const float *ap = D + (pm * 32 + r) * IRB_ES + 4 * hh;
-                const float *bq = Wp + (size_t)(nt * 32 + r) * Ce + ch * 32 + 4 * hh;
-                for (int k = 0; k < kend; k += 8) {
+                const float *bq = Wps + (nt * 32 + r) * IRB_ES + 4 * hh;
+                for (int k = k_lo; k < k_hi; k += 8) {
                     const float4 a = *(const float4 *)(ap + k);
                     const float4 b = *(const float4 *)(bq + k);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[j], 0, 0, 0);
@@ -1038,10 +1193,47 @@ __global__ __launch_bounds__(256) void k_irb(const float *__restrict__ X, int H,
         }
         if (!EXPAND) __syncthreads();
     }
+    if (KS > 1) {
+        // k-split partials -> LDS (over the dead Xs / E arrays), summed in split order; then bias (+ residual),
+        // one float4 of channels per thread
+        const int PS = CoutP + 4;
+        float *Pp = sm_irb;                                 // [KS][NOUT][PS]
+        __syncthreads();
+        {
+            const int pm = t0 % MP, nt = t0 / MP;
+            float *pp = Pp + ((size_t)ks * NOUT + pm * 32 + 4 * hh) * PS + nt * 32 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pp[((i & 3) + 8 * (i >> 2)) * PS] = acc[0][i];
+        }
+        __syncthreads();
+        const int c4o = CoutP >> 2;
+        for (int idx = tid; idx < NOUT * c4o; idx += 256) {
+            const int px = idx / c4o, col = (idx - px * c4o) * 4;
+            const int oy = oy0 + px / TOW, ox = ox0 + px % TOW;
+            if (col >= Cout || oy >= OH || ox >= OW) continue;
+            float4 v = *(const float4 *)(Pp + (size_t)px * PS + col);
+            for (int q = 1; q < KS; ++q) {
+                const float4 t = *(const float4 *)(Pp + ((size_t)q * NOUT + px) * PS + col);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            const float4 b = *(const float4 *)(bp + col);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            const size_t pix = ((size_t)f * OH + oy) * OW + ox;
+            if (R) {
+                const float4 rv = *(const float4 *)(R + pix * Cout + col);
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            }
+            *(float4 *)(Y + pix * ldy + col) = v;
+        }
+        return;
+    }
     // epilogue: bias (+ residual) and store
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int col = (pn0 + j * NG) * 32 + r;
+        const int tile = t0 + 4 * j;
+        if (tile >= ptiles) continue;
+        const int pm = tile % MP, nt = tile / MP;
+        const int col = nt * 32 + r;
         if (col >= Cout) continue;
         const float bv = bp[col];
 #pragma unroll
@@ -1072,9 +1264,8 @@ static int launch_irb(SvcHandle *h, hipStream_t s, const float *X, int n, int H,
     }
 #define IRB_LAUNCH(S_, TOH_, TOW_, EXP_)                                                                             \
     do {                                                                                                             \
-        constexpr int IH = (TOH_ - 1) * S_ + 3, IW = (TOW_ - 1) * S_ + 3, MROWS = (IH * IW + 31) / 32 * 32;           \
         const int tx = ceil_div(OW, TOW_), ty = ceil_div(OH, TOH_);                                                  \
-        const size_t lds = ((size_t)MROWS * (Cin + 4) + (EXP_ ? (size_t)MROWS * IRB_ES : 0) + (size_t)TOH_ * TOW_ * IRB_ES) * 4; \
+        const size_t lds = IrbGeom<S_, TOH_, TOW_>::lds_floats(Cin, CoutP, EXP_) * 4;                                \
         k_irb<S_, TOH_, TOW_, EXP_><<<dim3((unsigned)(n * tx * ty)), 256, lds, s>>>(                                  \
             X, H, W, Cin, EXP_ ? Le->w.dev : nullptr, EXP_ ? Le->b.dev : nullptr, Ce, Ld.w.dev, Ld.b.dev, Lp.w.dev,   \
             Lp.b.dev, Cout, CoutP, R, Y, Cout, OH, OW, tx, ty);                                                      \
@@ -1324,6 +1515,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->pw16 = atoi(env) != 0;
     env = getenv("SVC_FUSE_MAX");
     if (env) h->fuse_max = std::min(13, std::max(0, atoi(env)));
+    env = getenv("SVC_DW_TILE");
+    if (env) h->dw_tile = atoi(env);
     env = getenv("SVC_PRIM_PT");
     if (env && atoi(env) > 0) h->prim_pt = atoi(env);
     int rc = h->blob.ensure(n_bytes);

@@ -973,6 +973,162 @@ static int launch_dw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer
 }
 
 // --------------------------------------------------------------------------------------
+// Depthwise 3x3 (+BN+ReLU6) fused into the 1x1 project that follows it (the second half of an
+// inverted-residual block, MobileNetV2.py:48-55,66-73, and of the three decoder blocks).  The
+// depthwise output -- as large as the 6x expanded tensor -- never reaches memory.
+//
+// One workgroup = one patch of 32 pixels (PW x 32/PW) of one frame x NT*32 output channels.  Its four
+// waves split the K (channel) range in 32-channel chunks, chunk c -> wave c % 4, and each wave works
+// alone, without barriers: it computes the depthwise output of its chunk for the 32 pixels (a lane owns
+// 4 consecutive pixels x 4 channels: 18 tap loads + 9 weights for 4 outputs, like k_dw_tile), parks the
+// 32 x 32 tile in its private LDS slab in MFMA A layout, and multiplies it with the chunk's slice of the
+// project weights (B straight from global/L2) into NT accumulators.  The four partial sums meet in LDS at
+// the end and are added in wave order, so the result is deterministic and independent of the batch.
+// --------------------------------------------------------------------------------------
+#define IRB_ES 36      // LDS row stride (floats) of 32-channel tiles: 32 + 4 pad (conflict-free float4 rows)
+
+template <int NT, int PW, int NWV>     // NWV = waves per workgroup = ways of the K split (8 was measured: no gain)
+__global__ __launch_bounds__(64 * NWV) void k_dwpw(const float *__restrict__ X, int H, int W, int C,
+                                              const float *__restrict__ Wd, const float *__restrict__ bd,
+                                              const float *__restrict__ Wp, const float *__restrict__ bp, int N,
+                                              int Npad, const float *__restrict__ R, int ldr, float *__restrict__ Y,
+                                              int ldy, int relu6, int tiles_x, int tiles_y) {
+    constexpr int PH = 32 / PW;
+    __shared__ float Dw[NWV][32 * IRB_ES];
+    __shared__ float red[NWV][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y, f = bid / tiles_y;
+    const int x0 = tx * PW, y0 = ty * PH, n0 = blockIdx.y * (NT * 32);
+    // depthwise role of the lane: channel group c4 of the chunk, pixels p0 .. p0+3 of the patch (one row)
+    const int c4 = lane & 7, p0 = (lane >> 3) * 4;
+    const int py = p0 / PW, pxs = p0 % PW;
+    const int oy = y0 + py, ox0 = x0 + pxs;
+    const float *xf = X + (size_t)f * H * W * C;
+    float *D = Dw[wave];
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    const int nchunks = (C + 31) >> 5;
+    for (int ch = wave; ch < nchunks; ch += NWV) {
+        const int c = ch * 32 + c4 * 4;
+        float4 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C) {
+            float4 w[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) w[t] = *(const float4 *)(Wd + (size_t)t * C + c);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy - 1 + ky;
+                if (iy < 0 || iy >= H) continue;
+                float4 row[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int ix = ox0 - 1 + j;
+                    row[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ix >= 0 && ix < W) row[j] = *(const float4 *)(xf + ((size_t)iy * W + ix) * C + c);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float4 x = row[j + kx], ww = w[ky * 3 + kx];
+                        o[j].x = fmaf(x.x, ww.x, o[j].x);
+                        o[j].y = fmaf(x.y, ww.y, o[j].y);
+                        o[j].z = fmaf(x.z, ww.z, o[j].z);
+                        o[j].w = fmaf(x.w, ww.w, o[j].w);
+                    }
+            }
+            const float4 b = *(const float4 *)(bd + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j].x = fminf(fmaxf(o[j].x + b.x, 0.f), 6.f);
+                o[j].y = fminf(fmaxf(o[j].y + b.y, 0.f), 6.f);
+                o[j].z = fminf(fmaxf(o[j].z + b.z, 0.f), 6.f);
+                o[j].w = fminf(fmaxf(o[j].w + b.w, 0.f), 6.f);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(float4 *)(D + (p0 + j) * IRB_ES + c4 * 4) = o[j];
+        // the slab is private to the wave: its own LDS writes are visible to it once they have completed
+        __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        const int kend = min(32, C - ch * 32);
+        const float *ap = D + r * IRB_ES + 4 * hh;
+        for (int k = 0; k < kend; k += 8) {
+            const float4 a = *(const float4 *)(ap + k);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float4 b = *(const float4 *)(Wp + (size_t)min(n0 + t * 32 + r, Npad - 1) * C + ch * 32 + 4 * hh + k);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                    // the next chunk overwrites the slab
+    }
+    // sum of the NWV K partials (wave order), bias, residual, store: wave w finishes 16/NWV accumulator rows
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[t][i];
+        __syncthreads();
+        const int col = n0 + t * 32 + r;
+        if (col >= N) continue;
+        const float bv = bp[col];
+#pragma unroll
+        for (int ii = 0; ii < 16 / NWV; ++ii) {
+            const int i = (16 / NWV) * wave + ii;
+            const int p = (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const int yy = y0 + p / PW, xx = x0 + p % PW;
+            if (yy < H && xx < W) {
+                const size_t pix = ((size_t)f * H + yy) * W + xx;
+                float v = red[0][i][lane];
+#pragma unroll
+                for (int q = 1; q < NWV; ++q) v += red[q][i][lane];
+                v += bv;
+                if (R) v += R[pix * ldr + col];
+                if (relu6) v = fminf(fmaxf(v, 0.f), 6.f);
+                Y[pix * ldy + col] = v;
+            }
+        }
+    }
+}
+
+static int launch_dwpw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer &Ld, const SvcLayer &Lp, const float *R,
+                       int ldr, float *Y, int ldy, int n, int H, int W) {
+    ProfScope ps(h, SVC_K_PW, s);
+    const int C = Ld.cout, N = Lp.cout, Npad = (N + 31) / 32 * 32, tiles = Npad / 32;
+    // output-channel groups of at most 5 tiles, as even as possible (the depthwise part is redone per group)
+    const int groups = ceil_div(tiles, 5), nt = ceil_div(tiles, groups);
+    const int pw = (W % 8 == 0 || W > 16) ? 8 : 16;          // 8x4 patches; 16x2 on the narrow 13-wide level
+    const int tx = ceil_div(W, pw), ty = ceil_div(H, 32 / pw);
+    dim3 grid((unsigned)(n * tx * ty), groups);
+#define DWPW_ARGS X, H, W, C, Ld.w.dev, Ld.b.dev, Lp.w.dev, Lp.b.dev, N, Npad, R, ldr, Y, ldy, Lp.relu6, tx, ty
+#define DWPW_CASE(NTv)                                                                    \
+    case NTv:                                                                             \
+        if (pw == 8) k_dwpw<NTv, 8, 4><<<grid, 256, 0, s>>>(DWPW_ARGS);                   \
+        else k_dwpw<NTv, 16, 4><<<grid, 256, 0, s>>>(DWPW_ARGS);                          \
+        break
+    switch (nt) {
+        DWPW_CASE(1); DWPW_CASE(2); DWPW_CASE(3); DWPW_CASE(4);
+        default: DWPW_CASE(5);
+    }
+#undef DWPW_CASE
+#undef DWPW_ARGS
+    SVC_CHECK_LAUNCH();
+    return SVC_OK;
+}
+
+// --------------------------------------------------------------------------------------
 // Fused inverted-residual block (MobileNetV2.py:26-83): 1x1 expand + ReLU6 -> 3x3 depthwise
 // + ReLU6 -> 1x1 project (+ residual) for one tile of TOH x TOW output pixels.  The 6x
 // expanded tensor and the depthwise output never leave the CU: per 32-channel chunk of the
@@ -991,7 +1147,6 @@ static int launch_dw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer
 //   Wd[ch+1]          requested before expand(ch), stored after barrier 2 (readers: depthwise(ch))
 // so no MFMA k step or depthwise tap ever waits on an L2 round trip, and the register cost is 4 float4.
 // --------------------------------------------------------------------------------------
-#define IRB_ES 36      // LDS row stride (floats) of E, D and the Wp slice: 32 channels + 4 pad (conflict-free float4 rows)
 
 template <int S, int TOH, int TOW>
 struct IrbGeom {
@@ -1334,8 +1489,12 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
                     dwin = E0;
                 }
                 const SvcLayer &Ld = next();
-                RC(launch_dw(h, s, dwin, Ld, E1, n, H, W, dws));
-                RC(launch_pw(h, s, E1, inp * t, next(), res ? x : nullptr, oup, y, oup, n * OH * OW, n));
+                if (h->dwpw && dws == 1 && H * W >= h->dwpw_min_px) {
+                    RC(launch_dwpw(h, s, dwin, Ld, next(), res ? x : nullptr, oup, y, oup, n, H, W));
+                } else {
+                    RC(launch_dw(h, s, dwin, Ld, E1, n, H, W, dws));
+                    RC(launch_pw(h, s, E1, inp * t, next(), res ? x : nullptr, oup, y, oup, n * OH * OW, n));
+                }
             }
             if (tap) {
                 ProfScope ps(h, SVC_K_RESAMPLE, s);
@@ -1366,8 +1525,13 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
         SVC_CHECK_LAUNCH();
     }
     // post_cnn
-    RC(launch_dw(h, s, CAT1, next(), p->buf(B_PCD), n, H5, W5, 1));
-    RC(launch_pw(h, s, p->buf(B_PCD), 1296, next(), nullptr, 0, p->buf(B_PC), 256, n * H5 * W5, n));
+    if (h->dwpw && H5 * W5 >= h->dwpw_min_px) {
+        const SvcLayer &Ld = next();
+        RC(launch_dwpw(h, s, CAT1, Ld, next(), nullptr, 0, p->buf(B_PC), 256, n, H5, W5));
+    } else {
+        RC(launch_dw(h, s, CAT1, next(), p->buf(B_PCD), n, H5, W5, 1));
+        RC(launch_pw(h, s, p->buf(B_PCD), 1296, next(), nullptr, 0, p->buf(B_PC), 256, n * H5 * W5, n));
+    }
     // US1 + concat, US2 block
     {
         ProfScope ps(h, SVC_K_RESAMPLE, s);
@@ -1376,8 +1540,13 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
         SVC_CHECK_LAUNCH();
     }
     RC(launch_pw(h, s, CAT2, 384, next(), nullptr, 0, p->buf(B_U2E), 768, n * H4 * W4, n));
-    RC(launch_dw(h, s, p->buf(B_U2E), next(), p->buf(B_U2D), n, H4, W4, 1));
-    RC(launch_pw(h, s, p->buf(B_U2D), 768, next(), nullptr, 0, p->buf(B_U2), 128, n * H4 * W4, n));
+    if (h->dwpw) {
+        const SvcLayer &Ld = next();
+        RC(launch_dwpw(h, s, p->buf(B_U2E), Ld, next(), nullptr, 0, p->buf(B_U2), 128, n, H4, W4));
+    } else {
+        RC(launch_dw(h, s, p->buf(B_U2E), next(), p->buf(B_U2D), n, H4, W4, 1));
+        RC(launch_pw(h, s, p->buf(B_U2D), 768, next(), nullptr, 0, p->buf(B_U2), 128, n * H4 * W4, n));
+    }
     {
         ProfScope ps(h, SVC_K_RESAMPLE, s);
         k_upsample2x<<<blocks256((size_t)n * H3 * W3 * 32), 256, 0, s>>>(p->buf(B_U2), CAT3, n, H4, W4, 128, 192, make_fdiv(32),
@@ -1385,8 +1554,13 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
         SVC_CHECK_LAUNCH();
     }
     RC(launch_pw(h, s, CAT3, 192, next(), nullptr, 0, p->buf(B_P3E), 384, n * H3 * W3, n));
-    RC(launch_dw(h, s, p->buf(B_P3E), next(), p->buf(B_P3D), n, H3, W3, 1));
-    RC(launch_pw(h, s, p->buf(B_P3D), 384, next(), nullptr, 0, p->buf(B_DEC), 64, n * H3 * W3, n));
+    if (h->dwpw) {
+        const SvcLayer &Ld = next();
+        RC(launch_dwpw(h, s, p->buf(B_P3E), Ld, next(), nullptr, 0, p->buf(B_DEC), 64, n, H3, W3));
+    } else {
+        RC(launch_dw(h, s, p->buf(B_P3E), next(), p->buf(B_P3D), n, H3, W3, 1));
+        RC(launch_pw(h, s, p->buf(B_P3D), 384, next(), nullptr, 0, p->buf(B_DEC), 64, n * H3 * W3, n));
+    }
     // adaptation, smoothing, resize, quantise
     const SvcLayer &La = next();
     {
@@ -1515,6 +1689,10 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->pw16 = atoi(env) != 0;
     env = getenv("SVC_FUSE_MAX");
     if (env) h->fuse_max = std::min(13, std::max(0, atoi(env)));
+    env = getenv("SVC_DWPW");
+    if (env) h->dwpw = atoi(env) != 0;
+    env = getenv("SVC_DWPW_MIN_PX");
+    if (env) h->dwpw_min_px = atoi(env);
     env = getenv("SVC_DW_TILE");
     if (env) h->dw_tile = atoi(env);
     env = getenv("SVC_PRIM_PT");

@@ -1190,13 +1190,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     const int c4n = Cin >> 2;
     const int nchunks = (Ce + 31) >> 5;
     // weight slices as seen by this thread (one float4 each; the project slice has CoutP*8 float4 <= 4 per thread)
-    const int we_row = tid / c4n, we_c4 = tid - we_row * c4n;             // valid for tid < 32 * c4n
-    const bool we_mine = EXPAND && tid < 32 * c4n;
+    const int we_n = EXPAND ? (32 * c4n + 255) >> 8 : 0;                    // float4 per thread in the expand slice (<= 3: Cin <= 96)
     const bool wd_mine = tid < 72;
     const int wd_t = tid >> 3, wd_c4 = tid & 7;
     const int wp_n = (CoutP * 8 + 255) >> 8;                                // float4 per thread in the project slice
-    auto load_we = [&](int ch) -> float4 {
-        return we_mine ? *(const float4 *)(We + (size_t)(ch * 32 + we_row) * Cin + we_c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_we = [&](int ch, int q) -> float4 {
+        const int idx = tid + q * 256;                       // the slice is 32 rows x Cin floats, contiguous in We
+        return (q < we_n && idx < 32 * c4n) ? *(const float4 *)(We + (size_t)ch * 32 * Cin + (size_t)idx * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_we = [&](int q, float4 v) {
+        const int idx = tid + q * 256;
+        if (q < we_n && idx < 32 * c4n) {
+            const int row = idx / c4n, c4 = idx - row * c4n;
+            *(float4 *)(Wes + row * XS + c4 * 4) = v;
+        }
     };
     auto load_wd = [&](int ch) -> float4 {
         const int c = ch * 32 + wd_c4 * 4;
@@ -1219,7 +1226,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 v = *(const float4 *)(xf + ((size_t)iy * W + ix) * Cin + c4 * 4);
             *(float4 *)(Xs + row * XS + c4 * 4) = v;
         }
-        if (we_mine) *(float4 *)(Wes + we_row * XS + we_c4 * 4) = load_we(0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) store_we(q, load_we(0, q));
         if (wd_mine) *(float4 *)(Wds + wd_t * 32 + wd_c4 * 4) = load_wd(0);
     }
     __syncthreads();
@@ -1260,7 +1268,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 #pragma unroll
         for (int q = 0; q < 4; ++q) s_wp[q] = load_wp(ch, q);
         const bool more = ch + 1 < nchunks;
-        const float4 s_we = more ? load_we(ch + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 s_we[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) s_we[q] = more ? load_we(ch + 1, q) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 s_wd = more ? load_wd(ch + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (EXPAND) {
 #pragma unroll
@@ -1297,7 +1307,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             const int idx = tid + q * 256;
             if (q < wp_n && (idx >> 3) < CoutP) *(float4 *)(Wps + (idx >> 3) * IRB_ES + (idx & 7) * 4) = s_wp[q];
         }
-        if (we_mine && more) *(float4 *)(Wes + we_row * XS + we_c4 * 4) = s_we;
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) store_we(q, s_we[q]);
+        }
         // depthwise 3x3 on the chunk: one thread = one output pixel x 4 channels
         for (int idx = tid; idx < NOUT * 8; idx += 256) {
             const int px = idx >> 3, c4 = idx & 7;

@@ -90,6 +90,43 @@ def test_saliency_batch_and_chunk_independence(engine):
     assert torch.equal(engine.saliency(fr[33:40]), full[33:40])
 
 
+@pytest.mark.parametrize('knobs', [
+    {'SVC_FUSE_MAX': '0'},                                  # no fused inverted-residual blocks: k_pw / k_dw* / k_pw only
+    {'SVC_DWPW': '0'},                                      # depthwise and project as two kernels
+    {'SVC_DWPW': '0', 'SVC_DW_TILE': '0'},                  # ... with the one-output-per-thread depthwise
+    {'SVC_DWPW_MIN_PX': '1'},                               # fused depthwise+project on the 8x13 level too
+    {'SVC_PW_SK': '0', 'SVC_PW16': '0'},                    # no split-K, no 16x16x4 pointwise form
+    {'SVC_FUSE_MAX': '13'},                                 # every block that can be fused is
+    {'SVC_CHUNK': '5'},                                     # ragged chunks of the batch
+])
+def test_saliency_kernel_families_agree(engine, synthetic_sd, knobs):
+    """Every kernel family that can serve a layer (selected by shape at run time, forced here through
+    the tuning knobs) must produce the same network output within the fp32 tolerance."""
+    fr = torch.from_numpy(synth.blob_frames(7, 140, 250, seed=21)).cuda()
+    ref_maps = engine.saliency(fr).cpu().numpy()
+    ref_dec = engine.tap(ops.TAP_DEC, 3, (32, 52, 64))
+    old = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        other = ops.Engine(synthetic_sd)                     # the knobs are read when the handle is created
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        maps = other.saliency(fr).cpu().numpy()
+        # taps address a frame of the last chunk, so they are only comparable when the batch is one chunk
+        dec = other.tap(ops.TAP_DEC, 3, (32, 52, 64)) if 'SVC_CHUNK' not in knobs else None
+    finally:
+        other.close()
+    if dec is not None:
+        assert np.abs(dec - ref_dec).max() <= 2e-4 * np.abs(ref_dec).max()
+    d = np.abs(maps.astype(int) - ref_maps.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
 def test_tail_bit_exact_default_settings(engine, golden_dir):
     CP = P.init_crop_params()
     g = np.load(os.path.join(golden_dir, 'unisal_golden.npz'))

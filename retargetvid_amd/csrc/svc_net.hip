@@ -1163,13 +1163,14 @@ struct IrbGeom {
     }
 };
 
-template <int S, int TOH, int TOW, bool EXPAND>
+template <int S, int TOH, int TOW, bool EXPAND, bool STEM = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_irb(const float *__restrict__ X, int H, int W, int Cin,
                                              const float *__restrict__ We, const float *__restrict__ be, int Ce,
                                              const float *__restrict__ Wd, const float *__restrict__ bd,
                                              const float *__restrict__ Wp, const float *__restrict__ bp, int Cout,
                                              int CoutP, const float *__restrict__ R, float *__restrict__ Y, int ldy,
-                                             int OH, int OW, int tiles_x, int tiles_y) {
+                                             int OH, int OW, int tiles_x, int tiles_y,
+                                             const float *__restrict__ Ws, const float *__restrict__ bs) {
     using G = IrbGeom<S, TOH, TOW>;
     constexpr int IW = G::IW, NPX = G::NPX, MT = G::MT;
     constexpr int NOUT = G::NOUT, MP = NOUT / 32;
@@ -1214,8 +1215,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         const int k = ch * 32 + k4 * 4;
         return (q < wp_n && row < CoutP && k < Ce) ? *(const float4 *)(Wp + (size_t)row * Ce + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    // 1. input halo and the first weight slices -> LDS (zeros outside the image)
-    {
+    if constexpr (STEM) {
+        // features.0 fused in (t = 1 block only): X is the network input [2H][2W][3]; the 3x3 stride-2 stem
+        // conv of the halo tile runs here as one 32x32x32 MFMA tile per wave (K = 27 taps, zero-padded to 32)
+        // and its ReLU6 output is what the block would otherwise have read back from memory.  Scratch lives
+        // in arrays that are not yet in use: the input patch in D, the stem weights in the Wp slice, the
+        // im2col rows in E itself (a wave overwrites only the rows its own MFMA has consumed).
+        constexpr int PR = 2 * G::IH + 1, PCW = 2 * IW + 1, PRS = 64;      // patch rows, pixel columns, row stride
+        static_assert(PCW * 3 <= PRS && PR * PRS <= NOUT * IRB_ES, "stem patch must fit the D array");
+        float *Pin = D, *Bs = Wps;
+        const int HI = 2 * H, WI = 2 * W, py0 = 2 * iy0 - 1, px0 = 2 * ix0 - 1;
+        const float *xin = X + (size_t)f * HI * WI * 3;
+        for (int idx = tid; idx < PR * PCW * 3; idx += 256) {
+            const int pr = idx / (PCW * 3), rem = idx - pr * (PCW * 3), pc = rem / 3;
+            const int y = py0 + pr, x = px0 + pc;
+            float v = 0.f;
+            if ((unsigned)y < (unsigned)HI && (unsigned)x < (unsigned)WI) v = xin[((long long)y * WI + px0) * 3 + rem];
+            Pin[pr * PRS + rem] = v;
+        }
+        for (int idx = tid; idx < 32 * 32; idx += 256) {
+            const int co = idx >> 5, k = idx & 31;
+            Bs[co * IRB_ES + k] = k < 27 ? Ws[k * 32 + co] : 0.f;
+        }
+        if (wd_mine) *(float4 *)(Wds + wd_t * 32 + wd_c4 * 4) = load_wd(0);
+        __syncthreads();
+        {   // im2col: thread = fixed tap k (column of A), pixels tid/32, tid/32 + 8, ...
+            const int k = tid & 31, t = k / 3, ci = k - 3 * t, ky = t / 3, kx = t - 3 * ky;
+            const float *src = Pin + ky * PRS + kx * 3 + ci;
+            for (int px = tid >> 5; px < NPX; px += 8) {
+                const int hy = px / IW, hx = px - hy * IW;
+                E[px * IRB_ES + k] = k < 27 ? src[hy * (2 * PRS) + hx * 6] : 0.f;
+            }
+        }
+        __syncthreads();
+        f32x16 e;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) e[i] = 0.f;
+        const float *ap = E + (wave * 32 + r) * IRB_ES + 4 * hh;
+        const float *bq = Bs + r * IRB_ES + 4 * hh;
+#pragma unroll
+        for (int k = 0; k < 32; k += 8) {
+            const float4 a = *(const float4 *)(ap + k);
+            const float4 b = *(const float4 *)(bq + k);
+            e = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, e, 0, 0, 0);
+            e = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, e, 0, 0, 0);
+            e = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, e, 0, 0, 0);
+            e = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, e, 0, 0, 0);
+        }
+        const float bv = bs[r];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rr = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const int hy = rr / IW, hx = rr - hy * IW;
+            if (rr < NPX) {
+                const bool in = (unsigned)(iy0 + hy) < (unsigned)H && (unsigned)(ix0 + hx) < (unsigned)W;
+                E[rr * IRB_ES + r] = in ? fminf(fmaxf(e[i] + bv, 0.f), 6.f) : 0.f;
+            }
+        }
+    } else {
+        // 1. input halo and the first weight slices -> LDS (zeros outside the image)
         const float *xf = X + (size_t)f * H * W * Cin;
         for (int idx = tid; idx < NPX * c4n; idx += 256) {
             const int row = idx / c4n, c4 = idx - row * c4n;
@@ -1419,7 +1477,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 }
 
 static int launch_irb(SvcHandle *h, hipStream_t s, const float *X, int n, int H, int W, int Cin, const SvcLayer *Le,
-                      const SvcLayer &Ld, const SvcLayer &Lp, int stride, const float *R, float *Y) {
+                      const SvcLayer &Ld, const SvcLayer &Lp, int stride, const float *R, float *Y,
+                      const SvcLayer *Lstem = nullptr) {
     ProfScope ps(h, SVC_K_PW, s);
     const int Ce = Ld.cout, Cout = Lp.cout, CoutP = (Cout + 31) / 32 * 32;
     const int OH = H / stride, OW = W / stride;
@@ -1428,20 +1487,25 @@ static int launch_irb(SvcHandle *h, hipStream_t s, const float *X, int n, int H,
         SVC_HIP(hipFuncSetAttribute((const void *)k_irb<1, 8, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_irb<2, 4, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_irb<1, 8, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_irb<1, 8, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
         attr_done = true;
     }
-#define IRB_LAUNCH(S_, TOH_, TOW_, EXP_)                                                                             \
+#define IRB_LAUNCH(S_, TOH_, TOW_, EXP_) IRB_LAUNCH2(S_, TOH_, TOW_, EXP_, false)
+#define IRB_LAUNCH2(S_, TOH_, TOW_, EXP_, STEM_)                                                                     \
     do {                                                                                                             \
         const int tx = ceil_div(OW, TOW_), ty = ceil_div(OH, TOH_);                                                  \
         const size_t lds = IrbGeom<S_, TOH_, TOW_>::lds_floats(Cin, CoutP, EXP_) * 4;                                \
-        k_irb<S_, TOH_, TOW_, EXP_><<<dim3((unsigned)(n * tx * ty)), 256, lds, s>>>(                                  \
+        k_irb<S_, TOH_, TOW_, EXP_, STEM_><<<dim3((unsigned)(n * tx * ty)), 256, lds, s>>>(                           \
             X, H, W, Cin, EXP_ ? Le->w.dev : nullptr, EXP_ ? Le->b.dev : nullptr, Ce, Ld.w.dev, Ld.b.dev, Lp.w.dev,   \
-            Lp.b.dev, Cout, CoutP, R, Y, Cout, OH, OW, tx, ty);                                                      \
+            Lp.b.dev, Cout, CoutP, R, Y, Cout, OH, OW, tx, ty, STEM_ ? Lstem->w.dev : nullptr,                       \
+            STEM_ ? Lstem->b.dev : nullptr);                                                                         \
     } while (0)
-    if (!Le) IRB_LAUNCH(1, 8, 8, false);
+    if (!Le && Lstem) IRB_LAUNCH2(1, 8, 8, false, true);
+    else if (!Le) IRB_LAUNCH(1, 8, 8, false);
     else if (stride == 2) IRB_LAUNCH(2, 4, 8, true);
     else IRB_LAUNCH(1, 8, 8, true);
 #undef IRB_LAUNCH
+#undef IRB_LAUNCH2
     SVC_CHECK_LAUNCH();
     return SVC_OK;
 }
@@ -1467,12 +1531,13 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
                                              (const float *)p->lut.p, p->lz_rows, p->lz_tile_cap);
         SVC_CHECK_LAUNCH();
     }
-    // stem
-    {
+    // stem: on its own, or inside the kernel of backbone block 1 (which then reads the network input directly)
+    const SvcLayer &Lstem = next();
+    const bool stem_fused = h->stem_fused && h->fuse_max >= 1;
+    if (!stem_fused) {
         ProfScope ps(h, SVC_K_STEM, s);
-        const SvcLayer &L = next();
-        k_stem<<<blocks256((size_t)n * H * W * 8), 256, 0, s>>>(IN, L.w.dev, L.b.dev, P[0], n, NH, NW, H, W, make_fdiv(W),
-                                                                make_fdiv(H));
+        k_stem<<<blocks256((size_t)n * H * W * 8), 256, 0, s>>>(IN, Lstem.w.dev, Lstem.b.dev, P[0], n, NH, NW, H, W,
+                                                                make_fdiv(W), make_fdiv(H));
         SVC_CHECK_LAUNCH();
     }
     int cur = 0;
@@ -1494,7 +1559,9 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
                 const SvcLayer *Le = (t != 1) ? &next() : nullptr;
                 const SvcLayer &Ld = next();
                 const SvcLayer &Lp = next();
-                RC(launch_irb(h, s, x, n, H, W, inp, Le, Ld, Lp, dws, res ? x : nullptr, y));
+                const bool with_stem = stem_fused && idx == 1;
+                RC(launch_irb(h, s, with_stem ? IN : x, n, H, W, inp, Le, Ld, Lp, dws, res ? x : nullptr, y,
+                              with_stem ? &Lstem : nullptr));
             } else {
                 const float *dwin = x;
                 if (t != 1) {
@@ -1702,6 +1769,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->pw16 = atoi(env) != 0;
     env = getenv("SVC_FUSE_MAX");
     if (env) h->fuse_max = std::min(13, std::max(0, atoi(env)));
+    env = getenv("SVC_STEM_FUSED");
+    if (env) h->stem_fused = atoi(env) != 0;
     env = getenv("SVC_DWPW");
     if (env) h->dwpw = atoi(env) != 0;
     env = getenv("SVC_DWPW_MIN_PX");

@@ -189,6 +189,17 @@ def test_tail_ragged_sizes_and_sparse_points(engine):
         _check_tail(engine, m, np.array([0, 1, 0], np.uint8), CP)
 
 
+def test_tail_maximum_size_all_pixels_set(engine):
+    """N = 35 000 points (every pixel above the threshold): the largest problem a 140x250 map can pose.
+    Takes the global-memory forms of Prim (N > 32 768) and of the hierarchy (N > 4 352), and every
+    mutual-reachability distance ties with its neighbours', so the Prim / sort tie rules decide the tree."""
+    CP = P.init_crop_params()
+    m = np.full((1, 140, 250), 200, np.uint8)
+    m[0, 40:60, 100:130] = 0                           # a hole and a shorter first row: N = 34 390
+    m[0, 0, 0:10] = 0
+    _check_tail(engine, m, None, CP)                   # (the O(N^2) oracle needs about a minute for this one map)
+
+
 def test_tail_batch_independence_at_full_size(engine):
     """Size-independent property at BASELINE config 2 (B=32, 640x360): every map's result is
     independent of the batch it is processed in, and filtering only ever removes/closes."""

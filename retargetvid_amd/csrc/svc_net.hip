@@ -1163,14 +1163,19 @@ struct IrbGeom {
     }
 };
 
-template <int S, int TOH, int TOW, bool EXPAND, bool STEM = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_irb(const float *__restrict__ X, int H, int W, int Cin,
-                                             const float *__restrict__ We, const float *__restrict__ be, int Ce,
+// CIN / CE / COUT > 0 fix the channel counts at compile time (the MobileNetV2 blocks this kernel serves have six
+// distinct shapes): strides, trip counts and the slice bookkeeping fold to constants, which matters because the
+// kernel is bound by instruction issue.  0 = take them from the arguments (any other shape).
+template <int S, int TOH, int TOW, bool EXPAND, bool STEM = false, int CIN = 0, int CE = 0, int COUT = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_irb(const float *__restrict__ X, int H, int W, int Cin_,
+                                             const float *__restrict__ We, const float *__restrict__ be, int Ce_,
                                              const float *__restrict__ Wd, const float *__restrict__ bd,
-                                             const float *__restrict__ Wp, const float *__restrict__ bp, int Cout,
-                                             int CoutP, const float *__restrict__ R, float *__restrict__ Y, int ldy,
+                                             const float *__restrict__ Wp, const float *__restrict__ bp, int Cout_,
+                                             int CoutP_, const float *__restrict__ R, float *__restrict__ Y, int ldy_,
                                              int OH, int OW, int tiles_x, int tiles_y,
                                              const float *__restrict__ Ws, const float *__restrict__ bs) {
+    const int Cin = CIN > 0 ? CIN : Cin_, Ce = CE > 0 ? CE : Ce_, Cout = COUT > 0 ? COUT : Cout_;
+    const int CoutP = COUT > 0 ? (COUT + 31) / 32 * 32 : CoutP_, ldy = COUT > 0 ? COUT : ldy_;
     using G = IrbGeom<S, TOH, TOW>;
     constexpr int IW = G::IW, NPX = G::NPX, MT = G::MT;
     constexpr int NOUT = G::NOUT, MP = NOUT / 32;
@@ -1482,30 +1487,37 @@ static int launch_irb(SvcHandle *h, hipStream_t s, const float *X, int n, int H,
     ProfScope ps(h, SVC_K_PW, s);
     const int Ce = Ld.cout, Cout = Lp.cout, CoutP = (Cout + 31) / 32 * 32;
     const int OH = H / stride, OW = W / stride;
-    static bool attr_done = false;
-    if (!attr_done) {        // tiles of the 96-channel blocks need more than the default 64 KB of dynamic LDS
-        SVC_HIP(hipFuncSetAttribute((const void *)k_irb<1, 8, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-        SVC_HIP(hipFuncSetAttribute((const void *)k_irb<2, 4, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-        SVC_HIP(hipFuncSetAttribute((const void *)k_irb<1, 8, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-        SVC_HIP(hipFuncSetAttribute((const void *)k_irb<1, 8, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-        attr_done = true;
-    }
-#define IRB_LAUNCH(S_, TOH_, TOW_, EXP_) IRB_LAUNCH2(S_, TOH_, TOW_, EXP_, false)
-#define IRB_LAUNCH2(S_, TOH_, TOW_, EXP_, STEM_)                                                                     \
+#define IRB_LAUNCH(S_, TOH_, TOW_, EXP_) IRB_LAUNCH3(S_, TOH_, TOW_, EXP_, false, 0, 0, 0)
+#define IRB_LAUNCH2(S_, TOH_, TOW_, EXP_, STEM_) IRB_LAUNCH3(S_, TOH_, TOW_, EXP_, STEM_, 0, 0, 0)
+#define IRB_LAUNCH3(S_, TOH_, TOW_, EXP_, STEM_, CI_, CE_, CO_)                                                      \
     do {                                                                                                             \
         const int tx = ceil_div(OW, TOW_), ty = ceil_div(OH, TOH_);                                                  \
         const size_t lds = IrbGeom<S_, TOH_, TOW_>::lds_floats(Cin, CoutP, EXP_) * 4;                                \
-        k_irb<S_, TOH_, TOW_, EXP_, STEM_><<<dim3((unsigned)(n * tx * ty)), 256, lds, s>>>(                           \
+        auto kfn = k_irb<S_, TOH_, TOW_, EXP_, STEM_, CI_, CE_, CO_>;                                                \
+        static bool attr = false;                                                                                    \
+        if (!attr) {         /* tiles of the 96-channel blocks need more than the default 64 KB of dynamic LDS */    \
+            SVC_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024)); \
+            attr = true;                                                                                             \
+        }                                                                                                            \
+        kfn<<<dim3((unsigned)(n * tx * ty)), 256, lds, s>>>(                                                          \
             X, H, W, Cin, EXP_ ? Le->w.dev : nullptr, EXP_ ? Le->b.dev : nullptr, Ce, Ld.w.dev, Ld.b.dev, Lp.w.dev,   \
             Lp.b.dev, Cout, CoutP, R, Y, Cout, OH, OW, tx, ty, STEM_ ? Lstem->w.dev : nullptr,                       \
             STEM_ ? Lstem->b.dev : nullptr);                                                                         \
     } while (0)
+    const bool fixed = h->irb_fixed;
     if (!Le && Lstem) IRB_LAUNCH2(1, 8, 8, false, true);
+    else if (!Le && fixed && Cin == 32 && Ce == 32 && Cout == 16) IRB_LAUNCH3(1, 8, 8, false, false, 32, 32, 16);
     else if (!Le) IRB_LAUNCH(1, 8, 8, false);
+    else if (stride == 2 && fixed && Cin == 16 && Ce == 96 && Cout == 24) IRB_LAUNCH3(2, 4, 8, true, false, 16, 96, 24);
+    else if (stride == 2 && fixed && Cin == 24 && Ce == 144 && Cout == 32) IRB_LAUNCH3(2, 4, 8, true, false, 24, 144, 32);
     else if (stride == 2) IRB_LAUNCH(2, 4, 8, true);
+    else if (fixed && Cin == 24 && Ce == 144 && Cout == 24) IRB_LAUNCH3(1, 8, 8, true, false, 24, 144, 24);
+    else if (fixed && Cin == 32 && Ce == 192 && Cout == 32) IRB_LAUNCH3(1, 8, 8, true, false, 32, 192, 32);
+    else if (fixed && Cin == 32 && Ce == 192 && Cout == 64) IRB_LAUNCH3(1, 8, 8, true, false, 32, 192, 64);
     else IRB_LAUNCH(1, 8, 8, true);
 #undef IRB_LAUNCH
 #undef IRB_LAUNCH2
+#undef IRB_LAUNCH3
     SVC_CHECK_LAUNCH();
     return SVC_OK;
 }
@@ -1769,6 +1781,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->pw16 = atoi(env) != 0;
     env = getenv("SVC_FUSE_MAX");
     if (env) h->fuse_max = std::min(13, std::max(0, atoi(env)));
+    env = getenv("SVC_IRB_FIXED");
+    if (env) h->irb_fixed = atoi(env) != 0;
     env = getenv("SVC_STEM_FUSED");
     if (env) h->stem_fused = atoi(env) != 0;
     env = getenv("SVC_DWPW");

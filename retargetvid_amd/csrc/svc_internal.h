@@ -116,6 +116,7 @@ struct SvcHandle {
     int pw_small = 0;                  // small-M pointwise layers on 16-row wave tiles (SVC_PW_SMALL: 0 off, 1: 16x32, 2: 16x64, 3: 32x32)
     bool pw16 = true;                  // 16x16x4 MFMA pointwise kernel for narrow short-K layers (SVC_PW16=0: always 32x32x2)
     int fuse_max = 7;                  // backbone blocks 1..fuse_max run as the fused inverted-residual kernel (SVC_FUSE_MAX, 0..13)
+    bool split_up = true;              // decoder expansions as conv(skip) + up-sample(conv(low-res part)) (SVC_SPLIT_UP=0: up-sample, concatenate, one GEMM)
     bool irb_fixed = true;             // fused blocks of the six MobileNetV2 shapes run compile-time-shaped instances (SVC_IRB_FIXED=0: generic)
     bool stem_fused = false;           // features.0 computed inside the kernel of backbone block 1 (SVC_STEM_FUSED=1); measured equal to k_stem + block 1 at B=32 (146 vs 151 us), 218 MB less HBM traffic per 32 frames
     bool dwpw = true;                  // depthwise 3x3 fused into the following 1x1 project (SVC_DWPW=0: two kernels)

@@ -280,11 +280,22 @@ __global__ __launch_bounds__(256) void k_stem(const float *__restrict__ X, const
 // s-th MFMA of an 8-deep K chunk: both operands come from one float4 per lane, read
 // straight from global memory (the k order inside a chunk is a consistent permutation).
 // --------------------------------------------------------------------------------------
+// Optional epilogue term of k_pw: a low-resolution tensor U [n][UH][UW][ldu] added after 2x bilinear
+// up-sampling (align_corners = False, the arithmetic of k_upsample2x).  A 1x1 convolution commutes with the
+// up-sampling, so the decoder's "up-sample, concatenate with the skip, expand" (model.py:463-483) is evaluated
+// as conv(skip part) + up-sample(conv(low-resolution part)): the up-sampled half of the concatenation is
+// contracted at a quarter of the pixels and never materialised.
+struct UpsAdd {
+    const float *U;
+    int UH, UW, ldu;
+    FDiv dOW, dOH;
+};
+
 template <int TN, int PF>
-__global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx, const float *__restrict__ Wt,
+__global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
                                             const float *__restrict__ bias, const float *__restrict__ R, int ldr,
                                             float *__restrict__ Y, int ldy, int M, int N, int Npad, int K,
-                                            int relu6) {
+                                            int relu6, UpsAdd ups) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int m0 = blockIdx.x * 128 + wave * 32;
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
         int col = min(n0 + t * 32 + r, Npad - 1);
-        wp[t] = Wt + (size_t)col * K + 4 * hh;
+        wp[t] = Wt + (size_t)col * ldw + 4 * hh;
     }
     f32x16 acc[TN];
 #pragma unroll
@@ -338,11 +349,38 @@ __global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx
             }
         }
     }
+    if (ups.U) {
+        // rows first: the four taps and weights of an output pixel are shared by all of the wave's column tiles
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rr = m0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            if (rr >= M) continue;
+            uint32_t ox, oy;
+            const uint32_t f = fdivmod(fdivmod((uint32_t)rr, ups.dOW, ox), ups.dOH, oy);
+            const float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ox + 0.5f) - 0.5f, 0.f);
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < ups.UH - 1 ? 1 : 0), x1 = x0 + (x0 < ups.UW - 1 ? 1 : 0);
+            const float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+            const float *uf = ups.U + (size_t)f * ups.UH * ups.UW * ups.ldu;
+            const float *u00 = uf + ((size_t)y0 * ups.UW + x0) * ups.ldu, *u01 = uf + ((size_t)y0 * ups.UW + x1) * ups.ldu;
+            const float *u10 = uf + ((size_t)y1 * ups.UW + x0) * ups.ldu, *u11 = uf + ((size_t)y1 * ups.UW + x1) * ups.ldu;
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const int col = n0 + t * 32 + r;
+                if (col >= N) continue;
+                float v = acc[t][i] + (bias ? bias[col] : 0.f);
+                v += ly0 * (lx0 * u00[col] + lx1 * u01[col]) + ly1 * (lx0 * u10[col] + lx1 * u11[col]);
+                if (relu6) v = fminf(fmaxf(v, 0.f), 6.f);
+                Y[(size_t)rr * ldy + col] = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
         const int col = n0 + t * 32 + r;
         if (col >= N) continue;
-        const float bv = bias[col];
+        const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int rr = m0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
@@ -365,7 +403,7 @@ __global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx
 // --------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int MT, int NT>     // wave tile = (16*MT) rows x (16*NT) columns; workgroup = 4 waves stacked along M
-__global__ __launch_bounds__(256) void k_pw16(const float *__restrict__ X, int ldx, const float *__restrict__ Wt,
+__global__ __launch_bounds__(256) void k_pw16(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
                                               const float *__restrict__ bias, const float *__restrict__ R, int ldr,
                                               float *__restrict__ Y, int ldy, int M, int N, int Npad, int K,
                                               int relu6) {
@@ -379,7 +417,7 @@ __global__ __launch_bounds__(256) void k_pw16(const float *__restrict__ X, int l
     for (int i = 0; i < MT; ++i) xa[i] = X + (size_t)min(m0 + 16 * i + r16, M - 1) * ldx + 4 * q;
     const float *wb[NT];
 #pragma unroll
-    for (int c = 0; c < NT; ++c) wb[c] = Wt + (size_t)min(n0 + 16 * c + r16, Npad - 1) * K + 4 * q;
+    for (int c = 0; c < NT; ++c) wb[c] = Wt + (size_t)min(n0 + 16 * c + r16, Npad - 1) * ldw + 4 * q;
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -404,7 +442,7 @@ __global__ __launch_bounds__(256) void k_pw16(const float *__restrict__ X, int l
     for (int c = 0; c < NT; ++c) {
         const int col = n0 + 16 * c + r16;
         if (col >= N) continue;
-        const float bv = bias[col];
+        const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -427,7 +465,7 @@ __global__ __launch_bounds__(256) void k_pw16(const float *__restrict__ X, int l
 // order (deterministic), every wave finishing four of the sixteen accumulator rows.
 // --------------------------------------------------------------------------------------
 template <int TN>
-__global__ __launch_bounds__(256) void k_pw_sk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt,
+__global__ __launch_bounds__(256) void k_pw_sk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
                                                const float *__restrict__ bias, const float *__restrict__ R, int ldr,
                                                float *__restrict__ Y, int ldy, int M, int N, int Npad, int K,
                                                int relu6) {
@@ -438,7 +476,7 @@ __global__ __launch_bounds__(256) void k_pw_sk(const float *__restrict__ X, int 
     const float *xp = X + (size_t)min(m0 + r, M - 1) * ldx + 4 * hh;
     const float *wp[TN];
 #pragma unroll
-    for (int t = 0; t < TN; ++t) wp[t] = Wt + (size_t)min(n0 + t * 32 + r, Npad - 1) * K + 4 * hh;
+    for (int t = 0; t < TN; ++t) wp[t] = Wt + (size_t)min(n0 + t * 32 + r, Npad - 1) * ldw + 4 * hh;
     f32x16 acc[TN];
 #pragma unroll
     for (int t = 0; t < TN; ++t)
@@ -467,7 +505,7 @@ __global__ __launch_bounds__(256) void k_pw_sk(const float *__restrict__ X, int 
     for (int t = 0; t < TN; ++t) {
         const int col = n0 + t * 32 + r;
         if (col >= N) continue;
-        const float bv = bias[col];
+        const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
             const int i = 4 * wave + ii;
@@ -743,7 +781,7 @@ __global__ __launch_bounds__(256) void k_quantise(const float *__restrict__ pre,
 // plan / workspace
 // --------------------------------------------------------------------------------------
 enum Buf { B_IN, B_P0, B_P1, B_E0, B_E1, B_F4X, B_F2X, B_S4E, B_S2E, B_CAT1, B_PCD, B_PC, B_CAT2, B_U2E, B_U2D,
-           B_U2, B_CAT3, B_P3E, B_P3D, B_DEC, B_LOGIT, B_PRE, B_COUNT };
+           B_U2, B_CAT3, B_P3E, B_P3D, B_DEC, B_LOGIT, B_PRE, B_T1, B_T2, B_COUNT };
 
 struct NetPlan {
     int h = 0, w = 0, NH = 0, NW = 0, nb = 0;
@@ -801,6 +839,7 @@ static int build_plan(SvcHandle *h, int height, int width, int nb) {
     sz[B_CAT1] = H5 * W5 * 1296; sz[B_PCD] = H5 * W5 * 1296; sz[B_PC] = H5 * W5 * 256;
     sz[B_CAT2] = H4 * W4 * 384; sz[B_U2E] = H4 * W4 * 768; sz[B_U2D] = H4 * W4 * 768; sz[B_U2] = H4 * W4 * 128;
     sz[B_CAT3] = H3 * W3 * 192; sz[B_P3E] = H3 * W3 * 384; sz[B_P3D] = H3 * W3 * 384; sz[B_DEC] = H3 * W3 * 64;
+    sz[B_T1] = H5 * W5 * 768; sz[B_T2] = H4 * W4 * 384;   // low-resolution halves of the two decoder expansions
     sz[B_LOGIT] = (H3 * W3 + 3) / 4 * 4;
     sz[B_PRE] = ((size_t)height * width + 3) / 4 * 4;
     p->off[0] = 0;
@@ -887,10 +926,14 @@ int svc_net_release(SvcHandle *h) {
 // --------------------------------------------------------------------------------------
 static inline unsigned blocks256(size_t total) { return (unsigned)((total + 255) / 256); }
 
-static int launch_pw(SvcHandle *h, hipStream_t s, const float *X, int ldx, const SvcLayer &L, const float *R, int ldr,
-                     float *Y, int ldy, int M, int n) {
+// One pointwise layer, or a column slice of one: K of the ldw input channels of the weight rows, starting at Wt
+// (bias may be null).  ups != null adds the up-sampled low-resolution product (see UpsAdd).
+static int launch_pw_ex(SvcHandle *h, hipStream_t s, const float *X, int ldx, const float *Wt, int ldw, int K,
+                        const float *bias, int relu6v, int N, const float *R, int ldr, float *Y, int ldy, int M, int n,
+                        const UpsAdd *ups) {
     ProfScope ps(h, SVC_K_PW, s);
-    const int N = L.cout, K = L.cin, Npad = (N + 31) / 32 * 32, tiles = Npad / 32;
+    const int Npad = (N + 31) / 32 * 32, tiles = Npad / 32;
+    UpsAdd ua = ups ? *ups : UpsAdd{nullptr, 0, 0, 0, make_fdiv(1), make_fdiv(1)};
     const int rb = ceil_div(M, 128);
     int TN = 4;
     while (TN > 1 && (TN > tiles || rb * ceil_div(tiles, TN) < h->pw_min_wg)) --TN;
@@ -900,8 +943,8 @@ static int launch_pw(SvcHandle *h, hipStream_t s, const float *X, int ldx, const
     // must not depend on its batch.  The tile shape (TN) may follow the real M, it does not change
     // any sum order.
     const int rb_nom = ceil_div((M / n) * 32, 128);
-#define PW16_ARGS X, ldx, L.w.dev, L.b.dev, R, ldr, Y, ldy, M, N, Npad, K, L.relu6
-    if (h->pw_sk && K >= 256 && rb_nom * tiles <= 1024) {   // long K, few workgroups: split K over the four waves
+#define PW16_ARGS X, ldx, Wt, ldw, bias, R, ldr, Y, ldy, M, N, Npad, K, relu6v
+    if (!ups && h->pw_sk && K >= 256 && rb_nom * tiles <= 1024) {   // long K, few workgroups: split K over the four waves
         const int tn = (tiles % 2 == 0) ? 2 : 1;
         dim3 g(ceil_div(M, 32), ceil_div(tiles, tn));
         if (tn == 2) k_pw_sk<2><<<g, 256, 0, s>>>(PW16_ARGS);
@@ -911,7 +954,7 @@ static int launch_pw(SvcHandle *h, hipStream_t s, const float *X, int ldx, const
     }
     // small-M layers (8x13 and 16x26 levels at B = 32) leave most SIMDs idle with 32x32 wave tiles:
     // 16x32 wave tiles (SVC_PW_SMALL selects the shape) give 2-4x more waves
-    if (h->pw_small && K % 16 == 0 && K >= 64 && rb_nom * tiles < 1024) {
+    if (!ups && h->pw_small && K % 16 == 0 && K >= 64 && rb_nom * tiles < 1024) {
         if (h->pw_small == 1) {
             k_pw16<1, 2><<<dim3(ceil_div(M, 64), tiles), 256, 0, s>>>(PW16_ARGS);
         } else if (h->pw_small == 2) {
@@ -924,13 +967,13 @@ static int launch_pw(SvcHandle *h, hipStream_t s, const float *X, int ldx, const
     }
     // measured on MI355X: the 16x16x4 form wins for single-N-tile layers with a short K (the
     // high-resolution project layers), the 32x32x2 form everywhere else
-    if (h->pw16 && tiles == 1 && K % 16 == 0 && K >= 64 && K <= 192) {
+    if (!ups && h->pw16 && tiles == 1 && K % 16 == 0 && K >= 64 && K <= 192) {
         k_pw16<2, 2><<<dim3(rb, 1), 256, 0, s>>>(PW16_ARGS);
         SVC_CHECK_LAUNCH();
         return SVC_OK;
     }
 #undef PW16_ARGS
-#define PW_ARGS X, ldx, L.w.dev, L.b.dev, R, ldr, Y, ldy, M, N, Npad, K, L.relu6
+#define PW_ARGS X, ldx, Wt, ldw, bias, R, ldr, Y, ldy, M, N, Npad, K, relu6v, ua
     switch (TN) {
         case 4: k_pw<4, 1><<<grid, 256, 0, s>>>(PW_ARGS); break;
         case 3: k_pw<3, 1><<<grid, 256, 0, s>>>(PW_ARGS); break;
@@ -940,6 +983,11 @@ static int launch_pw(SvcHandle *h, hipStream_t s, const float *X, int ldx, const
 #undef PW_ARGS
     SVC_CHECK_LAUNCH();
     return SVC_OK;
+}
+
+static int launch_pw(SvcHandle *h, hipStream_t s, const float *X, int ldx, const SvcLayer &L, const float *R, int ldr,
+                     float *Y, int ldy, int M, int n) {
+    return launch_pw_ex(h, s, X, ldx, L.w.dev, L.cin, L.cin, L.b.dev, L.relu6, L.cout, R, ldr, Y, ldy, M, n, nullptr);
 }
 
 static int launch_dw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer &L, float *Y, int n, int H, int W,
@@ -1625,13 +1673,23 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
         RC(launch_pw(h, s, p->buf(B_PCD), 1296, next(), nullptr, 0, p->buf(B_PC), 256, n * H5 * W5, n));
     }
     // US1 + concat, US2 block
-    {
-        ProfScope ps(h, SVC_K_RESAMPLE, s);
-        k_upsample2x<<<blocks256((size_t)n * H4 * W4 * 64), 256, 0, s>>>(p->buf(B_PC), CAT2, n, H5, W5, 256, 384, make_fdiv(64),
-                                                                         make_fdiv(W4), make_fdiv(H4));
-        SVC_CHECK_LAUNCH();
+    if (h->split_up) {
+        // expand(concat(up(PC), skip)) = relu6(up(W[:, :256] . PC) + W[:, 256:] . skip + b)
+        const SvcLayer &Le = next();
+        RC(launch_pw_ex(h, s, p->buf(B_PC), 256, Le.w.dev, 384, 256, nullptr, 0, 768, nullptr, 0, p->buf(B_T1), 768,
+                        n * H5 * W5, n, nullptr));
+        const UpsAdd ua{p->buf(B_T1), H5, W5, 768, make_fdiv(W4), make_fdiv(H4)};
+        RC(launch_pw_ex(h, s, CAT2 + 256, 384, Le.w.dev + 256, 384, 128, Le.b.dev, Le.relu6, 768, nullptr, 0,
+                        p->buf(B_U2E), 768, n * H4 * W4, n, &ua));
+    } else {
+        {
+            ProfScope ps(h, SVC_K_RESAMPLE, s);
+            k_upsample2x<<<blocks256((size_t)n * H4 * W4 * 64), 256, 0, s>>>(p->buf(B_PC), CAT2, n, H5, W5, 256, 384,
+                                                                             make_fdiv(64), make_fdiv(W4), make_fdiv(H4));
+            SVC_CHECK_LAUNCH();
+        }
+        RC(launch_pw(h, s, CAT2, 384, next(), nullptr, 0, p->buf(B_U2E), 768, n * H4 * W4, n));
     }
-    RC(launch_pw(h, s, CAT2, 384, next(), nullptr, 0, p->buf(B_U2E), 768, n * H4 * W4, n));
     if (h->dwpw) {
         const SvcLayer &Ld = next();
         RC(launch_dwpw(h, s, p->buf(B_U2E), Ld, next(), nullptr, 0, p->buf(B_U2), 128, n, H4, W4));
@@ -1639,13 +1697,22 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
         RC(launch_dw(h, s, p->buf(B_U2E), next(), p->buf(B_U2D), n, H4, W4, 1));
         RC(launch_pw(h, s, p->buf(B_U2D), 768, next(), nullptr, 0, p->buf(B_U2), 128, n * H4 * W4, n));
     }
-    {
-        ProfScope ps(h, SVC_K_RESAMPLE, s);
-        k_upsample2x<<<blocks256((size_t)n * H3 * W3 * 32), 256, 0, s>>>(p->buf(B_U2), CAT3, n, H4, W4, 128, 192, make_fdiv(32),
-                                                                         make_fdiv(W3), make_fdiv(H3));
-        SVC_CHECK_LAUNCH();
+    if (h->split_up) {
+        const SvcLayer &Le = next();
+        RC(launch_pw_ex(h, s, p->buf(B_U2), 128, Le.w.dev, 192, 128, nullptr, 0, 384, nullptr, 0, p->buf(B_T2), 384,
+                        n * H4 * W4, n, nullptr));
+        const UpsAdd ua{p->buf(B_T2), H4, W4, 384, make_fdiv(W3), make_fdiv(H3)};
+        RC(launch_pw_ex(h, s, CAT3 + 128, 192, Le.w.dev + 128, 192, 64, Le.b.dev, Le.relu6, 384, nullptr, 0,
+                        p->buf(B_P3E), 384, n * H3 * W3, n, &ua));
+    } else {
+        {
+            ProfScope ps(h, SVC_K_RESAMPLE, s);
+            k_upsample2x<<<blocks256((size_t)n * H3 * W3 * 32), 256, 0, s>>>(p->buf(B_U2), CAT3, n, H4, W4, 128, 192,
+                                                                             make_fdiv(32), make_fdiv(W3), make_fdiv(H3));
+            SVC_CHECK_LAUNCH();
+        }
+        RC(launch_pw(h, s, CAT3, 192, next(), nullptr, 0, p->buf(B_P3E), 384, n * H3 * W3, n));
     }
-    RC(launch_pw(h, s, CAT3, 192, next(), nullptr, 0, p->buf(B_P3E), 384, n * H3 * W3, n));
     if (h->dwpw) {
         const SvcLayer &Ld = next();
         RC(launch_dwpw(h, s, p->buf(B_P3E), Ld, next(), nullptr, 0, p->buf(B_DEC), 64, n, H3, W3));
@@ -1781,6 +1848,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->pw16 = atoi(env) != 0;
     env = getenv("SVC_FUSE_MAX");
     if (env) h->fuse_max = std::min(13, std::max(0, atoi(env)));
+    env = getenv("SVC_SPLIT_UP");
+    if (env) h->split_up = atoi(env) != 0;
     env = getenv("SVC_IRB_FIXED");
     if (env) h->irb_fixed = atoi(env) != 0;
     env = getenv("SVC_STEM_FUSED");

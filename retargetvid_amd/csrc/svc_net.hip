@@ -291,7 +291,9 @@ struct UpsAdd {
     FDiv dOW, dOH;
 };
 
-template <int TN, int PF>
+// TR = true: the MFMA operands are swapped (weights as A, activations as B), so a lane ends up with ONE pixel and
+// 16 output channels in runs of four -- the epilogue then moves float4 (4 stores per tile instead of 16).
+template <int TN, int PF, bool TR = false>
 __global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
                                             const float *__restrict__ bias, const float *__restrict__ R, int ldr,
                                             float *__restrict__ Y, int ldy, int M, int N, int Npad, int K,
@@ -341,13 +343,63 @@ __global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx
                 }
 #pragma unroll
                 for (int t = 0; t < TN; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+                    if (TR) {
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].x, a.x, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].y, a.y, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].z, a.z, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].w, a.w, acc[t], 0, 0, 0);
+                    } else {
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+                    }
                 }
             }
         }
+    }
+    if (TR) {
+        // lane = pixel m0 + r; accumulator i = channel n0 + 32t + 8(i>>2) + 4hh + (i&3)
+        const int rr = m0 + r;
+        if (rr >= M) return;
+        const float *u00 = nullptr, *u01 = nullptr, *u10 = nullptr, *u11 = nullptr;
+        float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
+        if (ups.U) {
+            uint32_t ox, oy;
+            const uint32_t f = fdivmod(fdivmod((uint32_t)rr, ups.dOW, ox), ups.dOH, oy);
+            const float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ox + 0.5f) - 0.5f, 0.f);
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < ups.UH - 1 ? 1 : 0), x1 = x0 + (x0 < ups.UW - 1 ? 1 : 0);
+            const float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+            const float *uf = ups.U + (size_t)f * ups.UH * ups.UW * ups.ldu;
+            u00 = uf + ((size_t)y0 * ups.UW + x0) * ups.ldu; u01 = uf + ((size_t)y0 * ups.UW + x1) * ups.ldu;
+            u10 = uf + ((size_t)y1 * ups.UW + x0) * ups.ldu; u11 = uf + ((size_t)y1 * ups.UW + x1) * ups.ldu;
+            w00 = lx0; w01 = lx1; w10 = ly0; w11 = ly1;
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = n0 + t * 32 + 8 * g + 4 * hh;
+                if (col >= N) continue;
+                float4 v = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+                if (bias) { const float4 bv = *(const float4 *)(bias + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+                if (ups.U) {
+                    const float4 a0 = *(const float4 *)(u00 + col), a1 = *(const float4 *)(u01 + col);
+                    const float4 c0 = *(const float4 *)(u10 + col), c1 = *(const float4 *)(u11 + col);
+                    v.x += w10 * (w00 * a0.x + w01 * a1.x) + w11 * (w00 * c0.x + w01 * c1.x);
+                    v.y += w10 * (w00 * a0.y + w01 * a1.y) + w11 * (w00 * c0.y + w01 * c1.y);
+                    v.z += w10 * (w00 * a0.z + w01 * a1.z) + w11 * (w00 * c0.z + w01 * c1.z);
+                    v.w += w10 * (w00 * a0.w + w01 * a1.w) + w11 * (w00 * c0.w + w01 * c1.w);
+                }
+                if (R) { const float4 rv = *(const float4 *)(R + (size_t)rr * ldr + col); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+                if (relu6) {
+                    v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
+                    v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
+                }
+                *(float4 *)(Y + (size_t)rr * ldy + col) = v;
+            }
+        return;
     }
     if (ups.U) {
         // rows first: the four taps and weights of an output pixel are shared by all of the wave's column tiles
@@ -944,7 +996,7 @@ static int launch_pw_ex(SvcHandle *h, hipStream_t s, const float *X, int ldx, co
     // any sum order.
     const int rb_nom = ceil_div((M / n) * 32, 128);
 #define PW16_ARGS X, ldx, Wt, ldw, bias, R, ldr, Y, ldy, M, N, Npad, K, relu6v
-    if (!ups && h->pw_sk && K >= 256 && rb_nom * tiles <= 1024) {   // long K, few workgroups: split K over the four waves
+    if (!ups && h->pw_sk && K >= 256 && rb_nom * tiles <= h->pw_sk_max) {   // long K, few workgroups: split K over the four waves
         const int tn = (tiles % 2 == 0) ? 2 : 1;
         dim3 g(ceil_div(M, 32), ceil_div(tiles, tn));
         if (tn == 2) k_pw_sk<2><<<g, 256, 0, s>>>(PW16_ARGS);
@@ -974,11 +1026,20 @@ static int launch_pw_ex(SvcHandle *h, hipStream_t s, const float *X, int ldx, co
     }
 #undef PW16_ARGS
 #define PW_ARGS X, ldx, Wt, ldw, bias, R, ldr, Y, ldy, M, N, Npad, K, relu6v, ua
-    switch (TN) {
-        case 4: k_pw<4, 1><<<grid, 256, 0, s>>>(PW_ARGS); break;
-        case 3: k_pw<3, 1><<<grid, 256, 0, s>>>(PW_ARGS); break;
-        case 2: k_pw<2, 1><<<grid, 256, 0, s>>>(PW_ARGS); break;
-        default: k_pw<1, 1><<<grid, 256, 0, s>>>(PW_ARGS); break;
+    if (h->pw_tr) {
+        switch (TN) {
+            case 4: k_pw<4, 1, true><<<grid, 256, 0, s>>>(PW_ARGS); break;
+            case 3: k_pw<3, 1, true><<<grid, 256, 0, s>>>(PW_ARGS); break;
+            case 2: k_pw<2, 1, true><<<grid, 256, 0, s>>>(PW_ARGS); break;
+            default: k_pw<1, 1, true><<<grid, 256, 0, s>>>(PW_ARGS); break;
+        }
+    } else {
+        switch (TN) {
+            case 4: k_pw<4, 1><<<grid, 256, 0, s>>>(PW_ARGS); break;
+            case 3: k_pw<3, 1><<<grid, 256, 0, s>>>(PW_ARGS); break;
+            case 2: k_pw<2, 1><<<grid, 256, 0, s>>>(PW_ARGS); break;
+            default: k_pw<1, 1><<<grid, 256, 0, s>>>(PW_ARGS); break;
+        }
     }
 #undef PW_ARGS
     SVC_CHECK_LAUNCH();
@@ -1842,6 +1903,10 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env && atoi(env) > 0) h->pw_min_wg = atoi(env);
     env = getenv("SVC_PW_SK");
     if (env) h->pw_sk = atoi(env) != 0;
+    env = getenv("SVC_PW_TR");
+    if (env) h->pw_tr = atoi(env) != 0;
+    env = getenv("SVC_PW_SK_MAX");
+    if (env && atoi(env) > 0) h->pw_sk_max = atoi(env);
     env = getenv("SVC_PW_SMALL");
     if (env) h->pw_small = atoi(env);
     env = getenv("SVC_PW16");

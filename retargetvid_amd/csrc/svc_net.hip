@@ -1415,23 +1415,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     const int NT = CoutP >> 5, ptiles = MP * NT;
     const int KS = ptiles >= 4 ? 1 : 4 / ptiles, kw = 32 / KS;
     const int t0 = KS > 1 ? wave % ptiles : wave, ks = KS > 1 ? wave / ptiles : 0;
-    // per expand tile of this wave: which of the lane's 16 accumulator rows are halo pixels at all (rmask)
-    // and which of those lie inside the image (vmask); evaluated once, not per chunk
+    // MFMA operands are swapped throughout (weights as A, pixels as B): a lane owns ONE pixel of the tile and 16
+    // channels in runs of four, so bias / ReLU6 / masking and the LDS or global writes of the epilogues move float4.
+    // Per expand tile of this wave: is the lane's row a halo pixel at all (row_ok), and inside the image (in_img)?
     constexpr int MTW = (MT + 3) / 4;                     // expand tiles per wave
-    uint32_t vmask[MTW], rmask[MTW];
+    bool row_ok[MTW], in_img[MTW];
 #pragma unroll
     for (int u = 0; u < MTW; ++u) {
-        vmask[u] = 0; rmask[u] = 0;
         const int mt = (MT == 5 && u == 1) ? 4 : wave + 4 * u;    // MT == 5: the odd tile rotates over the waves
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int rr = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            const int hy = rr / IW, hx = rr - hy * IW;
-            if (mt < MT && rr < NPX) {
-                rmask[u] |= 1u << i;
-                if ((unsigned)(iy0 + hy) < (unsigned)H && (unsigned)(ix0 + hx) < (unsigned)W) vmask[u] |= 1u << i;
-            }
-        }
+        const int rr = mt * 32 + r;
+        const int hy = rr / IW, hx = rr - hy * IW;
+        row_ok[u] = mt < MT && rr < NPX;
+        in_img[u] = row_ok[u] && (unsigned)(iy0 + hy) < (unsigned)H && (unsigned)(ix0 + hx) < (unsigned)W;
     }
     for (int ch = 0; ch < nchunks; ++ch) {
         const int kend = min(32, Ce - ch * 32);
@@ -1458,19 +1453,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 for (int k = 0; k < Cin; k += 8) {
                     const float4 a = *(const float4 *)(ap + k);
                     const float4 b = *(const float4 *)(bq + k);
-                    e = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, e, 0, 0, 0);
-                    e = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, e, 0, 0, 0);
-                    e = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, e, 0, 0, 0);
-                    e = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, e, 0, 0, 0);
+                    e = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, e, 0, 0, 0);
+                    e = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, e, 0, 0, 0);
+                    e = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, e, 0, 0, 0);
+                    e = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, e, 0, 0, 0);
                 }
-                const int c = ch * 32 + r;
-                const float bv = c < Ce ? be[c] : 0.f;      // rows of We beyond Ce are zero, so e + bv = 0 there
-                float *ep = E + (mt * 32 + 4 * hh) * IRB_ES + r;
-                const uint32_t vm = vmask[u], rm = rmask[u];
+                // lane = halo pixel mt*32 + r; e[4g + j] = channel ch*32 + 8g + 4hh + j
+                if (row_ok[u]) {
+                    float *ep = E + (mt * 32 + r) * IRB_ES + 4 * hh;
+                    const bool in = in_img[u];
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if ((rm >> i) & 1u)
-                        ep[((i & 3) + 8 * (i >> 2)) * IRB_ES] = ((vm >> i) & 1u) ? fminf(fmaxf(e[i] + bv, 0.f), 6.f) : 0.f;
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = ch * 32 + 8 * g + 4 * hh;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (in && c < Ce) {                 // channels beyond Ce (zero weight rows) stay 0, like out-of-image pixels
+                            const float4 bv = *(const float4 *)(be + c);
+                            v.x = fminf(fmaxf(e[4 * g] + bv.x, 0.f), 6.f);
+                            v.y = fminf(fmaxf(e[4 * g + 1] + bv.y, 0.f), 6.f);
+                            v.z = fminf(fmaxf(e[4 * g + 2] + bv.z, 0.f), 6.f);
+                            v.w = fminf(fmaxf(e[4 * g + 3] + bv.w, 0.f), 6.f);
+                        }
+                        *(float4 *)(ep + 8 * g) = v;
+                    }
+                }
             }
             __syncthreads();                                // barrier 1: E complete; expand(ch), project(ch-1) retired
         }
@@ -1524,10 +1529,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 for (int k = k_lo; k < k_hi; k += 8) {
                     const float4 a = *(const float4 *)(ap + k);
                     const float4 b = *(const float4 *)(bq + k);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc[j], 0, 0, 0);
                 }
             }
         }
@@ -1541,9 +1546,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         __syncthreads();
         {
             const int pm = t0 % MP, nt = t0 / MP;
-            float *pp = Pp + ((size_t)ks * NOUT + pm * 32 + 4 * hh) * PS + nt * 32 + r;
+            float *pp = Pp + ((size_t)ks * NOUT + pm * 32 + r) * PS + nt * 32 + 4 * hh;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) pp[((i & 3) + 8 * (i >> 2)) * PS] = acc[0][i];
+            for (int g = 0; g < 4; ++g)
+                *(float4 *)(pp + 8 * g) = make_float4(acc[0][4 * g], acc[0][4 * g + 1], acc[0][4 * g + 2], acc[0][4 * g + 3]);
         }
         __syncthreads();
         const int c4o = CoutP >> 2;
@@ -1567,25 +1573,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         }
         return;
     }
-    // epilogue: bias (+ residual) and store
+    // epilogue: bias (+ residual) and store; lane = output pixel pm*32 + r, 16 channels in runs of four
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int tile = t0 + 4 * j;
         if (tile >= ptiles) continue;
         const int pm = tile % MP, nt = tile / MP;
-        const int col = nt * 32 + r;
-        if (col >= Cout) continue;
-        const float bv = bp[col];
+        const int px = pm * 32 + r;
+        const int oy = oy0 + px / TOW, ox = ox0 + px % TOW;
+        if (oy >= OH || ox >= OW) continue;
+        const size_t pix = ((size_t)f * OH + oy) * OW + ox;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int px = pm * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            const int oy = oy0 + px / TOW, ox = ox0 + px % TOW;
-            if (oy < OH && ox < OW) {
-                const size_t pix = ((size_t)f * OH + oy) * OW + ox;
-                float v = acc[j][i] + bv;
-                if (R) v += R[pix * Cout + col];
-                Y[pix * ldy + col] = v;
+        for (int g = 0; g < 4; ++g) {
+            const int col = nt * 32 + 8 * g + 4 * hh;
+            if (col >= Cout) continue;
+            const float4 bv = *(const float4 *)(bp + col);
+            float4 v = make_float4(acc[j][4 * g] + bv.x, acc[j][4 * g + 1] + bv.y, acc[j][4 * g + 2] + bv.z, acc[j][4 * g + 3] + bv.w);
+            if (R) {
+                const float4 rv = *(const float4 *)(R + pix * Cout + col);
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             }
+            *(float4 *)(Y + pix * ldy + col) = v;
         }
     }
 }

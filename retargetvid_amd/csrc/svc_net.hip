@@ -542,10 +542,10 @@ __global__ __launch_bounds__(256) void k_pw_sk(const float *__restrict__ X, int 
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
             const float4 b = *(const float4 *)(wp[t] + 8 * st);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc[t], 0, 0, 0);       // swapped: lane = row
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc[t], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -553,23 +553,26 @@ __global__ __launch_bounds__(256) void k_pw_sk(const float *__restrict__ X, int 
 #pragma unroll
         for (int i = 0; i < 16; ++i) red[wave][t][i][lane] = acc[t][i];
     __syncthreads();
+    // a lane holds row m0 + r and accumulator i = column 8(i>>2) + 4hh + (i&3) of the tile: wave w finishes the
+    // column run g = w with one float4
+    const int rr = m0 + r;
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
-        const int col = n0 + t * 32 + r;
-        if (col >= N) continue;
-        const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int i = 4 * wave + ii;
-            const int rr = m0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            if (rr < M) {
-                float v = ((red[0][t][i][lane] + red[1][t][i][lane]) + red[2][t][i][lane]) + red[3][t][i][lane];
-                v += bv;
-                if (R) v += R[(size_t)rr * ldr + col];
-                if (relu6) v = fminf(fmaxf(v, 0.f), 6.f);
-                Y[(size_t)rr * ldy + col] = v;
-            }
+        const int g = wave;
+        const int col = n0 + t * 32 + 8 * g + 4 * hh;
+        if (col >= N || rr >= M) continue;
+        float4 v;
+        v.x = ((red[0][t][4 * g][lane] + red[1][t][4 * g][lane]) + red[2][t][4 * g][lane]) + red[3][t][4 * g][lane];
+        v.y = ((red[0][t][4 * g + 1][lane] + red[1][t][4 * g + 1][lane]) + red[2][t][4 * g + 1][lane]) + red[3][t][4 * g + 1][lane];
+        v.z = ((red[0][t][4 * g + 2][lane] + red[1][t][4 * g + 2][lane]) + red[2][t][4 * g + 2][lane]) + red[3][t][4 * g + 2][lane];
+        v.w = ((red[0][t][4 * g + 3][lane] + red[1][t][4 * g + 3][lane]) + red[2][t][4 * g + 3][lane]) + red[3][t][4 * g + 3][lane];
+        if (bias) { const float4 bv = *(const float4 *)(bias + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+        if (R) { const float4 rv = *(const float4 *)(R + (size_t)rr * ldr + col); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+        if (relu6) {
+            v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
+            v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
         }
+        *(float4 *)(Y + (size_t)rr * ldy + col) = v;
     }
 }
 
@@ -1175,40 +1178,47 @@ __global__ __launch_bounds__(64 * NWV) void k_dwpw(const float *__restrict__ X, 
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const float4 b = *(const float4 *)(Wp + (size_t)min(n0 + t * 32 + r, Npad - 1) * C + ch * 32 + 4 * hh + k);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc[t], 0, 0, 0);   // swapped: lane = pixel
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc[t], 0, 0, 0);
             }
         }
         __builtin_amdgcn_wave_barrier();                    // the next chunk overwrites the slab
     }
-    // sum of the NWV K partials (wave order), bias, residual, store: wave w finishes 16/NWV accumulator rows
+    // sum of the NWV K partials (wave order), bias, residual, store.  With the operands swapped a lane holds pixel r
+    // of the patch and accumulator i = channel 8(i>>2) + 4hh + (i&3) of the tile: wave w finishes the channel
+    // runs g = w (and w + 4 ... when NWV < 4 does not apply: NWV is 4 or 8), one float4 per lane.
+    const int yy = y0 + r / PW, xx = x0 + r % PW;
+    const bool live = yy < H && xx < W;
+    const size_t pix = ((size_t)f * H + yy) * W + xx;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if (t) __syncthreads();
 #pragma unroll
         for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[t][i];
         __syncthreads();
-        const int col = n0 + t * 32 + r;
-        if (col >= N) continue;
-        const float bv = bp[col];
+        if (wave >= 4) continue;                            // (8-wave form: the upper waves only contribute partials)
+        const int g = wave;
+        const int col = n0 + t * 32 + 8 * g + 4 * hh;
+        if (col >= N || !live) continue;
+        float4 v = make_float4(red[0][4 * g][lane], red[0][4 * g + 1][lane], red[0][4 * g + 2][lane], red[0][4 * g + 3][lane]);
 #pragma unroll
-        for (int ii = 0; ii < 16 / NWV; ++ii) {
-            const int i = (16 / NWV) * wave + ii;
-            const int p = (i & 3) + 8 * (i >> 2) + 4 * hh;
-            const int yy = y0 + p / PW, xx = x0 + p % PW;
-            if (yy < H && xx < W) {
-                const size_t pix = ((size_t)f * H + yy) * W + xx;
-                float v = red[0][i][lane];
-#pragma unroll
-                for (int q = 1; q < NWV; ++q) v += red[q][i][lane];
-                v += bv;
-                if (R) v += R[pix * ldr + col];
-                if (relu6) v = fminf(fmaxf(v, 0.f), 6.f);
-                Y[pix * ldy + col] = v;
-            }
+        for (int q = 1; q < NWV; ++q) {
+            v.x += red[q][4 * g][lane]; v.y += red[q][4 * g + 1][lane];
+            v.z += red[q][4 * g + 2][lane]; v.w += red[q][4 * g + 3][lane];
         }
+        const float4 bv = *(const float4 *)(bp + col);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (R) {
+            const float4 rv = *(const float4 *)(R + pix * ldr + col);
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        if (relu6) {
+            v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
+            v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
+        }
+        *(float4 *)(Y + pix * ldy + col) = v;
     }
 }
 

@@ -113,7 +113,7 @@ struct SvcHandle {
     int chunk = 32;                    // frames per network pass
     int pw_min_wg = 1024;              // k_pw narrows its column tile until the grid has this many workgroups (SVC_PW_MIN_WG)
     bool pw_sk = true;                 // split-K pointwise kernel for long-K small-M layers (SVC_PW_SK=0 disables)
-    bool pw_tr = true;                 // k_pw with swapped MFMA operands: a lane owns one pixel, float4 epilogue (SVC_PW_TR=0: a lane owns one channel)
+    int pw_tr = 2;                     // k_pw with swapped MFMA operands (a lane owns one pixel, float4 epilogue): 0 never, 1 always, 2 for wave tiles of 2+ column tiles and up-sample-add launches (single-tile launches store whole 128 B lines with the scalar form)
     int pw_sk_max = 1024;              // ... when row blocks x column tiles (at the nominal batch) do not exceed this (SVC_PW_SK_MAX)
     int pw_small = 0;                  // small-M pointwise layers on 16-row wave tiles (SVC_PW_SMALL: 0 off, 1: 16x32, 2: 16x64, 3: 32x32)
     bool pw16 = true;                  // 16x16x4 MFMA pointwise kernel for narrow short-K layers (SVC_PW16=0: always 32x32x2)

@@ -843,8 +843,8 @@ struct NetPlan {
     size_t off[B_COUNT + 1];      // per-frame float offsets
     DevBuf ws, fmax, lut, gauss;
     DevBuf hb, hk, vb, vk;
-    int hks = 0, vks = 0, lz_rows = 16, lz_tile_cap = 0;
-    int sd_rows = 14, sd_tile_cap = 0;
+    int hks = 0, vks = 0, lz_rows = 8, lz_tile_cap = 0;       // output rows per workgroup of k_lanczos_norm (SVC_LZ_ROWS)
+    int sd_rows = 7, sd_tile_cap = 0;                         // output rows per workgroup of k_smooth_down (SVC_SD_ROWS)
     int last_n = 0;
     float *buf(int b) const { return (float *)ws.p + off[b] * (size_t)nb; }
     size_t per_frame(int b) const { return off[b + 1] - off[b]; }
@@ -880,6 +880,8 @@ static int build_plan(SvcHandle *h, int height, int width, int nb) {
     int NH, NW;
     optimal_out_size(height, width, NH, NW);
     const bool same_size = (p->h == height && p->w == width);
+    if (const char *e = getenv("SVC_LZ_ROWS")) if (atoi(e) > 0) p->lz_rows = atoi(e);
+    if (const char *e = getenv("SVC_SD_ROWS")) if (atoi(e) > 0) p->sd_rows = atoi(e);
     p->h = height; p->w = width; p->NH = NH; p->NW = NW; p->nb = nb;
     const size_t H1 = NH / 2, W1 = NW / 2, H2 = NH / 4, W2 = NW / 4, H3 = NH / 8, W3 = NW / 8, H4 = NH / 16,
                  W4 = NW / 16, H5 = NH / 32, W5 = NW / 32;
@@ -1029,7 +1031,7 @@ static int launch_pw_ex(SvcHandle *h, hipStream_t s, const float *X, int ldx, co
     }
 #undef PW16_ARGS
 #define PW_ARGS X, ldx, Wt, ldw, bias, R, ldr, Y, ldy, M, N, Npad, K, relu6v, ua
-    if (h->pw_tr) {
+    if (h->pw_tr == 1 || (h->pw_tr == 2 && (TN >= 2 || ups))) {
         switch (TN) {
             case 4: k_pw<4, 1, true><<<grid, 256, 0, s>>>(PW_ARGS); break;
             case 3: k_pw<3, 1, true><<<grid, 256, 0, s>>>(PW_ARGS); break;
@@ -1922,7 +1924,7 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     env = getenv("SVC_PW_SK");
     if (env) h->pw_sk = atoi(env) != 0;
     env = getenv("SVC_PW_TR");
-    if (env) h->pw_tr = atoi(env) != 0;
+    if (env) h->pw_tr = atoi(env);
     env = getenv("SVC_PW_SK_MAX");
     if (env && atoi(env) > 0) h->pw_sk_max = atoi(env);
     env = getenv("SVC_PW_SMALL");

@@ -100,7 +100,7 @@ static void cv_linear_tab(int src, int dst, bool horizontal, int *ofs, int *a, i
 
 extern "C" int svc_resize_frames_u8(SvcHandle *h, const uint8_t *frames, int n, int height, int width,
                                     uint8_t *out, int sh, int sw, void *stream) {
-    if (!h || !frames || !out || n < 0 || height < 1 || width < 1 || sh < 1 || sw < 1) {
+    if (!h || n < 0 || (n > 0 && (!frames || !out)) || height < 1 || width < 1 || sh < 1 || sw < 1) {     // n = 0: a no-op, null buffers allowed
         svc_set_error("svc_resize_frames_u8: invalid argument");
         return SVC_E_INVALID;
     }
@@ -1829,7 +1829,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
 
 extern "C" int svc_saliency_u8(SvcHandle *h, const uint8_t *frames, int n, int height, int width, uint8_t *maps,
                                void *stream) {
-    if (!h || !frames || !maps || n < 0 || height < 8 || width < 8) {
+    if (!h || n < 0 || (n > 0 && (!frames || !maps)) || height < 8 || width < 8) {     // n = 0: a no-op, null buffers allowed
         svc_set_error("svc_saliency_u8: invalid argument");
         return SVC_E_INVALID;
     }

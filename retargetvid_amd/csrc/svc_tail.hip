@@ -947,7 +947,8 @@ __global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
 // host side
 // --------------------------------------------------------------------------------------
 extern "C" int svc_threshold_u8(SvcHandle *h, uint8_t *maps, size_t n_bytes, int t, void *stream) {
-    if (!h || !maps) { svc_set_error("svc_threshold_u8: invalid argument"); return SVC_E_INVALID; }
+    if (!h || (n_bytes > 0 && !maps)) { svc_set_error("svc_threshold_u8: invalid argument"); return SVC_E_INVALID; }
+    if (n_bytes == 0) return SVC_OK;
     if (n_bytes == 0) return SVC_OK;
     SVC_HIP(hipSetDevice(h->device));
     ProfScope ps(h, SVC_K_THRESHOLD, (hipStream_t)stream);
@@ -1019,7 +1020,7 @@ static int ensure_ring(SvcHandle *h) {
 extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height, int width,
                                   const uint8_t *blend_flags_host, const SvcParams *params, double *xy,
                                   int32_t *stats, void *stream) {
-    if (!h || !maps || !params || !xy || n < 0 || height < 1 || width < 1) {
+    if (!h || !params || n < 0 || (n > 0 && (!maps || !xy)) || height < 1 || width < 1) {     // n = 0: a no-op, null buffers allowed
         svc_set_error("svc_cluster_center: invalid argument");
         return SVC_E_INVALID;
     }

@@ -949,7 +949,6 @@ __global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
 extern "C" int svc_threshold_u8(SvcHandle *h, uint8_t *maps, size_t n_bytes, int t, void *stream) {
     if (!h || (n_bytes > 0 && !maps)) { svc_set_error("svc_threshold_u8: invalid argument"); return SVC_E_INVALID; }
     if (n_bytes == 0) return SVC_OK;
-    if (n_bytes == 0) return SVC_OK;
     SVC_HIP(hipSetDevice(h->device));
     ProfScope ps(h, SVC_K_THRESHOLD, (hipStream_t)stream);
     k_threshold<<<(unsigned)((n_bytes + 4095) / 4096), 256, 0, (hipStream_t)stream>>>(maps, n_bytes, t);

@@ -7,8 +7,9 @@
  * handle.  `stream` is a hipStream_t passed as void* (NULL = the default stream);
  * all work is enqueued on it and nothing synchronises unless stated.  Every call
  * returns 0 on success or a negative SVC_E_* code; svc_last_error() then holds a
- * message for the calling thread.  The library never exits the process and never
- * reads stdin (the reference blocks on input() at smartVidCrop.py:544-545).
+ * message for the calling thread.  A call with n = 0 frames / maps / boxes is a
+ * successful no-op (its buffers may then be NULL).  The library never exits the
+ * process and never reads stdin (the reference blocks on input() at smartVidCrop.py:544-545).
  *
  * Reference interfaces replaced (paths relative to the reference tree):
  *   svc_create / svc_destroy    unisal_handler.init_unisal_for_images()

@@ -51,6 +51,16 @@ def set_engine(engine):
 sc_times = {}
 
 
+_video_reader = None
+
+
+def set_video_reader(fn):
+    """Install the decode hand-off: ``fn(video_path, crop_params) -> ingest_pickle dict`` (see
+    retargetvid_amd/ingest.py).  None removes it.  Decoding and shot detection are not part of the path."""
+    global _video_reader
+    _video_reader = fn
+
+
 def sc_init_time():
     global sc_times
     sc_times = {}
@@ -287,10 +297,13 @@ def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn=''
     elif isinstance(video_path, str) and video_path.endswith('.pkl'):
         with open(video_path, 'rb') as fp:
             video = pickle.load(fp)
+    elif _video_reader is not None:
+        video = _video_reader(video_path, CP)
     else:
         raise NotImplementedError('decoding video files and TransNetV1 shot detection stay outside this '
                                   'package: pass the ingest_pickle dict (fr, frame_count, w, h, frames, '
-                                  'trans_inds) or a .pkl holding it')
+                                  'trans_inds), a .pkl holding it, or install a reader with set_video_reader() '
+                                  '(retargetvid_amd/ingest.py)')
     VD = _LazySmaps(ingest_frames(video, CP, engine, verbose=verbose))
     if callback_status is not None and callback_session is not None:
         callback_status(callback_session, 'sc', 'SC PROCESSING', 'smart-cropping main process')

@@ -3,6 +3,7 @@ BN folding, blob packing, result files — each against the oracle's literal res
 import os
 
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -143,3 +144,35 @@ def test_entry_points_fail_loudly_without_gpu():
                          S.sc_init_crop_params(), save_vid=False)
     with pytest.raises(NotImplementedError):
         S.smart_vid_crop('movie.mp4', S.sc_init_crop_params(), save_vid=False, engine=object())
+
+
+def test_decode_hand_off_adapter(monkeypatch):
+    """ingest.read_video_cv2 against a stand-in for OpenCV: BGR -> RGB, frame count, shot list -> trans_inds."""
+    import sys, types
+    from retargetvid_amd import ingest
+    rng = np.random.RandomState(0)
+    bgr = rng.randint(0, 256, (7, 6, 8, 3)).astype(np.uint8)
+
+    class Cap:
+        def __init__(self, path): self.i = 0
+        def isOpened(self): return True
+        def get(self, prop): return {5: 25.0, 7: 7}[prop]
+        def read(self):
+            if self.i >= len(bgr): return False, None
+            self.i += 1
+            return True, bgr[self.i - 1]
+        def release(self): pass
+
+    fake = types.SimpleNamespace(VideoCapture=Cap, CAP_PROP_FPS=5, CAP_PROP_FRAME_COUNT=7)
+    monkeypatch.setitem(sys.modules, 'cv2', fake)
+    v = ingest.read_video_cv2('x.mp4', shot_detector=lambda fr: [3, 3, 0, 99])
+    assert v['fr'] == 25.0 and v['frame_count'] == 7 and (v['w'], v['h']) == (8, 6)
+    assert np.array_equal(v['frames'], bgr[..., ::-1]) and v['trans_inds'] == [0, 3, 7]
+    assert ingest.video_dict(bgr, 30)['trans_inds'] == [0, 7]
+    S.set_video_reader(lambda path, CP: v)
+    try:
+        with pytest.raises(Exception) as ei:          # reaches the device path, which needs a GPU here
+            S.smart_vid_crop('x.mp4', S.sc_init_crop_params(), save_vid=False)
+        assert not isinstance(ei.value, NotImplementedError)
+    finally:
+        S.set_video_reader(None)

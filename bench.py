@@ -115,7 +115,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    # BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, barrier, MAX all-reduce, box gather) with any
+    # world size, including 1 under torch.distributed.run -- a way to exercise it on a single-GPU box
+    dist_on = world > 1 or os.environ.get('BENCH_FORCE_DIST', '0') == '1'
+    if dist_on:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local)
         torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
@@ -174,7 +177,7 @@ def main():
         return boxes
 
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -207,7 +210,7 @@ def main():
     if not live:                                                  # fall back to the isolated per-class measurement
         dom_ms, dom_launches = per_class[dominant][0] * args.steps, per_class[dominant][1] * args.steps
 
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -265,7 +268,7 @@ def main():
                                parallelism='frames sharded, dp%d' % world),
                    roofline=roof, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         # the path's one exchange: every rank ends up with all crop windows (outside the timed region)
         counts = [B] * world
         allb = svc_dist.gather_boxes({i: np.asarray(boxes, np.int32) for i in svc_dist.shard_videos(counts, world)[rank]}, counts)

@@ -96,6 +96,9 @@ def test_saliency_batch_and_chunk_independence(engine):
     {'SVC_DWPW': '0', 'SVC_DW_TILE': '0'},                  # ... with the one-output-per-thread depthwise
     {'SVC_DWPW_MIN_PX': '1'},                               # fused depthwise+project on the 8x13 level too
     {'SVC_PW_SK': '0', 'SVC_PW16': '0'},                    # no split-K, no 16x16x4 pointwise form
+    {'SVC_PW_SMALL': '1'},                                  # 16x16x4 wave tiles for the small-M levels (three shapes)
+    {'SVC_PW_SMALL': '2'},
+    {'SVC_PW_SMALL': '3', 'SVC_PW_TR': '1'},               # ... and the float4 epilogue for every k_pw launch
     {'SVC_PW_TR': '0'},                                     # pointwise kernel with a lane per channel (scalar epilogue)
     {'SVC_FUSE_MAX': '13'},                                 # every block that can be fused is
     {'SVC_SPLIT_UP': '0'},                                  # decoder: up-sample + concatenate + one GEMM (the reference's order)

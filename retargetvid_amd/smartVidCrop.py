@@ -24,6 +24,7 @@ Failures raise exceptions; nothing blocks on input() (the reference does at :544
 """
 import math
 import pickle
+import threading
 import time
 
 import numpy as np
@@ -48,7 +49,7 @@ def set_engine(engine):
 
 
 # ---- time registry (smartVidCrop.py:98-127) ------------------------------------------------
-sc_times = {}
+_tls = threading.local()       # per-thread stage timers (the reference keeps one global dict, smartVidCrop.py:98)
 
 
 _video_reader = None
@@ -62,17 +63,17 @@ def set_video_reader(fn):
 
 
 def sc_init_time():
-    global sc_times
-    sc_times = {}
+    _tls.times = {}
 
 
 def sc_register_time(t, key_name):
-    sc_times[key_name] = sc_times.get(key_name, 0.0) + (time.perf_counter() - t)
+    times = _tls.__dict__.setdefault('times', {})
+    times[key_name] = times.get(key_name, 0.0) + (time.perf_counter() - t)
 
 
 def sc_all_times(vid_dur):
     t_dict, sum_t, sum_p = {}, 0.0, 0.0
-    for k, v in sc_times.items():
+    for k, v in _tls.__dict__.setdefault('times', {}).items():
         if k.startswith('_'):
             sum_t += v
             sum_p += (v / vid_dur) * 100.0
@@ -226,7 +227,7 @@ def ingest_frames(video, crop_params, engine=None, verbose=False):
                 sel = torch.from_numpy(np.ascontiguousarray(np.asarray(frames)[idx])).to(dev)
             small = engine.resize_frames(sel.contiguous(), sal_h, sal_w)
             smaps[first:first + cnt - 1] = engine.saliency(small)
-    torch.cuda.synchronize(dev)
+    torch.cuda.current_stream(dev).synchronize()      # the caller's stream only: other videos may be in flight on theirs
     sc_register_time(t, '_read_sal_det')
     scenes = []
     for i in range(len(trans_inds)):
@@ -321,8 +322,7 @@ def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn=''
     maps = VD['smaps_dev']
     t = time.perf_counter()
     engine.threshold_(maps, CP['t_threshold'])
-    torch.cuda.synchronize(maps.device)
-    sc_register_time(t, '_thresh')
+    sc_register_time(t, '_thresh')                     # (enqueue time; the stream is synchronised by the D2H below)
 
     t = time.perf_counter()
     flags = blend_flags(VD['fc_sel'], VD['segmentation_sel']) if CP['clust_filt'] else None
@@ -415,6 +415,46 @@ def smart_vid_crop_ratios(video_path, CP, ratios, engine=None, verbose=False):
                 VD['h_orig'], VD['w_orig'], VD['h_process'], VD['w_process'], VD['h_final'], VD['w_final'],
                 VD['fbb_h'], VD['fbb_w'])
         out[ratio] = (VD, res)
+    return out
+
+
+def crop_videos(videos, CP, ratios=None, workers=3, state_dict=None, seed=0):
+    """Many videos on one GPU with ``workers`` of them in flight: every worker thread owns an engine
+    (weights + workspace) and a HIP stream and runs smart_vid_crop_ratios on its share, so the
+    low-occupancy clustering tail and the host-side temporal stages of one video overlap the network of
+    the next ones (what bench.py does with its batches).  ``videos``: a sequence of ingest_pickle dicts or
+    of zero-argument callables producing them (built on the worker's stream).  Returns a list, in input
+    order, of {ratio: (VD, smart_crop_results)}; each entry equals a sequential smart_vid_crop_ratios call."""
+    import torch
+    ratios = tuple(ratios) if ratios else (CP['out_ratio'],)
+    videos = list(videos)
+    workers = max(1, min(int(workers), len(videos) or 1))
+    dev = torch.device('cuda', torch.cuda.current_device())
+    from . import ops as _ops
+    engines = [_ops.Engine(state_dict, device=dev.index, seed=seed) for _ in range(workers)]
+    out, errors = [None] * len(videos), []
+
+    def run(k):
+        torch.cuda.set_device(dev)
+        stream = torch.cuda.Stream(device=dev)
+        try:
+            with torch.cuda.stream(stream):
+                for i in range(k, len(videos), workers):
+                    v = videos[i]() if callable(videos[i]) else videos[i]
+                    out[i] = smart_vid_crop_ratios(v, CP, ratios, engine=engines[k])
+                stream.synchronize()
+        except BaseException as e:                       # surfaced in the caller's thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(workers)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in engines:
+        e.close()
+    if errors:
+        raise errors[0]
     return out
 
 

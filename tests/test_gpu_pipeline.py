@@ -113,3 +113,14 @@ def test_multi_ratio_run_equals_separate_calls_and_lazy_frames(engine):
     a = video['frames'].select([5, 17])
     b = video['frames'].select([17])
     assert torch.equal(a[1], b[0]) and a.shape == (2, 360, 640, 3) and a.dtype == torch.uint8
+
+
+def test_videos_in_flight_equal_sequential_runs(engine):
+    """S.crop_videos (worker threads, one engine + stream each) returns exactly what sequential calls return."""
+    CP = S.sc_init_crop_params()
+    vids = [_video(40 + 7 * k, 30 + k, [0, 17 + k, 40 + 7 * k]) for k in range(5)]
+    seq = [S.smart_vid_crop_ratios(v, CP, ('1:3', '3:1'), engine=engine) for v in vids]
+    par = S.crop_videos([(lambda v=v: v) for v in vids], CP, ('1:3', '3:1'), workers=3)
+    for a, b in zip(seq, par):
+        for r in ('1:3', '3:1'):
+            assert a[r][0]['bbs'] == b[r][0]['bbs'] and a[r][0]['dx'] == b[r][0]['dx']

@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--videos', type=int, default=200)
     ap.add_argument('--max-frames', type=int, default=0, help='truncate every video (0 = real length)')
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'config3'))
+    ap.add_argument('--workers', type=int, default=4, help='videos in flight per GPU (S.crop_videos)')
     ap.add_argument('--annotations', default=os.path.join(ROOT, 'tests', 'golden', 'retargetvid'))
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
@@ -41,21 +42,25 @@ def main():
     if args.max_frames:
         counts = [min(c, args.max_frames) for c in counts]
     mine = D.shard_videos(counts, world)[rank]
-    eng = ops.Engine(seed=0)
     CP = S.sc_init_crop_params()
     ratios = ('1:3', '3:1')
     local_boxes = {r: {} for r in ratios}
     infos = {}
+
+    def make(i):
+        def build():
+            n = counts[i]
+            rng = np.random.RandomState(vids[i])
+            cuts = sorted(set([0] + [int(c) for c in rng.randint(20, max(21, n - 20), rng.randint(0, 4))]))
+            return dict(fr=30.0, frame_count=n, w=640, h=360, frames=synth.LazyBlobVideo(n, seed=vids[i]),
+                        trans_inds=cuts + [n])
+        return build
+
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    res_all = S.crop_videos([make(i) for i in mine], CP, ratios, workers=args.workers)
     n_sal = 0
-    for i in mine:
-        n = counts[i]
-        rng = np.random.RandomState(vids[i])
-        cuts = sorted(set([0] + [int(c) for c in rng.randint(20, max(21, n - 20), rng.randint(0, 4))]))
-        video = dict(fr=30.0, frame_count=n, w=640, h=360, frames=synth.LazyBlobVideo(n, seed=vids[i]),
-                     trans_inds=cuts + [n])
-        res = S.smart_vid_crop_ratios(video, CP, ratios, engine=eng)
+    for i, res in zip(mine, res_all):
         for r in ratios:
             local_boxes[r][i] = np.asarray(res[r][0]['bbs'], np.int32)
         infos[i] = {r: res[r][1] for r in ratios}

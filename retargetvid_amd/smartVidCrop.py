@@ -141,10 +141,12 @@ def sc_compute_bb(vid_data, crop_params, verbose=False):
     scale_h = float(vid_data['h_process']) / float(fh)
     scale_w = float(vid_data['w_process']) / float(fw)
     bt, bb, bl, br = (vid_data.get(k, 0) for k in ('border_t', 'border_b', 'border_l', 'border_r'))
-    xs, ys = vid_data['dxs'], vid_data['dys']
-    for i in range(vid_data['fc']):
-        xs[i] = int(xs[i] / scale_w)
-        ys[i] = int(ys[i] / scale_h)
+    fc = vid_data['fc']
+    # full-resolution integer centres, int() = truncation toward zero (:995-999); vectorised, same float64 arithmetic
+    xs = np.trunc(np.asarray(vid_data['dxs'][:fc], np.float64) / scale_w).astype(np.int64)
+    ys = np.trunc(np.asarray(vid_data['dys'][:fc], np.float64) / scale_h).astype(np.int64)
+    vid_data['dxs'][:fc] = xs.tolist()
+    vid_data['dys'][:fc] = ys.tolist()
     bb_w, bb_h = vid_data['w_final'], vid_data['h_final']
     fbb_w, fbb_h = bb_w, bb_h
     if bb_h == fh:
@@ -158,20 +160,18 @@ def sc_compute_bb(vid_data, crop_params, verbose=False):
     hw2 = fbb_w - hw1
     hh1 = int(fbb_h / 2.0)
     hh2 = fbb_h - hh1
-    out = []
-    for i in range(vid_data['fc']):
-        x1, y1, x2, y2 = xs[i] - hw1, ys[i] - hh1, xs[i] + hw2, ys[i] + hh2
-        if x1 < bl:
-            x1, x2 = bl, bl + fbb_w
-        if x2 > fw - br:
-            x2 = fw - br
-            x1 = x2 - fbb_w
-        if y1 < bt:
-            y1, y2 = bt, bt + fbb_h
-        if y2 > fh - bb:
-            y2 = fh - bb
-            y1 = y2 - fbb_h
-        out.append([x1, y1, x2, y2])
+    x1, x2, y1, y2 = xs - hw1, xs + hw2, ys - hh1, ys + hh2
+    m = x1 < bl                                    # the four clamps in the reference's order (:1027-1044)
+    x1[m], x2[m] = bl, bl + fbb_w
+    m = x2 > fw - br
+    x2[m] = fw - br
+    x1[m] = x2[m] - fbb_w
+    m = y1 < bt
+    y1[m], y2[m] = bt, bt + fbb_h
+    m = y2 > fh - bb
+    y2[m] = fh - bb
+    y1[m] = y2[m] - fbb_h
+    out = np.stack([x1, y1, x2, y2], axis=1).tolist()
     vid_data['bbs'] = out
     return vid_data
 
@@ -355,6 +355,7 @@ def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn=''
     sc_register_time(t, '_interpolation')
     t = time.perf_counter()
     VD['dxs'], VD['dys'] = temporal.smoothing(VD['dxi'], VD['dyi'], VD['segmentation'], VD['fr'], CP)
+    VD['dxs_smooth'], VD['dys_smooth'] = list(VD['dxs']), list(VD['dys'])    # sc_compute_bb overwrites dxs / dys (:995-999)
     sc_register_time(t, '_smooth')
     t = time.perf_counter()
     VD = sc_compute_bb(VD, CP, verbose=verbose)
@@ -406,7 +407,7 @@ def smart_vid_crop_ratios(video_path, CP, ratios, engine=None, verbose=False):
             VD = _LazySmaps({k: (copy.copy(v) if isinstance(v, list) else v) for k, v in base[0].items()})
             res = dict(base[1])
             VD = sc_calc_dest_size(VD, cp)
-            VD['dxs'], VD['dys'] = temporal.smoothing(VD['dxi'], VD['dyi'], VD['segmentation'], VD['fr'], cp)
+            VD['dxs'], VD['dys'] = list(base[0]['dxs_smooth']), list(base[0]['dys_smooth'])   # smoothing does not depend on the ratio
             VD = sc_compute_bb(VD, cp)
             if cp['shift_time'] > 0:
                 temporal.shift_time(VD['bbs'], cp['shift_time'])

@@ -15,6 +15,8 @@ Reference (smartVidCrop.py unless noted):
   focus_stability        sc_check_for_extra_cuts + focus hold :1337-1455, :2425-2473
   shift_time             sc_shift_time                      :1740-1746
 """
+import functools
+
 import numpy as np
 from scipy import interpolate as _interp, signal as _signal
 
@@ -59,10 +61,15 @@ def interpolate(dx, dy, segmentation, segmentation_sel, true_inds):
     return dxi, dyi
 
 
+@functools.lru_cache(maxsize=64)
+def _butter_design(order, wn):
+    return _signal.butter(order, wn, btype='lowpass', analog=False)      # the design is ~10x the cost of filtering a shot
+
+
 def butter_lowpass(x, cutoff, fs, order):
     """Zero-phase Butterworth low-pass with the reference's fall-back chain for short series."""
     try:
-        b, a = _signal.butter(order, cutoff / (0.5 * fs), btype='lowpass', analog=False)
+        b, a = _butter_design(order, cutoff / (0.5 * fs))
         return _signal.filtfilt(b, a, x)
     except Exception:
         pass
@@ -76,13 +83,11 @@ def butter_lowpass(x, cutoff, fs, order):
     return x
 
 
-def loess(y, window, degree):
-    """pyloess.Loess(arange(n), y).estimate(j, window, degree=degree) for every j, vectorised."""
-    y = np.asarray(y, np.float64)
-    n = y.shape[0]
-    ymin, ymax = y.min(), y.max()
+@functools.lru_cache(maxsize=32)
+def _loess_design(n, window, degree):
+    """Everything of the local regressions that does not depend on the data: neighbourhoods, tricube weights
+    and, for degree > 1, the operator pinv(X^T W X) X^T W of every point (pyloess.py:60-83)."""
     with np.errstate(all='ignore'):
-        ny = (y - ymin) / (ymax - ymin)
         nx = np.arange(n, dtype=np.float64) / (n - 1)
         h = window // 2
         j = np.arange(n)
@@ -95,10 +100,25 @@ def loess(y, window, degree):
         if degree > 1:
             xm = nx[idx][:, :, None] ** np.arange(degree + 1)[None, None, :]     # [n, window, d+1]
             xtw = np.transpose(xm, (0, 2, 1)) * w[:, None, :]                    # X^T W
-            beta = np.linalg.pinv(xtw @ xm) @ xtw @ ny[idx][:, :, None]          # [n, d+1, 1]
+            op = np.linalg.pinv(xtw @ xm) @ xtw                                   # [n, d+1, window]
             xp = nx[j][:, None] ** np.arange(degree + 1)[None, :]
+            return idx, w, nx, op, xp
+        return idx, w, nx, None, None
+
+
+def loess(y, window, degree):
+    """pyloess.Loess(arange(n), y).estimate(j, window, degree=degree) for every j, vectorised."""
+    y = np.asarray(y, np.float64)
+    n = y.shape[0]
+    ymin, ymax = y.min(), y.max()
+    idx, w, nx, op, xp = _loess_design(n, int(window), int(degree))
+    with np.errstate(all='ignore'):
+        ny = (y - ymin) / (ymax - ymin)
+        if degree > 1:
+            beta = op @ ny[idx][:, :, None]                                       # [n, d+1, 1]
             est = np.einsum('nd,nd->n', beta[:, :, 0], xp)
         else:
+            j = np.arange(n)
             sx, sy = nx[idx], ny[idx]
             sw = w.sum(axis=1)
             mx, my = (sx * w).sum(1) / sw, (sy * w).sum(1) / sw

@@ -134,7 +134,8 @@ def main():
     frames_host = synth.blob_frames(B, 360, 640, seed=100 + rank)
     frames = torch.from_numpy(frames_host).to(dev)
     flags = np.zeros(B, np.uint8)
-    flags[:2] = 1                      # the batch starts a shot: maps 0,1 blend into 1,2 (smartVidCrop.py:2369-2373)
+    if os.environ.get('BENCH_NO_BLEND', '0') != '1':   # (diagnostic: a batch without a cut has one tail round instead of three)
+        flags[:2] = 1                  # the batch starts a shot: maps 0,1 blend into 1,2 (smartVidCrop.py:2369-2373)
 
     class Slot:
         """One in-flight step: its own engine (weights + workspace), HIP stream and pinned result buffer,

@@ -602,20 +602,23 @@ __device__ __forceinline__ bool build_wave(hdb::Tree &t, const hdb::Edge *edges,
             pre = hdb::resolve_ro(t, e);
         }
         const uint32_t v_r = pre.ra | (pre.rb << 16);
-        uint32_t v_c = pre.ca | (pre.cb << 16);
+        // the scan: straight-line steps (four v_readlane, scalar selects, two v_cndmask; no exec-mask handling, one taken
+        // branch): ~28 instructions = ~240 cycles per edge on a lone wavefront -- the floor of this formulation
+        uint32_t cur_a = pre.ca, cur_b = pre.cb;
         int P = m;
         for (int k = 0; k < m; ++k) {
-            const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)v_c, k);
-            const bool abig = (cc & 0xFFFFu) != hdb::NONE16, bbig = (cc >> 16) != hdb::NONE16;
+            const uint32_t ska = (uint32_t)__builtin_amdgcn_readlane((int)cur_a, k);
+            const uint32_t skb = (uint32_t)__builtin_amdgcn_readlane((int)cur_b, k);
+            const uint32_t sra = (uint32_t)__builtin_amdgcn_readlane((int)pre.ra, k);
+            const uint32_t srb = (uint32_t)__builtin_amdgcn_readlane((int)pre.rb, k);
+            const bool abig = ska != hdb::NONE16, bbig = skb != hdb::NONE16;
             if (abig == bbig) { P = k; break; }
-            const uint32_t rr = (uint32_t)__builtin_amdgcn_readlane((int)v_r, k);
-            const uint32_t ck = abig ? (cc & 0xFFFFu) : (cc >> 16);
-            const uint32_t rk = abig ? (rr >> 16) : (rr & 0xFFFFu);
-            if (lane > k) {                              // sides rooted at rk belong to ck from here on
-                if ((v_r & 0xFFFFu) == rk) v_c = (v_c & 0xFFFF0000u) | ck;
-                if ((v_r >> 16) == rk) v_c = (v_c & 0xFFFFu) | (ck << 16);
-            }
+            const uint32_t ck = abig ? ska : skb, rk = abig ? srb : sra;
+            const bool later = lane > k;                 // sides rooted at rk belong to ck from here on
+            cur_a = (later & (pre.ra == rk)) ? ck : cur_a;
+            cur_b = (later & (pre.rb == rk)) ? ck : cur_b;
         }
+        const uint32_t v_c = cur_a | (cur_b << 16);
         if (P > 0) {
             const bool act = lane < P;
             const uint32_t ca = v_c & 0xFFFFu, cb = v_c >> 16;
@@ -697,6 +700,20 @@ __device__ __forceinline__ void accumulate_wave(hdb::Tree &t, const hdb::Edge *e
             }
         }
         unsigned long long live = __ballot(c != hdb::NONE16);
+        if (!live) continue;
+        // the common batch -- every row a single point falling out of one and the same cluster -- as 64 additions
+        // with compile-time lane numbers (rows without an event add +0.0, which changes nothing)
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c, __builtin_ctzll(live));
+        if (__ballot(c != hdb::NONE16 && (c != c0 || s != 1)) == 0ull) {
+            if (c0 != cur) {
+                if (cur != hdb::NONE16 && lane == 0) t.cacc[cur] = acc;
+                cur = c0;
+                acc = t.cacc[c0];
+            }
+#pragma unroll
+            for (int j = 0; j < 64; ++j) acc += readlane_f64(term, j);
+            continue;
+        }
         while (live) {
             const int j = __builtin_ctzll(live);
             live &= live - 1;

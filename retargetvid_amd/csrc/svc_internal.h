@@ -104,6 +104,9 @@ struct SvcHandle {
     DevBuf tail_ws;
     DevBuf tail_offsets;     // ring-walk offset table
     int tail_n_offsets = 0, tail_n_offsets1 = 0;
+    std::vector<uint32_t> tail_offsets_host;
+    DevBuf tail_delta;       // dr * width + dc of every offset, for the map width of the last call
+    int tail_delta_w = -1;
     int tail_frames = 0, tail_h = 0, tail_w = 0;
     size_t tail_frame_stride = 0;      // bytes of per-frame tail workspace
     DevBuf rs_maps, rs_down, rs_up;    // resize_factor != 1: shrunk maps and the two INTER_LINEAR tables

@@ -25,8 +25,8 @@
 
 #define TB 1024                 // threads per frame workgroup
 #define NW16 (TB / 64)          // wavefronts per workgroup
-#define RING_R 40               // ring table radius for core distances
-#define RING_R1 6                // radius walked by the one-thread-per-point phase
+#define RING_R 20               // ring table radius for core distances
+#define RING_R1 4                // radius walked by the one-thread-per-point phase
 #define DEPTH_SLOT 4096          // maps per svc_cluster_center call
 #define REACH_INF 0x1FFFFu      // > any squared distance on a <=256x256 grid (17 bits)
 
@@ -77,6 +77,7 @@ struct TailArgs {
     int mcs, min_samples, select_sum, op_close, clust_filt;
     int prim_pt;            // tuning: smallest points-per-thread variant of k_prim
     const uint32_t *ring;   // sorted neighbour offsets
+    const int32_t *ring_delta;  // dr * w + dc of the same offsets
     int n_ring, n_ring1;    // all offsets within RING_R / the prefix within RING_R1
     double *xy;
     int32_t *stats;
@@ -261,6 +262,17 @@ __global__ __launch_bounds__(TB) void k_compact(TailArgs A) {
     }
 }
 
+// map <-> LDS copies, 8 bytes per lane when the map allows it (a 140x250 map does), bytes otherwise
+__device__ __forceinline__ void copy_bytes(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int n) {
+    if ((((uintptr_t)src | (uintptr_t)dst) & 7) == 0) {
+        const int n8 = n >> 3;
+        for (int i = threadIdx.x; i < n8; i += TB) ((uint2 *)dst)[i] = ((const uint2 *)src)[i];
+        for (int i = (n8 << 3) + threadIdx.x; i < n; i += TB) dst[i] = src[i];
+    } else {
+        for (int i = threadIdx.x; i < n; i += TB) dst[i] = src[i];
+    }
+}
+
 // --------------------------------------------------------------------------------------
 // k_core: squared distance to the k-th nearest other point, three exact phases:
 //  1. one thread per point walks the neighbour offsets (sorted by distance) of the inner
@@ -281,10 +293,13 @@ __global__ __launch_bounds__(TB) void k_core(TailArgs A) {
     const int hw = A.h * A.w;
     uint8_t *occ = sm_core;                                   // [hw]
     uint32_t *ring = (uint32_t *)(sm_core + (hw + 15) / 16 * 16);   // [n_ring]
+    int32_t *dl1 = (int32_t *)(ring + A.n_ring);                    // [n_ring1] linear form of the inner offsets
     __shared__ int n_fb, n_fb2;
     const uint8_t *map = A.maps + (size_t)f * hw;
-    for (int i = threadIdx.x; i < hw; i += TB) occ[i] = map[i];
+    const long long tc0 = wall_clock64();
+    copy_bytes(occ, map, hw);
     for (int i = threadIdx.x; i < A.n_ring; i += TB) ring[i] = A.ring[i];
+    for (int i = threadIdx.x; i < A.n_ring1; i += TB) dl1[i] = A.ring_delta[i];
     if (threadIdx.x == 0) { n_fb = 0; n_fb2 = 0; }
     __syncthreads();
     const uint32_t *pts = (const uint32_t *)(ws + A.L.pts);
@@ -295,22 +310,55 @@ __global__ __launch_bounds__(TB) void k_core(TailArgs A) {
     k = min(N - 1, k);
     if (k == 0) k = 1;
     const int h = A.h, w = A.w;
-    for (int p = threadIdx.x; p < N; p += TB) {
-        const uint32_t v = pts[p];
+    // phase 1: thread per point, ring offsets in groups of eight.  The offsets are the same for every thread, so
+    // they (and their linear form dr*w + dc) are broadcast reads of a small LDS table, and the eight occupancy probes of a
+    // group are independent LDS reads in flight together; only a group that contains the k-th neighbour is walked
+    // in order.  A point at least RING_R1 away from every border needs no bounds tests: 3 vector instructions
+    // per probe.
+    const int nr1 = A.n_ring1;
+    for (int pbase = 0; pbase < N; pbase += TB) {          // uniform trip count; lanes past N carry a dummy answer
+        const int p = pbase + threadIdx.x;
+        const bool live = p < N;
+        const uint32_t v = live ? pts[p] : 0u;
         const int r = v & 255, c = (v >> 8) & 255;
+        const bool interior = r >= RING_R1 && r < h - RING_R1 && c >= RING_R1 && c < w - RING_R1;
+        const uint8_t *op = occ + r * w + c;
         int cnt = 0;
-        uint32_t res = 0xFFFFFFFFu;
-        for (int i = 0; i < A.n_ring1; ++i) {
-            const uint32_t o = ring[i];
-            const int rr = r + (int)(o & 255) - 128, cc = c + (int)((o >> 8) & 255) - 128;
-            if ((unsigned)rr < (unsigned)h && (unsigned)cc < (unsigned)w && occ[rr * w + cc]) {
-                if (++cnt == k) { res = o >> 16; break; }
+        uint32_t res = live ? 0xFFFFFFFFu : 0u;
+        // (a wave-uniform loop, left when every lane has its answer: i0 stays scalar, and so do the table reads)
+        for (int i0 = 0; i0 < nr1 && __ballot(res == 0xFFFFFFFFu) != 0ull; i0 += 8) {
+            bool hit[8];
+            if (interior) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hit[j] = (i0 + j < nr1) && op[dl1[min(i0 + j, nr1 - 1)]] != 0;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t o = ring[min(i0 + j, nr1 - 1)];
+                    const int rr = r + (int)(o & 255) - 128, cc = c + (int)((o >> 8) & 255) - 128;
+                    const bool in = (i0 + j < nr1) && (unsigned)rr < (unsigned)h && (unsigned)cc < (unsigned)w;
+                    hit[j] = in && occ[in ? rr * w + cc : 0] != 0;
+                }
+            }
+            int add = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) add += hit[j] ? 1 : 0;
+            if (res != 0xFFFFFFFFu) continue;
+            if (cnt + add >= k) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (res == 0xFFFFFFFFu && hit[j] && ++cnt == k) res = ring[min(i0 + j, nr1 - 1)] >> 16;
+            } else {
+                cnt += add;
             }
         }
+        if (!live) continue;
         if (res != 0xFFFFFFFFu) core[p] = res;
         else fb[atomicAdd(&n_fb, 1)] = p;
     }
     __syncthreads();
+    int32_t *stamp = (int32_t *)(ws + A.L.hdr);                 // [5] phase 1, [6] phase 2, [7] end (10 ns units; debug door)
+    if (threadIdx.x == 0) stamp[5] = (int)(wall_clock64() - tc0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int nf = n_fb;
@@ -320,47 +368,100 @@ __global__ __launch_bounds__(TB) void k_core(TailArgs A) {
         const int r = v & 255, c = (v >> 8) & 255;
         int cum = 0;
         bool done = false;
-        for (int base = 0; base < A.n_ring; base += 64) {
-            const int i = base + lane;
-            bool hit = false;
-            uint32_t o = 0;
-            if (i < A.n_ring) {
-                o = ring[i];
-                const int rr = r + (int)(o & 255) - 128, cc = c + (int)((o >> 8) & 255) - 128;
-                hit = (unsigned)rr < (unsigned)h && (unsigned)cc < (unsigned)w && occ[rr * w + cc];
+        for (int base = 0; base < A.n_ring && !done; base += 256) {     // four independent probe chains per lane
+            bool hit[4];
+            uint32_t o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + 64 * u + lane;
+                hit[u] = false;
+                o[u] = 0;
+                if (i < A.n_ring) {
+                    o[u] = ring[i];
+                    const int rr = r + (int)(o[u] & 255) - 128, cc = c + (int)((o[u] >> 8) & 255) - 128;
+                    hit[u] = (unsigned)rr < (unsigned)h && (unsigned)cc < (unsigned)w && occ[rr * w + cc];
+                }
             }
-            const unsigned long long bal = __ballot(hit);
-            const int cnt = __popcll(bal);
-            if (cum + cnt >= k) {
-                if (hit && __popcll(bal & lt) == k - cum - 1) core[p] = o >> 16;
-                done = true;
-                break;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (done) break;
+                const unsigned long long bal = __ballot(hit[u]);
+                const int cnt = __popcll(bal);
+                if (cum + cnt >= k) {
+                    if (hit[u] && __popcll(bal & lt) == k - cum - 1) core[p] = o[u] >> 16;
+                    done = true;
+                } else {
+                    cum += cnt;
+                }
             }
-            cum += cnt;
         }
         if (!done && lane == 0) fb2[atomicAdd(&n_fb2, 1)] = p;
     }
     __syncthreads();
     const int nf2 = n_fb2;
+    if (threadIdx.x == 0) { stamp[6] = (int)(wall_clock64() - tc0); stamp[7] = stamp[6]; }
+    if (nf2 == 0) return;
+    // phase 3 counts over all points many times: their coordinates go to LDS (over the occupancy map and the ring
+    // table, which are no longer needed) when they fit
+    uint16_t *rcl = (uint16_t *)sm_core;
+    const bool in_lds = (size_t)N * 2 <= (size_t)(hw + 15) / 16 * 16 + (size_t)A.n_ring * 4;
+    if (in_lds) {
+        for (int j = threadIdx.x; j < N; j += TB) rcl[j] = (uint16_t)(pts[j] & 0xFFFFu);
+        __syncthreads();
+    }
     const uint32_t maxd = (uint32_t)((h - 1) * (h - 1) + (w - 1) * (w - 1));
     for (int q = wave; q < nf2; q += NW16) {
         const int p = fb2[q];
         const uint32_t v = pts[p];
         const int r = v & 255, c = (v >> 8) & 255;
         uint32_t lo = RING_R * RING_R + 1, hi = maxd;         // smallest t with #{d2 <= t} >= k+1 (self included)
+        if (in_lds && N <= 64 * 32) {
+            // all N distances of this point in registers (32 per lane), the bisection then touches no memory
+            uint32_t d[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int j = lane + 64 * i;
+                d[i] = 0xFFFFFFFFu;
+                if (j < N) {
+                    const uint32_t u = rcl[j];
+                    const int dr = (int)(u & 255) - r, dc = (int)(u >> 8) - c;
+                    d[i] = (uint32_t)(dr * dr + dc * dc);
+                }
+            }
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                int cnt = 0;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) cnt += d[i] <= mid;
+                cnt = wave_sum_i32(cnt);
+                if (cnt >= k + 1) hi = mid; else lo = mid + 1;
+            }
+            if (lane == 0) core[p] = lo;
+            continue;
+        }
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
             int cnt = 0;
-            for (int j = lane; j < N; j += 64) {
-                const uint32_t u = pts[j];
-                const int dr = (int)(u & 255) - r, dc = (int)((u >> 8) & 255) - c;
-                cnt += (uint32_t)(dr * dr + dc * dc) <= mid;
+            if (in_lds) {
+                for (int j = lane; j < N; j += 64) {
+                    const uint32_t u = rcl[j];
+                    const int dr = (int)(u & 255) - r, dc = (int)(u >> 8) - c;
+                    cnt += (uint32_t)(dr * dr + dc * dc) <= mid;
+                }
+            } else {
+                for (int j = lane; j < N; j += 64) {
+                    const uint32_t u = pts[j];
+                    const int dr = (int)(u & 255) - r, dc = (int)((u >> 8) & 255) - c;
+                    cnt += (uint32_t)(dr * dr + dc * dc) <= mid;
+                }
             }
             cnt = wave_sum_i32(cnt);
             if (cnt >= k + 1) hi = mid; else lo = mid + 1;
         }
         if (lane == 0) core[p] = lo;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) stamp[7] = (int)(wall_clock64() - tc0);
 }
 
 // --------------------------------------------------------------------------------------
@@ -887,7 +988,7 @@ __global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
     // ---- map phase: the LDS buffer now holds the map (the hierarchy state is no longer needed)
     uint8_t *m0 = sm_fin;                            // [hw]
     uint8_t *m1 = sm_fin + (hw + 15) / 16 * 16;      // [hw]
-    for (int i = tid; i < hw; i += TB) m0[i] = map[i];
+    copy_bytes(m0, map, hw);
     __syncthreads();
     if (best >= 0) {
         const uint32_t *pts = (const uint32_t *)(ws + A.L.pts);
@@ -930,7 +1031,7 @@ __global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
             }
             __syncthreads();
         }
-        for (int i = tid; i < hw; i += TB) map[i] = m0[i];
+        copy_bytes(map, m0, hw);
     }
     __syncthreads();
     // centroid of the non-zero pixels of the final map
@@ -1014,6 +1115,8 @@ static int upload_map_tab(DevBuf &buf, int h, int w, int oh, int ow, double sy, 
     return SVC_OK;
 }
 
+#define RC_TAIL(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
 static int ensure_ring(SvcHandle *h) {
     if (h->tail_n_offsets) return SVC_OK;
     std::vector<uint32_t> v;
@@ -1027,9 +1130,25 @@ static int ensure_ring(SvcHandle *h) {
     int rc = h->tail_offsets.ensure(v.size() * 4);
     if (rc) return rc;
     SVC_HIP(hipMemcpy(h->tail_offsets.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    h->tail_offsets_host = v;
     h->tail_n_offsets = (int)v.size();
     h->tail_n_offsets1 = 0;
     for (uint32_t x : v) h->tail_n_offsets1 += (int)((x >> 16) <= RING_R1 * RING_R1);
+    return SVC_OK;
+}
+
+// linear offsets of the ring table for maps of this width (rebuilt only when the width changes)
+static int ensure_ring_delta(SvcHandle *h, int width) {
+    if (h->tail_delta_w == width) return SVC_OK;
+    std::vector<int32_t> d(h->tail_offsets_host.size());
+    for (size_t i = 0; i < d.size(); ++i) {
+        const uint32_t o = h->tail_offsets_host[i];
+        d[i] = ((int)(o & 255) - 128) * width + ((int)((o >> 8) & 255) - 128);
+    }
+    int rc = h->tail_delta.ensure(d.size() * 4);
+    if (rc) return rc;
+    SVC_HIP(hipMemcpy(h->tail_delta.p, d.data(), d.size() * 4, hipMemcpyHostToDevice));
+    h->tail_delta_w = width;
     return SVC_OK;
 }
 
@@ -1095,10 +1214,12 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
     A.mcs = params->hdbscan_min; A.min_samples = params->hdbscan_min_samples; A.select_sum = params->select_sum;
     A.op_close = params->op_close; A.clust_filt = params->clust_filt;
     A.prim_pt = h->prim_pt;
+    RC_TAIL(ensure_ring_delta(h, width));
     A.ring = (const uint32_t *)h->tail_offsets.p; A.n_ring = h->tail_n_offsets; A.n_ring1 = h->tail_n_offsets1;
+    A.ring_delta = (const int32_t *)h->tail_delta.p;
     A.xy = xy; A.stats = stats; A.L = L;
     const int hw = height * width;
-    const size_t lds_core = (size_t)(hw + 15) / 16 * 16 + (size_t)h->tail_n_offsets * 4;
+    const size_t lds_core = (size_t)(hw + 15) / 16 * 16 + (size_t)h->tail_n_offsets * 4 + (size_t)h->tail_n_offsets1 * 4;
     const size_t lds_prim = 2 * NW16 * 16 + (size_t)hw * 2;
     const size_t lds_fin = 2 * ((size_t)(hw + 15) / 16 * 16);
     static bool attr_done = false;

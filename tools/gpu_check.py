@@ -139,6 +139,10 @@ try:
         torch.cuda.synchronize(); t3 = time.time()
         print('B=32: resize %.2f ms, saliency %.2f ms, tail %.2f ms  (N mean %.0f)' % (
             (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, stats[:, 0].float().mean().item()))
+    core_end = [eng.cluster_state(i, 8)['hdr'][5:8] / 100.0 for i in range(32)]
+    worst = int(np.argmax([c[2] for c in core_end]))
+    print('  k_core stamps (us): median phase1 %.1f phase2 %.1f end %.1f | slowest map %d: %.1f %.1f %.1f' % (
+        np.median([c[0] for c in core_end]), np.median([c[1] for c in core_end]), np.median([c[2] for c in core_end]), worst, *core_end[worst]))
     for i in range(0, 32, 4):
         st = eng.cluster_state(i, 35000)
         print('  warm frame %2d: N=%5d nclusters %3d  finish stamps (us): sorted %.1f built %.1f hierarchy %.1f chosen %.1f done %.1f | prim %.1f us | k_tree shader clock %.0f MHz' % (

@@ -618,6 +618,37 @@ __global__ __launch_bounds__(TB) void k_prim(TailArgs A) {
     if (threadIdx.x == 0) ((int32_t *)(ws + A.L.hdr))[12] = (int)(wall_clock64() - t0);
 }
 
+// One 1x5 (ROWS) or 5x1 pass of the separable grey CLOSE over a map in LDS: MAX = dilate, else erode; samples
+// outside the image are ignored (OpenCV's morphology border).  A thread produces four consecutive outputs
+// along the pass direction from one sliding window of eight samples (2 LDS reads per output instead of 5).
+template <bool MAX, bool ROWS>
+__device__ __forceinline__ void close_pass(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int h, int w) {
+    const int len = ROWS ? w : h, lines = ROWS ? h : w;      // length of a line along the pass, number of lines
+    const int stride = ROWS ? 1 : w, lstride = ROWS ? w : 1;
+    const int groups = (len + 3) >> 2;
+    const int ident = MAX ? 0 : 255;
+    for (int it = threadIdx.x; it < lines * groups; it += TB) {
+        // consecutive threads take consecutive positions ACROSS lines for the column pass (adjacent bytes in LDS)
+        const int line = ROWS ? it / groups : it % lines, g = ROWS ? it - line * groups : it / lines;
+        const int p0 = 4 * g;
+        const uint8_t *sp = src + line * lstride;
+        int win[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = p0 - 2 + j;
+            win[j] = (unsigned)q < (unsigned)len ? (int)sp[q * stride] : ident;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (p0 + j >= len) break;
+            int v = win[j];
+#pragma unroll
+            for (int d = 1; d < 5; ++d) v = MAX ? max(v, win[j + d]) : min(v, win[j + d]);
+            dst[line * lstride + (p0 + j) * stride] = (uint8_t)v;
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------------
 // k_finish: stable LSD radix sort of the MST edges by weight, hierarchy + EOM
 // (hdb_tree.h, one lane; its arrays live in LDS when N <= TREE_LDS_CAP), labels, cluster
@@ -1002,33 +1033,13 @@ __global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
         if (A.op_close) {
             // grey CLOSE with a 5x5 rectangle = separable max (dilate) then separable min (erode);
             // out-of-image samples are ignored
-            for (int i = tid; i < hw; i += TB) {
-                uint32_t cu; const int r = (int)fdivmod((uint32_t)i, A.dW, cu); const int c = (int)cu;
-                int v = 0;
-                for (int d = -2; d <= 2; ++d) { int cc = c + d; if ((unsigned)cc < (unsigned)A.w) v = max(v, (int)m0[r * A.w + cc]); }
-                m1[i] = (uint8_t)v;
-            }
+            close_pass<true, true>(m0, m1, A.h, A.w);      // dilate: rows then columns
             __syncthreads();
-            for (int i = tid; i < hw; i += TB) {
-                uint32_t cu; const int r = (int)fdivmod((uint32_t)i, A.dW, cu); const int c = (int)cu;
-                int v = 0;
-                for (int d = -2; d <= 2; ++d) { int rr = r + d; if ((unsigned)rr < (unsigned)A.h) v = max(v, (int)m1[rr * A.w + c]); }
-                m0[i] = (uint8_t)v;
-            }
+            close_pass<true, false>(m1, m0, A.h, A.w);
             __syncthreads();
-            for (int i = tid; i < hw; i += TB) {
-                uint32_t cu; const int r = (int)fdivmod((uint32_t)i, A.dW, cu); const int c = (int)cu;
-                int v = 255;
-                for (int d = -2; d <= 2; ++d) { int cc = c + d; if ((unsigned)cc < (unsigned)A.w) v = min(v, (int)m0[r * A.w + cc]); }
-                m1[i] = (uint8_t)v;
-            }
+            close_pass<false, true>(m0, m1, A.h, A.w);     // erode
             __syncthreads();
-            for (int i = tid; i < hw; i += TB) {
-                uint32_t cu; const int r = (int)fdivmod((uint32_t)i, A.dW, cu); const int c = (int)cu;
-                int v = 255;
-                for (int d = -2; d <= 2; ++d) { int rr = r + d; if ((unsigned)rr < (unsigned)A.h) v = min(v, (int)m1[rr * A.w + c]); }
-                m0[i] = (uint8_t)v;
-            }
+            close_pass<false, false>(m1, m0, A.h, A.w);
             __syncthreads();
         }
         copy_bytes(map, m0, hw);

@@ -232,36 +232,6 @@ __global__ __launch_bounds__(256) void k_centre_nearest(const uint8_t *__restric
 // --------------------------------------------------------------------------------------
 // k_compact: non-zero pixels in raster order
 // --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TB) void k_compact(TailArgs A) {
-    const int f = blockIdx.x;
-    if (A.depth[f] != A.round) return;
-    __shared__ int lds16[NW16];
-    const int hw = A.h * A.w;
-    const uint8_t *map = A.maps + (size_t)f * hw;
-    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
-    uint32_t *pts = (uint32_t *)(ws + A.L.pts);
-    int32_t *hdr = (int32_t *)(ws + A.L.hdr);
-    const int per = (hw + TB - 1) / TB;
-    const int lo = min(hw, (int)threadIdx.x * per), hi = min(hw, lo + per);
-    int cnt = 0;
-    for (int i = lo; i < hi; ++i) cnt += map[i] != 0;
-    int total;
-    int pos = block_excl_scan(cnt, lds16, &total);
-    for (int i = lo; i < hi; ++i) {
-        uint32_t v = map[i];
-        if (v) {
-            uint32_t c; const uint32_t r = fdivmod((uint32_t)i, A.dW, c);
-            pts[pos++] = r | (c << 8) | (v << 16);
-        }
-    }
-    if (threadIdx.x == 0) {
-        hdr[0] = total;
-        hdr[1] = 0;
-        hdr[2] = -1;
-        hdr[3] = (A.clust_filt && total > A.mcs + 1) ? 1 : 0;
-    }
-}
-
 // map <-> LDS copies, 8 bytes per lane when the map allows it (a 140x250 map does), bytes otherwise
 __device__ __forceinline__ void copy_bytes(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int n) {
     if ((((uintptr_t)src | (uintptr_t)dst) & 7) == 0) {
@@ -270,6 +240,41 @@ __device__ __forceinline__ void copy_bytes(uint8_t *__restrict__ dst, const uint
         for (int i = (n8 << 3) + threadIdx.x; i < n; i += TB) dst[i] = src[i];
     } else {
         for (int i = threadIdx.x; i < n; i += TB) dst[i] = src[i];
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_compact(TailArgs A) {
+    const int f = blockIdx.x;
+    if (A.depth[f] != A.round) return;
+    __shared__ int lds16[NW16];
+    extern __shared__ uint8_t sm_compact[];                  // the map: read once with whole lines, scanned from LDS
+    const int hw = A.h * A.w;
+    const uint8_t *gmap = A.maps + (size_t)f * hw;
+    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
+    uint32_t *pts = (uint32_t *)(ws + A.L.pts);
+    int32_t *hdr = (int32_t *)(ws + A.L.hdr);
+    uint8_t *map = sm_compact;
+    copy_bytes(map, gmap, hw);
+    __syncthreads();
+    const int per = (hw + TB - 1) / TB;
+    const int lo = min(hw, (int)threadIdx.x * per), hi = min(hw, lo + per);
+    int cnt = 0;
+    for (int i = lo; i < hi; ++i) cnt += map[i] != 0;
+    int total;
+    int pos = block_excl_scan(cnt, lds16, &total);
+    if (cnt) {
+        uint32_t c; uint32_t r = fdivmod((uint32_t)lo, A.dW, c);     // one division per thread, then walk
+        for (int i = lo; i < hi; ++i) {
+            const uint32_t v = map[i];
+            if (v) pts[pos++] = r | (c << 8) | (v << 16);
+            if (++c == (uint32_t)A.w) { c = 0; ++r; }
+        }
+    }
+    if (threadIdx.x == 0) {
+        hdr[0] = total;
+        hdr[1] = 0;
+        hdr[2] = -1;
+        hdr[3] = (A.clust_filt && total > A.mcs + 1) ? 1 : 0;
     }
 }
 
@@ -1254,7 +1259,7 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
         }
         {
             ProfScope ps(h, SVC_K_COMPACT, s);
-            k_compact<<<n, TB, 0, s>>>(A);
+            k_compact<<<n, TB, (size_t)(hw + 15) / 16 * 16, s>>>(A);
             SVC_CHECK_LAUNCH();
         }
         if (params->clust_filt) {

@@ -43,6 +43,23 @@ def test_smart_vid_crop_matches_oracle_boxes(engine, synthetic_sd, tmp_path):
     assert VD2['bbs'] == VD['bbs']
 
 
+def test_other_frame_shapes_match_oracle_boxes(engine, synthetic_sd):
+    """Portrait and 4:3 sources: other saliency sizes (250x140, 187x250), other network inputs (416x256, 288x384),
+    other tile / patch edge cases in every kernel."""
+    torch.set_num_threads(8)
+    for (h, w, ratio, seed) in ((640, 360, '1:1', 11), (480, 640, '9:16', 12)):
+        video = dict(fr=25.0, frame_count=36, w=w, h=h, frames=synth.blob_frames(36, h, w, seed=seed), trans_inds=[0, 14, 36])
+        CP = S.sc_init_crop_params()
+        CP['out_ratio'] = ratio
+        VD, _ = S.smart_vid_crop(video, CP, save_vid=False, engine=engine)
+        ref = P.smart_vid_crop(video, dict(P.init_crop_params(), out_ratio=ratio), synthetic_sd)
+        assert (VD['h_process'], VD['w_process']) == (ref['h_process'], ref['w_process'])
+        got, exp = np.array(VD['bbs']), np.array(ref['bbs'])
+        assert got.shape == exp.shape == (36, 4) and np.abs(got - exp).max() <= 1
+        d = np.abs(VD['smaps'].astype(int) - ref['smaps'].astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 5e-3
+
+
 def test_pickle_door_and_error_conventions(engine, tmp_path):
     import pickle
     video = _video(30, 6, [0, 30])

@@ -195,6 +195,27 @@ def test_tail_ragged_sizes_and_sparse_points(engine):
         _check_tail(engine, m, np.array([0, 1, 0], np.uint8), CP)
 
 
+def test_tail_randomised_maps_bit_exact(engine):
+    """Many small maps of mixed texture (blobs, speckle, stripes, ties everywhere) and several parameter sets:
+    point lists, core distances, Prim order, hierarchy, selection, CLOSE and centres must all agree with the oracle."""
+    rng = np.random.RandomState(2024)
+    for trial, (mcs, ms, ssum, close) in enumerate([(26, None, 2, True), (5, 3, 1, True), (12, 4, 2, False), (3, 2, 1, True)]):
+        h, w = int(rng.randint(24, 70)), int(rng.randint(24, 90))
+        maps = np.zeros((8, h, w), np.uint8)
+        ys, xs = np.mgrid[0:h, 0:w]
+        for i in range(8):
+            m = rng.rand(h, w) < rng.choice([0.0, 0.03, 0.15, 0.5])
+            for _ in range(rng.randint(0, 4)):
+                cy, cx, ry, rx = rng.randint(0, h), rng.randint(0, w), rng.randint(2, 12), rng.randint(2, 16)
+                m |= (((ys - cy) / ry) ** 2 + ((xs - cx) / rx) ** 2) < 1
+            if i == 5:
+                m = (xs % 4 == 0)                                  # stripes: every distance ties
+            maps[i] = np.where(m, rng.randint(121, 256, (h, w)), rng.randint(0, 120, (h, w))).astype(np.uint8)
+        flags = (rng.rand(8) < 0.4).astype(np.uint8)
+        CP = dict(P.init_crop_params(), hdbscan_min=mcs, hdbscan_min_samples=ms, select_sum=ssum, op_close=close)
+        _check_tail(engine, maps, flags, CP)
+
+
 def test_tail_maximum_size_all_pixels_set(engine):
     """N = 35 000 points (every pixel above the threshold): the largest problem a 140x250 map can pose.
     Takes the global-memory forms of Prim (N > 32 768) and of the hierarchy (N > 4 352), and every

@@ -739,8 +739,10 @@ __global__ __launch_bounds__(256) void k_upsample2x(const float *__restrict__ X,
 
 // adaptation: logit[p] = sum_c X[p][c] * w[c] + b, C = 64
 __global__ __launch_bounds__(256) void k_adapt(const float *__restrict__ X, const float *__restrict__ w,
-                                               const float *__restrict__ b, float *__restrict__ Y, size_t npix) {
+                                               const float *__restrict__ b, float *__restrict__ Y, size_t npix,
+                                               unsigned *__restrict__ fmax, int n) {
     size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid < (size_t)n) fmax[gid] = 0;                     // per-frame running maximum of k_smooth_down (encoded floats)
     if (gid >= npix) return;
     const float4 *x = (const float4 *)(X + gid * 64);
     const float4 *w4 = (const float4 *)w;
@@ -846,6 +848,7 @@ struct NetPlan {
     int hks = 0, vks = 0, lz_rows = 8, lz_tile_cap = 0;       // output rows per workgroup of k_lanczos_norm (SVC_LZ_ROWS)
     int sd_rows = 7, sd_tile_cap = 0;                         // output rows per workgroup of k_smooth_down (SVC_SD_ROWS)
     int last_n = 0;
+    int gauss_filled = 0;          // frames of the workspace whose Gaussian-prior channels of CAT1 are already written
     float *buf(int b) const { return (float *)ws.p + off[b] * (size_t)nb; }
     size_t per_frame(int b) const { return off[b + 1] - off[b]; }
 };
@@ -877,6 +880,7 @@ static int build_plan(SvcHandle *h, int height, int width, int nb) {
     NetPlan *p = h->plan;
     if (!p) p = h->plan = new NetPlan();
     if (p->h == height && p->w == width && p->nb >= nb) return SVC_OK;
+    p->gauss_filled = 0;            // the workspace layout (and possibly the maps) change below
     int NH, NW;
     optimal_out_size(height, width, NH, NW);
     const bool same_size = (p->h == height && p->w == width);
@@ -1739,11 +1743,12 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     RC(launch_pw(h, s, p->buf(B_F4X), 64, next(), nullptr, 0, p->buf(B_S4E), 128, n * H3 * W3, n));
     RC(launch_pw(h, s, p->buf(B_S4E), 128, next(), nullptr, 0, CAT3 + 128, 192, n * H3 * W3, n));
     next();   // GAUSS placeholder layer (raw parameters; maps live in plan->gauss)
-    {
+    if (p->gauss_filled < n) {       // the prior maps are constants: nothing else writes channels 1280..1295 of CAT1
         ProfScope ps(h, SVC_K_RESAMPLE, s);
         k_gauss_fill<<<blocks256((size_t)n * H5 * W5 * 16), 256, 0, s>>>((const float *)p->gauss.p, CAT1, n, H5 * W5,
                                                                          1296, 1280);
         SVC_CHECK_LAUNCH();
+        p->gauss_filled = n;
     }
     // post_cnn
     if (h->dwpw && H5 * W5 >= h->dwpw_min_px) {
@@ -1806,12 +1811,11 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     {
         ProfScope ps(h, SVC_K_RESAMPLE, s);
         k_adapt<<<blocks256((size_t)n * H3 * W3), 256, 0, s>>>(p->buf(B_DEC), La.w.dev, La.b.dev, p->buf(B_LOGIT),
-                                                              (size_t)n * H3 * W3);
+                                                              (size_t)n * H3 * W3, (unsigned *)p->fmax.p, n);
         SVC_CHECK_LAUNCH();
     }
     // B_LOGIT per-frame stride may exceed H3*W3 (rounded to 4): compact layout is used instead
     const SvcLayer &Ls = next();
-    SVC_HIP(hipMemsetAsync(p->fmax.p, 0, (size_t)n * sizeof(unsigned), s));
     ProfScope ps_smooth(h, SVC_K_SMOOTH, s);
     {
         dim3 grid(ceil_div(p->h, p->sd_rows), n);

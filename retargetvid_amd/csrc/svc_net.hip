@@ -273,6 +273,75 @@ __global__ __launch_bounds__(256) void k_stem(const float *__restrict__ X, const
     *(float4 *)(Y + gid * 4) = acc;
 }
 
+// features.0 on the matrix cores: one workgroup = 8 x 16 output pixels.  The 17 x 33 x 3 input patch is read once
+// (whole rows, coalesced) into LDS; every lane owns one output pixel and gathers its 27 taps (K padded to 32) from
+// the patch as the B operand of sixteen 32x32x2 MFMAs against the transposed weights (A operand, four float4 per
+// lane, loaded once).  With the operands this way round a lane ends with all 32 channels of its pixel in runs of
+// four: bias, ReLU6 and 128 contiguous bytes per pixel as float4 stores.  k_stem (FMA form) issues 27 scalar loads
+// and 27 LDS weight reads per 4 outputs and runs at a third of the HBM rate.
+#define STEM_TH 8
+#define STEM_TW 16
+#define STEM_PRS 100      // floats per patch row: (2 * 16 + 1) pixels x 3 channels = 99
+__global__ __launch_bounds__(256) void k_stem_mfma(const float *__restrict__ X, const float *__restrict__ Wtr,
+                                                   const float *__restrict__ bias, float *__restrict__ Y, int NH,
+                                                   int NW, int OH, int OW, int tiles_x, int tiles_y) {
+    constexpr int PR = 2 * STEM_TH + 1, PCW = 2 * STEM_TW + 1;
+    __shared__ float Pin[PR * STEM_PRS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y, f = bid / tiles_y;
+    const int oy0 = ty * STEM_TH, ox0 = tx * STEM_TW, py0 = 2 * oy0 - 1, px0 = 2 * ox0 - 1;
+    const float *xin = X + (size_t)f * NH * NW * 3;
+    for (int idx = tid; idx < PR * PCW * 3; idx += 256) {
+        const int pr = idx / (PCW * 3), rem = idx - pr * (PCW * 3), pc = rem / 3;
+        const int y = py0 + pr, x = px0 + pc;
+        float v = 0.f;                                       // the conv's zero padding and the ragged right / bottom edge
+        if ((unsigned)y < (unsigned)NH && (unsigned)x < (unsigned)NW) v = xin[((long long)y * NW + px0) * 3 + rem];
+        Pin[pr * STEM_PRS + rem] = v;
+    }
+    // A operand: weights of output channel r, taps 4hh + 8q .. + 3
+    float4 wv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wv[q] = *(const float4 *)(Wtr + r * 32 + 8 * q + 4 * hh);
+    __syncthreads();
+    // B operand: this lane's pixel = 32 * wave + r of the tile
+    const int p = 32 * wave + r, py = p / STEM_TW, px = p - py * STEM_TW;
+    const float *src = Pin + (2 * py) * STEM_PRS + (2 * px) * 3;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 8 * q + 4 * hh + e;                // tap (ky, kx, ci) = (k / 9, (k % 9) / 3, k % 3): offset k + 91 * ky
+            const int ky = (k * 57) >> 9;
+            t[e] = k < 27 ? src[k + (STEM_PRS - 9) * ky] : 0.f;
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[q].x, t[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[q].y, t[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[q].z, t[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[q].w, t[3], acc, 0, 0, 0);
+    }
+    const int oy = oy0 + py, ox = ox0 + px;
+    if (oy >= OH || ox >= OW) return;
+    float *yp = Y + (((size_t)f * OH + oy) * OW + ox) * 32;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c = 8 * g + 4 * hh;
+        const float4 b = *(const float4 *)(bias + c);
+        float4 v;
+        v.x = fminf(fmaxf(acc[4 * g] + b.x, 0.f), 6.f);
+        v.y = fminf(fmaxf(acc[4 * g + 1] + b.y, 0.f), 6.f);
+        v.z = fminf(fmaxf(acc[4 * g + 2] + b.z, 0.f), 6.f);
+        v.w = fminf(fmaxf(acc[4 * g + 3] + b.w, 0.f), 6.f);
+        *(float4 *)(yp + c) = v;
+    }
+}
+
 // --------------------------------------------------------------------------------------
 // pointwise conv as a GEMM on the f32 MFMA:  Y[M,N] = act(X[M,K] * W[N,K]^T + b) (+ R)
 // Block = 4 waves; wave v owns rows m0+32v..+31 and TN column tiles of 32.
@@ -1681,8 +1750,14 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     const bool stem_fused = h->stem_fused && h->fuse_max >= 1;
     if (!stem_fused) {
         ProfScope ps(h, SVC_K_STEM, s);
-        k_stem<<<blocks256((size_t)n * H * W * 8), 256, 0, s>>>(IN, Lstem.w.dev, Lstem.b.dev, P[0], n, NH, NW, H, W,
-                                                                make_fdiv(W), make_fdiv(H));
+        if (h->stem_mfma) {
+            const int tx = ceil_div(W, STEM_TW), ty = ceil_div(H, STEM_TH);
+            k_stem_mfma<<<dim3((unsigned)(n * tx * ty)), 256, 0, s>>>(IN, (const float *)h->stem_wt.p, Lstem.b.dev, P[0], NH, NW,
+                                                                     H, W, tx, ty);
+        } else {
+            k_stem<<<blocks256((size_t)n * H * W * 8), 256, 0, s>>>(IN, Lstem.w.dev, Lstem.b.dev, P[0], n, NH, NW, H, W,
+                                                                    make_fdiv(W), make_fdiv(H));
+        }
         SVC_CHECK_LAUNCH();
     }
     int cur = 0;
@@ -1941,6 +2016,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->split_up = atoi(env) != 0;
     env = getenv("SVC_IRB_FIXED");
     if (env) h->irb_fixed = atoi(env) != 0;
+    env = getenv("SVC_STEM_MFMA");
+    if (env) h->stem_mfma = atoi(env);
     env = getenv("SVC_STEM_FUSED");
     if (env) h->stem_fused = atoi(env) != 0;
     env = getenv("SVC_DWPW");
@@ -1970,6 +2047,16 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
         SvcLayer L{SvcLayer::STEM, 3, 32, 2, 1, {}, {}};
         if ((rc = take(h, ti, 27 * 32, L.w, "stem.w")) || (rc = take(h, ti, 32, L.b, "stem.b"))) return fail(rc);
         h->layers.push_back(L);
+        // [27 taps][32 out] -> [32 out][32 taps] for k_stem_mfma
+        const float *w_host = (const float *)blob_host + (L.w.dev - (const float *)h->blob.p);
+        std::vector<float> wt(32 * 32, 0.f);
+        for (int k = 0; k < 27; ++k)
+            for (int co = 0; co < 32; ++co) wt[co * 32 + k] = w_host[k * 32 + co];
+        if ((rc = h->stem_wt.ensure(wt.size() * 4))) return fail(rc);
+        if (hipMemcpy(h->stem_wt.p, wt.data(), wt.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            svc_set_error("svc_create: stem weight upload failed");
+            return fail(SVC_E_HIP);
+        }
     }
     static const int T[7] = {1, 6, 6, 6, 6, 6, 6}, Cc[7] = {16, 24, 32, 64, 96, 160, 320}, Nn[7] = {1, 2, 3, 4, 3, 3, 1},
                      Ss[7] = {1, 2, 2, 2, 1, 2, 1};
@@ -2039,6 +2126,8 @@ extern "C" int svc_destroy(SvcHandle *h) {
     svc_net_release(h);
     h->tail_ws.release();
     h->tail_offsets.release();
+    h->tail_delta.release();
+    h->stem_wt.release();
     h->rs_maps.release(); h->rs_down.release(); h->rs_up.release();
     if (h->depth_pinned) (void)hipHostFree(h->depth_pinned);
     h->blob.release();

@@ -124,6 +124,7 @@ struct SvcHandle {
     bool split_up = true;              // decoder expansions as conv(skip) + up-sample(conv(low-res part)) (SVC_SPLIT_UP=0: up-sample, concatenate, one GEMM)
     bool irb_fixed = true;             // fused blocks of the six MobileNetV2 shapes run compile-time-shaped instances (SVC_IRB_FIXED=0: generic)
     DevBuf stem_wt;                    // stem weights transposed to [32 out][32 taps, 27 used] for the MFMA stem
+    int smooth_mfma = 1;               // 41x41 smoothing phases as a GEMM on the matrix cores (SVC_SMOOTH_MFMA=0: the FMA kernel)
     int stem_mfma = 1;                 // features.0 as MFMA im2col tiles (SVC_STEM_MFMA=0: the FMA kernel k_stem)
     bool stem_fused = false;           // features.0 computed inside the kernel of backbone block 1 (SVC_STEM_FUSED=1); measured equal to k_stem + block 1 at B=32 (146 vs 151 us), 218 MB less HBM traffic per 32 frames
     bool dwpw = true;                  // depthwise 3x3 fused into the following 1x1 project (SVC_DWPW=0: two kernels)

@@ -838,6 +838,95 @@ __device__ __forceinline__ float dec_f32(unsigned u) {
 // nearest x8 -> replicate pad 20 -> 41x41 conv, evaluated as 64 phase kernels of 7x7
 // low-res taps, then bilinear (align_corners=False) down to (h, w).  One block = one
 // frame x rows_per_block output rows; the needed rows of the NHxNW map live in LDS.
+// The same on the matrix cores.  For one low-resolution cell (cy, cx) the 64 outputs of its 8 x 8 block are
+// 64 different 7x7 kernels ("phases") applied to the same 49 logits: a GEMM [cells x 49] . [49 x 64 phases].  A lane
+// owns one cell (B operand: its 49 logits gathered from LDS once, taps padded to 56), the phase kernels are the A
+// operand (padded copy in LDS, float4 reads); the accumulator then holds, per lane, 16 phases in runs of four
+// consecutive px -- float4 writes into the smoothed-row tile.  The bilinear down-scale and the running maximum are
+// those of k_smooth_down.  The sum over the 49 taps is grouped by the MFMA (pairs of taps) instead of one chain of
+// FMAs, a difference of a few ulp.
+#define SD_KP 56          // taps per phase, padded to a multiple of 8
+__global__ __launch_bounds__(256) void k_smooth_down_mfma(const float *__restrict__ logit, const float *__restrict__ phase,
+                                                          float *__restrict__ pre, unsigned *__restrict__ fmax, int LH,
+                                                          int LW, int NH, int NW, int h, int w, int rows_per_block,
+                                                          int tile_cap, FDiv dw) {
+    extern __shared__ float sm[];
+    float *L = sm, *ph = sm + LH * LW, *tile = ph + 64 * SD_KP;
+    __shared__ unsigned wmax[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int f = blockIdx.y;
+    const int oy0 = blockIdx.x * rows_per_block, oy1 = min(h, oy0 + rows_per_block);
+    const float scy = (float)NH / (float)h, scx = (float)NW / (float)w;
+    const int ylo = (int)fmaxf(scy * (oy0 + 0.5f) - 0.5f, 0.f);
+    const int yhi = min((int)fmaxf(scy * ((oy1 - 1) + 0.5f) - 0.5f, 0.f) + 1, NH - 1);
+    const int nrows = min(yhi - ylo + 1, tile_cap);
+    for (int i = tid; i < LH * LW; i += 256) L[i] = logit[(size_t)f * LH * LW + i];
+    for (int i = tid; i < 64 * SD_KP; i += 256) {
+        const int p = i / SD_KP, k = i - p * SD_KP;
+        ph[i] = k < 49 ? phase[p * 49 + k] : 0.f;
+    }
+    __syncthreads();
+    const int cy_lo = ylo >> 3, cy_hi = (ylo + nrows - 1) >> 3;
+    const int ncell = (cy_hi - cy_lo + 1) * LW;
+    const int mtiles = (ncell + 31) >> 5;
+    for (int mt = wave; mt < mtiles; mt += 4) {
+        // this lane's cell and its logits for the taps k = 8q + 4hh + e (clamped at the borders: replicate padding)
+        const int cell = min(mt * 32 + r, ncell - 1);
+        const int cy = cy_lo + cell / LW, cx = cell % LW;
+        float bv[7][4];
+#pragma unroll
+        for (int q = 0; q < 7; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 8 * q + 4 * hh + e;
+                const int a = (k * 37) >> 8, b = k - 7 * a;          // k / 7 for k < 56
+                const int yy = min(max(cy + a - 3, 0), LH - 1), xx = min(max(cx + b - 3, 0), LW - 1);
+                bv[q][e] = k < 49 ? L[yy * LW + xx] : 0.f;
+            }
+        const bool live = mt * 32 + r < ncell;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {                             // phases 32 nt .. 32 nt + 31 = py 4 nt .. 4 nt + 3
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            const float *ap = ph + (nt * 32 + r) * SD_KP + 4 * hh;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const float4 av = *(const float4 *)(ap + 8 * q);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[q][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[q][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[q][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[q][3], acc, 0, 0, 0);
+            }
+            if (!live) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                            // accumulator 4g + j = phase (py = 4 nt + g, px = 4 hh + j)
+                const int y = cy * 8 + 4 * nt + g - ylo;
+                if (y < 0 || y >= nrows) continue;
+                *(float4 *)(tile + y * NW + cx * 8 + 4 * hh) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+            }
+        }
+    }
+    __syncthreads();
+    float lmax = -INFINITY;
+    for (int idx = tid; idx < (oy1 - oy0) * w; idx += 256) {
+        uint32_t ox;
+        const int oy = oy0 + (int)fdivmod((uint32_t)idx, dw, ox);
+        float sy = fmaxf(scy * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(scx * (ox + 0.5f) - 0.5f, 0.f);
+        int y0 = (int)sy, x0 = (int)sx;
+        int y1 = y0 + (y0 < NH - 1 ? 1 : 0), x1 = x0 + (x0 < NW - 1 ? 1 : 0);
+        float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float *t0 = tile + (y0 - ylo) * NW, *t1 = tile + (y1 - ylo) * NW;
+        float v = ly0 * (lx0 * t0[x0] + lx1 * t0[x1]) + ly1 * (lx0 * t1[x0] + lx1 * t1[x1]);
+        pre[((size_t)f * h + oy) * w + ox] = v;
+        lmax = fmaxf(lmax, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if ((tid & 63) == 0) wmax[tid >> 6] = enc_f32(lmax);
+    __syncthreads();
+    if (tid == 0) atomicMax(fmax + f, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+}
+
 __global__ __launch_bounds__(256) void k_smooth_down(const float *__restrict__ logit, const float *__restrict__ phase,
                                                      float *__restrict__ pre, unsigned *__restrict__ fmax, int LH,
                                                      int LW, int NH, int NW, int h, int w, int rows_per_block,
@@ -1894,9 +1983,15 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     ProfScope ps_smooth(h, SVC_K_SMOOTH, s);
     {
         dim3 grid(ceil_div(p->h, p->sd_rows), n);
-        size_t lds = ((size_t)H3 * W3 + 64 * 49 + (size_t)p->sd_tile_cap * NW) * sizeof(float);
-        k_smooth_down<<<grid, 256, lds, s>>>(p->buf(B_LOGIT), Ls.w.dev, p->buf(B_PRE), (unsigned *)p->fmax.p, H3, W3, NH,
-                                             NW, p->h, p->w, p->sd_rows, p->sd_tile_cap, make_fdiv(NW), make_fdiv(p->w));
+        if (h->smooth_mfma && NW % 8 == 0 && NW == 8 * W3 && NH == 8 * H3) {
+            size_t lds = ((size_t)H3 * W3 + 64 * SD_KP + (size_t)p->sd_tile_cap * NW) * sizeof(float);
+            k_smooth_down_mfma<<<grid, 256, lds, s>>>(p->buf(B_LOGIT), Ls.w.dev, p->buf(B_PRE), (unsigned *)p->fmax.p, H3, W3,
+                                                      NH, NW, p->h, p->w, p->sd_rows, p->sd_tile_cap, make_fdiv(p->w));
+        } else {
+            size_t lds = ((size_t)H3 * W3 + 64 * 49 + (size_t)p->sd_tile_cap * NW) * sizeof(float);
+            k_smooth_down<<<grid, 256, lds, s>>>(p->buf(B_LOGIT), Ls.w.dev, p->buf(B_PRE), (unsigned *)p->fmax.p, H3, W3, NH,
+                                                 NW, p->h, p->w, p->sd_rows, p->sd_tile_cap, make_fdiv(NW), make_fdiv(p->w));
+        }
         SVC_CHECK_LAUNCH();
     }
     k_quantise<<<blocks256((size_t)n * p->h * p->w), 256, 0, s>>>(p->buf(B_PRE), (const unsigned *)p->fmax.p, maps, n,
@@ -2016,6 +2111,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->split_up = atoi(env) != 0;
     env = getenv("SVC_IRB_FIXED");
     if (env) h->irb_fixed = atoi(env) != 0;
+    env = getenv("SVC_SMOOTH_MFMA");
+    if (env) h->smooth_mfma = atoi(env);
     env = getenv("SVC_STEM_MFMA");
     if (env) h->stem_mfma = atoi(env);
     env = getenv("SVC_STEM_FUSED");

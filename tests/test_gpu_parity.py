@@ -103,7 +103,7 @@ def test_saliency_batch_and_chunk_independence(engine):
     {'SVC_FUSE_MAX': '13'},                                 # every block that can be fused is
     {'SVC_SPLIT_UP': '0'},                                  # decoder: up-sample + concatenate + one GEMM (the reference's order)
     {'SVC_IRB_FIXED': '0'},                                 # generic (run-time shaped) fused block instead of the fixed-shape instances
-    {'SVC_STEM_MFMA': '0'},                                 # features.0 as the FMA kernel
+    {'SVC_STEM_MFMA': '0', 'SVC_SMOOTH_MFMA': '0'},          # features.0 and the 41x41 smoothing as FMA kernels                                 # features.0 as the FMA kernel
     {'SVC_STEM_FUSED': '1'},                                # features.0 inside the kernel of block 1 (MFMA im2col form)
     {'SVC_CHUNK': '5'},                                     # ragged chunks of the batch
 ])

@@ -38,6 +38,7 @@
 namespace hdb {
 
 static const uint32_t NONE16 = 0xFFFFu;
+static const uint32_t NO_LANE = 0xFFFFFFFFu;     // absw[] of an un-absorbed root: no edge of the current batch contains it
 static const int32_t ROOT_NOISE = -2;
 
 struct Edge {          // 8 bytes
@@ -128,7 +129,7 @@ SVC_HD void init_points(Tree &t, int lo, int hi) {      // callable by many thre
         t.sp[i] = (uint16_t)i;
         t.ssz[i] = 1;
         t.absc[i] = (uint16_t)NONE16;
-        t.absw[i] = 0;
+        t.absw[i] = NO_LANE;       // doubles as the per-batch "first edge containing this root" table (build_batched)
         t.sdn[i] = (uint32_t)i;
     }
 }
@@ -251,15 +252,38 @@ inline bool build_batched(Tree &t, const Edge *edges, int n, int mcs) {
     while (i0 < n - 1) {
         const int m = (n - 1 - i0) < B ? (n - 1 - i0) : B;
         for (int j = 0; j < m; ++j) pre[j] = resolve_ro(t, edges[i0 + j]);
+        // Which sides are big when an edge's turn comes?  A root that is still small at the start of the batch is
+        // absorbed by the FIRST edge of the batch that contains it: at that edge's turn the root's side cannot be big
+        // yet, so the edge either absorbs it (its other side is big) or joins two small components and ends the
+        // prefix.  Hence, for every edge up to the end of the prefix,
+        //     big(side) = big at the start of the batch  ||  first edge containing the side's root < this edge,
+        // with no reference to the order of evaluation: one scatter-min of lane numbers per root (the table lives in
+        // absw[], which is meaningless for un-absorbed roots and is restored to "none" below), then P by a ballot and
+        // the clusters by following the "first edge" links (pointer jumping on the device).
+        for (int j = 0; j < m; ++j) {
+            if (pre[j].ca == NONE16 && (uint32_t)j < t.absw[pre[j].ra]) t.absw[pre[j].ra] = (uint32_t)j;
+            if (pre[j].cb == NONE16 && (uint32_t)j < t.absw[pre[j].rb]) t.absw[pre[j].rb] = (uint32_t)j;
+        }
+        uint32_t fa[B], fb[B];
+        for (int j = 0; j < m; ++j) {
+            fa[j] = pre[j].ca == NONE16 ? t.absw[pre[j].ra] : (uint32_t)j;
+            fb[j] = pre[j].cb == NONE16 ? t.absw[pre[j].rb] : (uint32_t)j;
+        }
+        for (int j = 0; j < m; ++j) {                  // restore the table
+            if (pre[j].ca == NONE16) t.absw[pre[j].ra] = NO_LANE;
+            if (pre[j].cb == NONE16) t.absw[pre[j].rb] = NO_LANE;
+        }
         int P = m;
-        for (int k = 0; k < m; ++k) {
-            const bool abig = pre[k].ca != NONE16, bbig = pre[k].cb != NONE16;
-            if (abig == bbig) { P = k; break; }
-            const uint32_t ck = abig ? pre[k].ca : pre[k].cb, rk = abig ? pre[k].rb : pre[k].ra;
-            for (int j = k + 1; j < m; ++j) {
-                if (pre[j].ra == rk) pre[j].ca = ck;
-                if (pre[j].rb == rk) pre[j].cb = ck;
-            }
+        for (int j = 0; j < m; ++j) {
+            const bool abig = pre[j].ca != NONE16 || fa[j] < (uint32_t)j, bbig = pre[j].cb != NONE16 || fb[j] < (uint32_t)j;
+            if (abig == bbig) { P = j; break; }
+        }
+        uint32_t cl[B];                                // cluster an edge of the prefix falls into
+        for (int j = 0; j <= P && j < m; ++j) {
+            // a side absorbed inside the batch takes the cluster of the edge that absorbed it (an earlier lane)
+            if (pre[j].ca == NONE16 && fa[j] < (uint32_t)j) pre[j].ca = cl[fa[j]];
+            if (pre[j].cb == NONE16 && fb[j] < (uint32_t)j) pre[j].cb = cl[fb[j]];
+            if (j < P) cl[j] = pre[j].ca != NONE16 ? pre[j].ca : pre[j].cb;
         }
         for (int j = 0; j < P; ++j) {                  // independent per j on the device
             const Resolved &q = pre[j];

@@ -739,23 +739,42 @@ __device__ __forceinline__ bool build_wave(hdb::Tree &t, const hdb::Edge *edges,
             pre = hdb::resolve_ro(t, e);
         }
         const uint32_t v_r = pre.ra | (pre.rb << 16);
-        // the scan: straight-line steps (four v_readlane, scalar selects, two v_cndmask; no exec-mask handling, one taken
-        // branch): ~28 instructions = ~240 cycles per edge on a lone wavefront -- the floor of this formulation
-        uint32_t cur_a = pre.ca, cur_b = pre.cb;
-        int P = m;
-        for (int k = 0; k < m; ++k) {
-            const uint32_t ska = (uint32_t)__builtin_amdgcn_readlane((int)cur_a, k);
-            const uint32_t skb = (uint32_t)__builtin_amdgcn_readlane((int)cur_b, k);
-            const uint32_t sra = (uint32_t)__builtin_amdgcn_readlane((int)pre.ra, k);
-            const uint32_t srb = (uint32_t)__builtin_amdgcn_readlane((int)pre.rb, k);
-            const bool abig = ska != hdb::NONE16, bbig = skb != hdb::NONE16;
-            if (abig == bbig) { P = k; break; }
-            const uint32_t ck = abig ? ska : skb, rk = abig ? srb : sra;
-            const bool later = lane > k;                 // sides rooted at rk belong to ck from here on
-            cur_a = (later & (pre.ra == rk)) ? ck : cur_a;
-            cur_b = (later & (pre.rb == rk)) ? ck : cur_b;
+        // Which sides are big at an edge's turn, without walking the batch (hdb::build_batched has the argument): a
+        // root still small at the start of the batch is absorbed by the first edge that contains it, so
+        //     big(side) = big at the start  ||  first lane containing the side's root < this lane.
+        // The "first lane" table is absw[] (unused for un-absorbed roots): a scatter-min of lane numbers, read back
+        // with atomic loads (the minimum is formed in L2 / LDS, not in this CU's vector L1), then restored.
+        const bool in = lane < m;
+        const bool a_small = in && pre.ca == hdb::NONE16, b_small = in && pre.cb == hdb::NONE16;
+        if (a_small) atomicMin(&t.absw[pre.ra], (uint32_t)lane);
+        if (b_small) atomicMin(&t.absw[pre.rb], (uint32_t)lane);
+        uint32_t fa = (uint32_t)lane, fb = (uint32_t)lane;
+        if (a_small) fa = __hip_atomic_load(&t.absw[pre.ra], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b_small) fb = __hip_atomic_load(&t.absw[pre.rb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a_small) __hip_atomic_store(&t.absw[pre.ra], hdb::NO_LANE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b_small) __hip_atomic_store(&t.absw[pre.rb], hdb::NO_LANE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool big_a = in && (!a_small || fa < (uint32_t)lane), big_b = in && (!b_small || fb < (uint32_t)lane);
+        const unsigned long long stop = __ballot(in && big_a == big_b);
+        const int P = stop ? min(m, (int)__builtin_ctzll(stop)) : m;
+        // cluster of every edge of the prefix: its own if one side was big from the start, else that of the edge which
+        // absorbed its big side's root -- resolved by six rounds of pointer jumping along those links
+        uint32_t cval = hdb::NONE16, ptr = (uint32_t)lane;
+        if (lane < P) {
+            if (!a_small) cval = pre.ca;
+            else if (!b_small) cval = pre.cb;
+            else ptr = big_a ? fa : fb;
         }
-        const uint32_t v_c = cur_a | (cur_b << 16);
+#pragma unroll
+        for (int round = 0; round < 6; ++round) {
+            const uint32_t pv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ptr << 2), (int)cval);
+            const uint32_t pp = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ptr << 2), (int)ptr);
+            if (cval == hdb::NONE16) { cval = pv; ptr = pp; }
+        }
+        const uint32_t ga = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(min(fa, 63u) << 2), (int)cval);
+        const uint32_t gb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(min(fb, 63u) << 2), (int)cval);
+        const uint32_t cur_a = !a_small ? pre.ca : (fa < (uint32_t)lane ? ga : hdb::NONE16);
+        const uint32_t cur_b = !b_small ? pre.cb : (fb < (uint32_t)lane ? gb : hdb::NONE16);
+        const uint32_t v_c = (cur_a & 0xFFFFu) | (cur_b << 16);
         if (P > 0) {
             const bool act = lane < P;
             const uint32_t ca = v_c & 0xFFFFu, cb = v_c >> 16;

@@ -47,6 +47,8 @@ typedef struct SvcHandle SvcHandle;
 /* The crop parameters (sc_init_crop_params, smartVidCrop.py:132-209) that the
  * device path consumes. */
 typedef struct SvcParams {
+    uint32_t struct_size;         /* = sizeof(SvcParams) as the CALLER compiled it: a binding built against an older
+                                     layout is rejected with SVC_E_INVALID instead of being read past its end */
     int32_t hdbscan_min;          /* CP['hdbscan_min']  (min_cluster_size)             */
     int32_t hdbscan_min_samples;  /* CP['hdbscan_min_samples'], 0 = None               */
     int32_t select_sum;           /* CP['select_sum']: 1 = cluster sum, else cluster max */
@@ -62,6 +64,11 @@ typedef struct SvcParams {
 #define SVC_STATS_STRIDE 4
 
 const char *svc_last_error(void);
+
+/* ABI revision of the loaded library (bumped whenever a struct layout or a signature changes); a binding
+ * checks it once after dlopen.  2 = SvcParams starts with struct_size and carries resize_factor. */
+#define SVC_ABI_VERSION 2
+int svc_abi_version(void);
 
 /* weights_blob_host: the packed, BN-folded static SALICON slice of a UNISAL
  * checkpoint (retargetvid_amd.weights.pack_blob).  The blob is copied to `device`. */

@@ -9,15 +9,26 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsvc_hip.so')
 
-EXPORTS = ('svc_last_error', 'svc_create', 'svc_destroy', 'svc_resize_frames_u8', 'svc_saliency_u8',
+ABI_VERSION = 2          # include/svc.h SVC_ABI_VERSION this binding was written against
+
+EXPORTS = ('svc_last_error', 'svc_abi_version', 'svc_create', 'svc_destroy', 'svc_resize_frames_u8', 'svc_saliency_u8',
            'svc_threshold_u8', 'svc_cluster_center', 'svc_iou_i32', 'svc_debug_cluster_state', 'svc_debug_tap',
            'svc_profile_enable', 'svc_profile_read')
 
 
 class SvcParams(ctypes.Structure):
-    _fields_ = [('hdbscan_min', ctypes.c_int32), ('hdbscan_min_samples', ctypes.c_int32),
+    _fields_ = [('struct_size', ctypes.c_uint32), ('hdbscan_min', ctypes.c_int32), ('hdbscan_min_samples', ctypes.c_int32),
                 ('select_sum', ctypes.c_int32), ('op_close', ctypes.c_int32), ('clust_filt', ctypes.c_int32),
                 ('resize_factor', ctypes.c_int32)]
+
+
+def make_params(CP):
+    """SvcParams from a crop-parameter dict (sc_init_crop_params keys, smartVidCrop.py:132-209)."""
+    factor = CP.get('resize_factor', 1.0)
+    if float(factor) != int(factor) or (int(factor) != 1 and CP.get('resize_type', 1) != 1):
+        raise NotImplementedError('resize_factor must be an integer and resize_type 1 (bilinear)')
+    return SvcParams(ctypes.sizeof(SvcParams), int(CP['hdbscan_min']), int(CP['hdbscan_min_samples'] or 0),
+                     int(CP['select_sum']), int(bool(CP['op_close'])), int(bool(CP['clust_filt'])), int(factor))
 
 
 class SvcError(RuntimeError):
@@ -39,6 +50,11 @@ def load():
     vp, i32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     lib.svc_last_error.restype = ctypes.c_char_p
     lib.svc_last_error.argtypes = []
+    lib.svc_abi_version.argtypes = []
+    lib.svc_abi_version.restype = ctypes.c_int
+    if lib.svc_abi_version() != ABI_VERSION:
+        raise SvcError('%s has ABI version %d, this binding expects %d: rebuild the library'
+                       % (LIB_PATH, lib.svc_abi_version(), ABI_VERSION))
     lib.svc_create.argtypes = [vp, sz, i32, ctypes.POINTER(vp)]
     lib.svc_destroy.argtypes = [vp]
     lib.svc_resize_frames_u8.argtypes = [vp, vp, i32, i32, i32, vp, i32, i32, vp]
@@ -51,7 +67,7 @@ def load():
     lib.svc_profile_enable.argtypes = [vp, i32]
     lib.svc_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     for name in EXPORTS:
-        if name != 'svc_last_error':
+        if name not in ('svc_last_error', 'svc_abi_version'):
             getattr(lib, name).restype = i32
     _lib = lib
     return lib

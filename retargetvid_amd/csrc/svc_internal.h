@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <map>
+#include <set>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -105,14 +106,16 @@ struct SvcHandle {
     DevBuf tail_offsets;     // ring-walk offset table
     int tail_n_offsets = 0, tail_n_offsets1 = 0;
     std::vector<uint32_t> tail_offsets_host;
-    DevBuf tail_delta;       // dr * width + dc of every offset, for the map width of the last call
-    int tail_delta_w = -1;
+    std::map<int, DevBuf> tail_delta;  // dr * width + dc of every offset, one table per map width (never rewritten:
+                                       // a call still in flight on the stream may be reading the one it was given)
     int tail_frames = 0, tail_h = 0, tail_w = 0;
     size_t tail_frame_stride = 0;      // bytes of per-frame tail workspace
-    DevBuf rs_maps, rs_down, rs_up;    // resize_factor != 1: shrunk maps and the two INTER_LINEAR tables
-    int rs_h = 0, rs_w = 0, rs_factor = 0;
+    DevBuf rs_maps;                    // resize_factor != 1: the shrunk maps
+    std::map<std::tuple<int, int, int>, std::pair<DevBuf, DevBuf>> rs_tabs;   // (h, w, factor) -> INTER_LINEAR tables down / up
     uint8_t *depth_pinned = nullptr;   // pinned staging ring for the per-map round numbers
     unsigned depth_slot = 0;
+    hipEvent_t depth_ev[8] = {};       // recorded behind the upload of a slot; waited on before the slot is rewritten
+    std::set<const void *> lds_attr_done;   // kernels whose dynamic-LDS limit has been raised on this handle's device
     int chunk = 32;                    // frames per network pass
     int pw_min_wg = 1024;              // k_pw narrows its column tile until the grid has this many workgroups (SVC_PW_MIN_WG)
     bool pw_sk = true;                 // split-K pointwise kernel for long-K small-M layers (SVC_PW_SK=0 disables)

@@ -37,6 +37,7 @@ void svc_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 extern "C" const char *svc_last_error(void) { return g_err; }
+extern "C" int svc_abi_version(void) { return SVC_ABI_VERSION; }
 
 // --------------------------------------------------------------------------------------
 // ingest down-scale: OpenCV INTER_LINEAR on u8 (11-bit fixed-point weights)
@@ -1785,11 +1786,10 @@ static int launch_irb(SvcHandle *h, hipStream_t s, const float *X, int n, int H,
         const int tx = ceil_div(OW, TOW_), ty = ceil_div(OH, TOH_);                                                  \
         const size_t lds = IrbGeom<S_, TOH_, TOW_>::lds_floats(Cin, CoutP, EXP_) * 4;                                \
         auto kfn = k_irb<S_, TOH_, TOW_, EXP_, STEM_, CI_, CE_, CO_>;                                                \
-        static bool attr = false;                                                                                    \
-        if (!attr) {         /* tiles of the 96-channel blocks need more than the default 64 KB of dynamic LDS */    \
+        /* tiles of the 96-channel blocks need more than the default 64 KB of dynamic LDS; the attribute is per  */  \
+        /* device, so the once-flag lives in the handle (one handle = one device), not in the process            */  \
+        if (h->lds_attr_done.insert((const void *)kfn).second)                                                       \
             SVC_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024)); \
-            attr = true;                                                                                             \
-        }                                                                                                            \
         kfn<<<dim3((unsigned)(n * tx * ty)), 256, lds, s>>>(                                                          \
             X, H, W, Cin, EXP_ ? Le->w.dev : nullptr, EXP_ ? Le->b.dev : nullptr, Ce, Ld.w.dev, Ld.b.dev, Lp.w.dev,   \
             Lp.b.dev, Cout, CoutP, R, Y, Cout, OH, OW, tx, ty, STEM_ ? Lstem->w.dev : nullptr,                       \
@@ -2223,9 +2223,11 @@ extern "C" int svc_destroy(SvcHandle *h) {
     svc_net_release(h);
     h->tail_ws.release();
     h->tail_offsets.release();
-    h->tail_delta.release();
+    for (auto &kv : h->tail_delta) kv.second.release();
     h->stem_wt.release();
-    h->rs_maps.release(); h->rs_down.release(); h->rs_up.release();
+    h->rs_maps.release();
+    for (auto &kv : h->rs_tabs) { kv.second.first.release(); kv.second.second.release(); }
+    for (auto &e : h->depth_ev) if (e) (void)hipEventDestroy(e);
     if (h->depth_pinned) (void)hipHostFree(h->depth_pinned);
     h->blob.release();
     delete h;

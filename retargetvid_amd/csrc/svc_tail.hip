@@ -1173,17 +1173,20 @@ static int ensure_ring(SvcHandle *h) {
 }
 
 // linear offsets of the ring table for maps of this width (rebuilt only when the width changes)
-static int ensure_ring_delta(SvcHandle *h, int width) {
-    if (h->tail_delta_w == width) return SVC_OK;
+static int ensure_ring_delta(SvcHandle *h, int width, const int32_t **out) {
+    auto it = h->tail_delta.find(width);
+    if (it != h->tail_delta.end()) { *out = (const int32_t *)it->second.p; return SVC_OK; }
     std::vector<int32_t> d(h->tail_offsets_host.size());
     for (size_t i = 0; i < d.size(); ++i) {
         const uint32_t o = h->tail_offsets_host[i];
         d[i] = ((int)(o & 255) - 128) * width + ((int)((o >> 8) & 255) - 128);
     }
-    int rc = h->tail_delta.ensure(d.size() * 4);
+    DevBuf buf;                     // a fresh buffer: nothing in flight can be reading it during the upload
+    int rc = buf.ensure(d.size() * 4);
     if (rc) return rc;
-    SVC_HIP(hipMemcpy(h->tail_delta.p, d.data(), d.size() * 4, hipMemcpyHostToDevice));
-    h->tail_delta_w = width;
+    SVC_HIP(hipMemcpy(buf.p, d.data(), d.size() * 4, hipMemcpyHostToDevice));
+    h->tail_delta.emplace(width, buf);
+    *out = (const int32_t *)buf.p;
     return SVC_OK;
 }
 
@@ -1198,6 +1201,11 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
         svc_set_error("svc_cluster_center: map %dx%d exceeds the supported 255x255", height, width);
         return SVC_E_INVALID;
     }
+    if (params->struct_size != sizeof(SvcParams)) {
+        svc_set_error("svc_cluster_center: SvcParams.struct_size is %u, this library expects %zu (ABI %d): rebuild the binding "
+                      "against include/svc.h", params->struct_size, sizeof(SvcParams), SVC_ABI_VERSION);
+        return SVC_E_INVALID;
+    }
     if (params->hdbscan_min < 2) { svc_set_error("svc_cluster_center: hdbscan_min must be >= 2"); return SVC_E_INVALID; }
     if (params->resize_factor < 1 || params->resize_factor > 16) { svc_set_error("svc_cluster_center: resize_factor must be an integer in 1..16"); return SVC_E_INVALID; }
     if (n == 0) return SVC_OK;
@@ -1209,15 +1217,21 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
     const int factor = params->clust_filt ? params->resize_factor : 1;
     const int full_h = height, full_w = width;
     uint8_t *full_maps = maps;
+    const int *rs_down = nullptr, *rs_up = nullptr;
     if (factor > 1) {
         height = (int)lrint((double)full_h * (1.0 / factor));
         width = (int)lrint((double)full_w * (1.0 / factor));
         if (height < 1 || width < 1) { svc_set_error("svc_cluster_center: map too small for resize_factor"); return SVC_E_INVALID; }
-        if (h->rs_h != full_h || h->rs_w != full_w || h->rs_factor != factor) {
-            if ((rc = upload_map_tab(h->rs_down, full_h, full_w, height, width, (double)factor, (double)factor))) return rc;
-            if ((rc = upload_map_tab(h->rs_up, height, width, full_h, full_w, (double)height / full_h, (double)width / full_w))) return rc;
-            h->rs_h = full_h; h->rs_w = full_w; h->rs_factor = factor;
+        auto key = std::make_tuple(full_h, full_w, factor);
+        auto it = h->rs_tabs.find(key);
+        if (it == h->rs_tabs.end()) {       // tables are keyed by shape and never rewritten (earlier calls may still read theirs)
+            std::pair<DevBuf, DevBuf> t;
+            if ((rc = upload_map_tab(t.first, full_h, full_w, height, width, (double)factor, (double)factor))) return rc;
+            if ((rc = upload_map_tab(t.second, height, width, full_h, full_w, (double)height / full_h, (double)width / full_w))) return rc;
+            it = h->rs_tabs.emplace(key, t).first;
         }
+        rs_down = (const int *)it->second.first.p;
+        rs_up = (const int *)it->second.second.p;
         if ((rc = h->rs_maps.ensure((size_t)n * height * width))) return rc;
         maps = (uint8_t *)h->rs_maps.p;
     }
@@ -1239,9 +1253,12 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
     // asynchronous (up to 8 calls may be in flight on the stream before a slot is reused)
     if (!h->depth_pinned) SVC_HIP(hipHostMalloc((void **)&h->depth_pinned, 8 * (size_t)DEPTH_SLOT, hipHostMallocDefault));
     const int slot = h->depth_slot++ & 7;
+    if (h->depth_ev[slot]) SVC_HIP(hipEventSynchronize(h->depth_ev[slot]));      // the upload that last used this slot has run
+    else SVC_HIP(hipEventCreateWithFlags(&h->depth_ev[slot], hipEventDisableTiming));
     uint8_t *depth_dev = (uint8_t *)h->tail_ws.p + (size_t)L.total * n + (size_t)slot * DEPTH_SLOT;
     memcpy(h->depth_pinned + (size_t)slot * DEPTH_SLOT, depth.data(), n);
     SVC_HIP(hipMemcpyAsync(depth_dev, h->depth_pinned + (size_t)slot * DEPTH_SLOT, n, hipMemcpyHostToDevice, s));
+    SVC_HIP(hipEventRecord(h->depth_ev[slot], s));
     h->tail_frames = n; h->tail_h = height; h->tail_w = width; h->tail_frame_stride = L.total;
     TailArgs A;
     A.maps = maps; A.ws = (uint8_t *)h->tail_ws.p; A.ws_stride = L.total; A.depth = depth_dev; A.round = 0;
@@ -1249,21 +1266,20 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
     A.mcs = params->hdbscan_min; A.min_samples = params->hdbscan_min_samples; A.select_sum = params->select_sum;
     A.op_close = params->op_close; A.clust_filt = params->clust_filt;
     A.prim_pt = h->prim_pt;
-    RC_TAIL(ensure_ring_delta(h, width));
+    const int32_t *ring_delta = nullptr;
+    RC_TAIL(ensure_ring_delta(h, width, &ring_delta));
     A.ring = (const uint32_t *)h->tail_offsets.p; A.n_ring = h->tail_n_offsets; A.n_ring1 = h->tail_n_offsets1;
-    A.ring_delta = (const int32_t *)h->tail_delta.p;
+    A.ring_delta = ring_delta;
     A.xy = xy; A.stats = stats; A.L = L;
     const int hw = height * width;
     const size_t lds_core = (size_t)(hw + 15) / 16 * 16 + (size_t)h->tail_n_offsets * 4 + (size_t)h->tail_n_offsets1 * 4;
     const size_t lds_prim = 2 * NW16 * 16 + (size_t)hw * 2;
     const size_t lds_fin = 2 * ((size_t)(hw + 15) / 16 * 16);
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (h->lds_attr_done.insert((const void *)k_core).second) {      // per handle = per device (the attribute is per device)
         SVC_HIP(hipFuncSetAttribute((const void *)k_core, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_prim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_tree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
-        attr_done = true;
     }
     for (int r = 0; r <= maxd; ++r) {
         A.round = r;
@@ -1272,7 +1288,7 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
             SVC_CHECK_LAUNCH();
         }
         if (factor > 1) {
-            k_map_resize<<<dim3(8, n), 256, 0, s>>>(full_maps, maps, (const int *)h->rs_down.p, depth_dev, r, full_h, full_w,
+            k_map_resize<<<dim3(8, n), 256, 0, s>>>(full_maps, maps, rs_down, depth_dev, r, full_h, full_w,
                                                     height, width);
             SVC_CHECK_LAUNCH();
         }
@@ -1303,7 +1319,7 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
             SVC_CHECK_LAUNCH();
         }
         if (factor > 1) {
-            k_map_resize<<<dim3(16, n), 256, 0, s>>>(maps, full_maps, (const int *)h->rs_up.p, depth_dev, r, height, width,
+            k_map_resize<<<dim3(16, n), 256, 0, s>>>(maps, full_maps, rs_up, depth_dev, r, height, width,
                                                      full_h, full_w);
             SVC_CHECK_LAUNCH();
         }

@@ -11,11 +11,15 @@ behind ``svc_iou_i32`` (include/svc.h).
 
 Differences from the reference script, none of which change the numbers:
 annotation zips are read in place instead of being extracted next to the script
-(:45-63); box pairs are batched into two int32 arrays before scoring.
+(:45-63); box pairs are batched into two int32 arrays before scoring.  A run file with
+fewer rows than the annotation is scored over the rows it has, with a warning, like the
+reference's print-and-break at :163-178 (a file with no rows at all raises, as
+statistics.mean does there); 'cuts_extra:' / 'no_extra_cuts:' info lines are parsed (:208-218).
 """
 import io
 import math
 import os
+import warnings
 import zipfile
 
 import numpy as np
@@ -107,9 +111,12 @@ def pair_boxes(annots, boxes):
                 continue
             n = len(annots[0]['1-3'][v])                   # frame_counts, retargetvid_eval.py:99-101
             m = boxes[ar][v]
-            if len(m) < n:
-                raise ValueError('run has %d rows for video %03d_%s, annotations have %d'
-                                 % (len(m), v, ar, n))
+            if len(m) < n:                                 # reference: "could not find annotation!" + break, mean over what exists
+                if len(m) == 0:
+                    raise ValueError('run has no rows for video %03d_%s' % (v, ar))
+                warnings.warn('run has %d rows for video %03d_%s, annotations have %d: scoring the first %d frames'
+                              % (len(m), v, ar, n, len(m)))
+                n = len(m)
             for user in range(6):
                 gts.append(np.maximum(annots[user][ar][v][:n], 0))
                 mts.append(np.maximum(m[:n], 0))
@@ -144,8 +151,11 @@ def parse_info_stats(infos):
                 if '%' in k:
                     key = k.split(':')[0].strip().lower()
                     stats[ar].setdefault(key, []).append(float(k.split(',')[1].replace('%', '').strip()))
-                elif 'cuts_clust:' in k:
-                    stats[ar].setdefault('cuts_clust', []).append(int(k.split(':')[1].strip()))
+                else:
+                    for name in ('cuts_clust', 'cuts_extra', 'no_extra_cuts'):      # first match wins, like the elif chain
+                        if name + ':' in k:
+                            stats[ar].setdefault(name, []).append(int(k.split(':')[1].strip()))
+                            break
     return stats
 
 
@@ -161,7 +171,10 @@ def format_report(rows):
         return -1, -1
 
     for run, scores, stats, missing in rows:
-        s = '%-36s,' % run.replace('_', ',')
+        name = run.replace('_', ',')
+        if 'mt=1.0_rf=' not in name:                       # retargetvid_eval.py:229-231 (a no-op after the first replace, kept verbatim)
+            name = name.replace('_mt=1.0', '_mt=1.0_rf=1')
+        s = '%-36s,' % name.replace('_', ',')
         for ar in ARS:
             if ar not in scores:
                 continue

@@ -90,11 +90,7 @@ class Engine:
         (or None).  -> xy float64 [n,2] (NaN = None) [, stats int32 [n,4]]."""
         _need_cuda(maps, torch.uint8, 'maps')
         n, h, w = maps.shape
-        factor = CP.get('resize_factor', 1.0)
-        if float(factor) != int(factor) or (int(factor) != 1 and CP.get('resize_type', 1) != 1):
-            raise NotImplementedError('resize_factor must be an integer and resize_type 1 (bilinear)')
-        p = SvcParams(int(CP['hdbscan_min']), int(CP['hdbscan_min_samples'] or 0), int(CP['select_sum']),
-                      int(bool(CP['op_close'])), int(bool(CP['clust_filt'])), int(factor))
+        p = _lib.make_params(CP)
         xy = torch.empty((n, 2), dtype=torch.float64, device=maps.device)
         stats = torch.zeros((n, 4), dtype=torch.int32, device=maps.device) if want_stats else None
         flags = None

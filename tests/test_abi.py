@@ -26,9 +26,14 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layout_matches_header():
-    assert ctypes.sizeof(_lib.SvcParams) == 24
-    assert [f[0] for f in _lib.SvcParams._fields_] == ['hdbscan_min', 'hdbscan_min_samples', 'select_sum', 'op_close',
+    assert ctypes.sizeof(_lib.SvcParams) == 28
+    assert [f[0] for f in _lib.SvcParams._fields_] == ['struct_size', 'hdbscan_min', 'hdbscan_min_samples', 'select_sum', 'op_close',
                                                        'clust_filt', 'resize_factor']
+
+
+def test_abi_version_matches_header():
+    text = open(os.path.join(ROOT, 'include', 'svc.h')).read()
+    assert int(re.search(r'#define SVC_ABI_VERSION (\d+)', text).group(1)) == _lib.ABI_VERSION == _lib.load().svc_abi_version()
 
 
 def test_create_reports_errors():

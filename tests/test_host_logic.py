@@ -133,6 +133,34 @@ def test_result_files_roundtrip_through_evaluator_parser(tmp_path):
     assert stats['1-3']['t__clustering'] == [0.1] and stats['1-3']['t_total'] == [0.5] and stats['1-3']['cuts_clust'] == [0]
 
 
+def test_evaluator_short_run_file_and_extra_cut_lines():
+    """retargetvid_eval.py:163-178 scores the rows a short file has (print + break); :208-218 parses the
+    'cuts_extra:' / 'no_extra_cuts:' info lines into the ecm / eca columns."""
+    import warnings
+    from oracle import tail_ref as T
+    from retargetvid_amd import evaluate as E
+    v = E.VID_INDS[0]
+    gt = np.array([[0, 0, 120, 360]] * 5, np.int32)
+    annots = [{ar: {v: gt.copy()} for ar in E.ARS} for _ in range(6)]
+    boxes = {'1-3': {v: np.array([[10, 0, 130, 360]] * 3, np.int32)}, '3-1': {}}
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        g, m, index = E.pair_boxes(annots, boxes)
+    assert len(w) == 1 and 'scoring the first 3' in str(w[0].message)
+    assert g.shape == m.shape == (18, 4) and all(n == 3 for *_, n in index)
+    ious = np.array([T.iou(a, b) for a, b in zip(g.tolist(), m.tolist())])
+    w_, b_, mean = E.aggregate(ious, index)['1-3']
+    assert abs(mean - 100 * T.iou([0, 0, 120, 360], [10, 0, 130, 360])) < 1e-9
+    import pytest
+    with pytest.raises(ValueError):
+        E.pair_boxes(annots, {'1-3': {v: np.zeros((0, 4), np.int32)}, '3-1': {}})
+    stats = E.parse_info_stats({'1-3': {1: 'cuts_clust:2\ncuts_extra:3\nno_extra_cuts:1\nt_total:  0.5s,  1.500%\n'}, '3-1': {}})
+    assert stats['1-3'] == {'cuts_clust': [2], 'cuts_extra': [3], 'no_extra_cuts': [1], 't_total': [1.5]}
+    text = E.format_report([('smartvidcrop', {'1-3': (1.0, 2.0, 1.5)}, stats, 0)])
+    assert text.splitlines()[1].split(',')[1:12] == ['1.000', '2.000', '1.500', '1.500', '1.500', '-1.000', '-1.000',
+                                                     '2.000', '2.000', '3.000', '3.000']
+
+
 def test_entry_points_fail_loudly_without_gpu():
     if torch.cuda.is_available():
         return

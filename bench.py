@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Headline benchmark: end-to-end saliency+crop frames/s on synthetic 640x360 frame batches.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 without WORLD_SIZE in the environment: this process starts `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ...` on this same file as a CHILD (before anything here has touched the
+GPU; nothing is exec'ed) and exits with its code.  Under torch.distributed.run (the driver's form) every rank runs
+main() directly; --gpus must then equal WORLD_SIZE.
 
 A step is one pass of the hot path over one batch of B=32 device-resident 640x360 RGB
 frames (BASELINE.json configs[1]): ingest down-scale -> UNISAL static saliency ->
@@ -10,10 +15,20 @@ then one D2H of the 32 centres and the crop-box arithmetic on the host.  Frames 
 across ranks with no data-path collective ("weak" scaling: 32 frames per GPU per step); the
 only exchange is the all_gather of the final boxes after the timed region.
 
-Rank 0 prints ONE JSON line.  `roofline` describes the kernel class that takes the most
-time inside the timed region (HIP events recorded by the library around each launch of that
-class on its stream); `cpu_baseline` is the oracle (CPU restatement of the same path) timed
-on this node's host cores on a bounded sample of the same workload.
+Rank 0 prints ONE JSON line.  `roofline` describes the kernel class that takes the most device time
+(HIP events recorded by the library around each launch of that class, on the stream it is launched on):
+  achieved / frac          algorithmic FLOPs (or bytes) of the class per step / the summed durations of its launches
+                           in an UN-PIPELINED step (one batch in flight: launch durations that do not overlap anything,
+                           what `rocprofv3 --kernel-trace --stats` of `bench.py --pipeline 1` shows per kernel)
+  *_in_flight              the same quotient over the events of the timed region, where several batches are in flight
+                           on their own streams: launch durations then include time shared with other streams' kernels
+                           and their sum exceeds the wall clock; kept for reference, never the headline fraction
+  frac_wall                algorithmic work of the class per step / ms_per_step: what the class achieves per wall-clock
+                           second of the pipelined run (a lower bound: every other kernel shares that time)
+  traffic                  HBM bytes per launch of the class from the stored rocprofv3 PMC passes (file named in
+                           traffic_source; not re-measured by this run)
+`cpu_baseline` is the oracle (CPU restatement of the same path) timed on this node's host cores on a bounded
+sample of the same workload.
 """
 import argparse
 import json
@@ -25,11 +40,44 @@ import time
 # share one (ROCclr default is 4; with it the same run is ~20 % slower) — must be set before HIP starts
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--pipeline', type=int, default=4, help='batches in flight per GPU (engines / HIP streams)')
+    ap.add_argument('--cpu-sample', type=int, default=160, help='frames of the CPU baseline sample (0 = skip)')
+    ap.add_argument('--iso-steps', type=int, default=3, help='un-pipelined profiling steps per kernel class')
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """--gpus N > 1 outside torch.distributed.run: start the N ranks as a child job and return its exit code.
+    Runs before torch / HIP are imported in this process, and starts a child instead of replacing this process."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+if __name__ == '__main__' and 'WORLD_SIZE' not in os.environ:
+    _a = parse_args()
+    if _a.gpus > 1:
+        sys.exit(self_launch(_a))
+
+import numpy as np      # noqa: E402
+import torch            # noqa: E402
 
 from retargetvid_amd import dist as svc_dist, ops, smartVidCrop as S, synth, weights   # noqa: E402
 
@@ -103,18 +151,15 @@ def cpu_baseline(sd, frames_u8, CP, flags):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32)
-    ap.add_argument('--pipeline', type=int, default=4, help='batches in flight per GPU (engines / HIP streams)')
-    ap.add_argument('--cpu-sample', type=int, default=160, help='frames of the CPU baseline sample (0 = skip)')
-    args = ap.parse_args()
-
+    args = parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d: launch with `python bench.py --gpus N` (self-launching) or '
+                         '`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`' % (args.gpus, world))
+    if args.gpus > torch.cuda.device_count():
+        raise SystemExit('bench.py: --gpus %d but only %d GPU(s) visible' % (args.gpus, torch.cuda.device_count()))
     # BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, barrier, MAX all-reduce, box gather) with any
     # world size, including 1 under torch.distributed.run -- a way to exercise it on a single-GPU box
     dist_on = world > 1 or os.environ.get('BENCH_FORCE_DIST', '0') == '1'
@@ -183,68 +228,96 @@ def main():
         torch.cuda.synchronize()
 
     boxes = run(max(args.warmup, P))
-    # find the kernel class that takes the most device time (one profiled, un-pipelined, untimed step per class)
+    # 1. un-pipelined pass (one batch in flight, slot 0 only): per kernel class, iso_steps profiled steps -> launch
+    #    durations that overlap nothing; also the latency of one batch and the step time with one batch in flight
     eng = slots[0].eng
+    iso = max(1, args.iso_steps)
     per_class = {}
     for k in eng.KERNEL_CLASSES:
         eng.profile_enable(k)
+        for _ in range(iso):
+            slots[0].enqueue()
+            slots[0].finish()
+        ms, cnt = eng.profile_read()
+        per_class[k] = (ms / iso, cnt / iso)                      # ms per step, launches per step
+    eng.profile_enable(None)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(10):
         slots[0].enqueue()
         slots[0].finish()
-        per_class[k] = eng.profile_read()
+    latency_ms = (time.perf_counter() - t1) / 10 * 1e3
     dominant = max(per_class, key=lambda k: per_class[k][0])
     live = os.environ.get('BENCH_LIVE_PROFILE', '1') != '0'      # diagnostic: cost of the in-library events
     for sl in slots:
         sl.eng.profile_enable(dominant if live else None)
         sl.eng.profile_read()
 
+    # 2. the timed region: K steps, P batches in flight
     barrier()
     t0 = time.perf_counter()
     boxes = run(args.steps)
     barrier()
-    dt = time.perf_counter() - t0
-    dom_ms, dom_launches = 0.0, 0
+    dt_local = dt = time.perf_counter() - t0
+    fl_ms, fl_launches = 0.0, 0
     for sl in slots:
         ms, cnt = sl.eng.profile_read()
-        dom_ms += ms
-        dom_launches += cnt
+        fl_ms += ms
+        fl_launches += cnt
         sl.eng.profile_enable(None)
-    if not live:                                                  # fall back to the isolated per-class measurement
-        dom_ms, dom_launches = per_class[dominant][0] * args.steps, per_class[dominant][1] * args.steps
 
+    rank_fps = [B * args.steps / dt_local]
+    seen_world = 1
     if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
+        seen_world = torch.distributed.get_world_size()
+        tl = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(seen_world)]
+        torch.distributed.all_gather(tl, torch.tensor([dt_local], dtype=torch.float64, device=dev))
+        rank_fps = [B * args.steps / float(t.item()) for t in tl]
 
     if rank == 0:
         work = layer_work(B)
         steps = max(args.steps, 1)
-        ms_per_launch = dom_ms / max(dom_launches, 1)
-        if dominant == 'pw':
-            tfl = work['pw_flops'] * steps / (dom_ms * 1e-3) / 1e12
-            gbs = work['pw_bytes'] * steps / (dom_ms * 1e-3) / 1e9
-            roof = dict(bound='mfma', achieved=round(tfl, 3), peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
-                        frac=round(tfl / MFMA_F32_PEAK_TFLOPS, 5), traffic=None,
-                        hbm_achieved_GBs=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 5))
-        else:
-            byt = {'dw': work['dw_bytes'], 'lanczos': B * (140 * 250 * 3 + 256 * 416 * 12.0),
-                   'stem': B * (256 * 416 * 12.0 + 128 * 208 * 128.0), 'resize': B * (360 * 640 * 3 + 140 * 250 * 3.0),
-                   'smooth': B * (32 * 52 * 4 + 140 * 250 * 9.0)}.get(dominant, work['map_bytes'])
-            gbs = byt * steps / (dom_ms * 1e-3) / 1e9
-            roof = dict(bound='hbm', achieved=round(gbs, 3), peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=round(gbs / HBM_PEAK_GBS, 6), traffic=None)
-        # un-pipelined view of the same class (the profiling pass before the timed region) and the PMC traffic
         iso_ms, iso_n = per_class[dominant]
-        if dominant == 'pw' and iso_ms > 0:
-            roof.update(achieved_isolated=round(work['pw_flops'] / (iso_ms * 1e-3) / 1e12, 3),
-                        frac_isolated=round(work['pw_flops'] / (iso_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 5))
+        byte_work = {'pw': work['pw_bytes'], 'dw': work['dw_bytes'], 'lanczos': B * (140 * 250 * 3 + 256 * 416 * 12.0),
+                     'stem': B * (256 * 416 * 12.0 + 128 * 208 * 128.0), 'resize': B * (360 * 640 * 3 + 140 * 250 * 3.0),
+                     'smooth': B * (32 * 52 * 4 + 140 * 250 * 9.0)}.get(dominant, work['map_bytes'])
+        if dominant == 'pw':
+            unit_work, peak, unit, bound, scale = work['pw_flops'], MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', 'mfma', 1e12
+        else:
+            unit_work, peak, unit, bound, scale = byte_work, HBM_PEAK_GBS, 'GB/s', 'hbm', 1e9
+        rate = lambda ms_per_step: unit_work / (ms_per_step * 1e-3) / scale if ms_per_step > 0 else 0.0
+        ach = rate(iso_ms)
+        roof = dict(bound=bound, kernel=dominant, achieved=round(ach, 3), peak=peak, unit=unit, frac=round(ach / peak, 5),
+                    measured='HIP events around every launch of the class in %d un-pipelined steps (one batch in flight) '
+                             'before the timed region' % iso,
+                    launches_per_step=round(iso_n, 2), class_ms_per_step=round(iso_ms, 4),
+                    avg_launch_ms=round(iso_ms / max(iso_n, 1), 5),
+                    algorithmic_per_step=unit_work, algorithmic_unit='FLOP' if dominant == 'pw' else 'B',
+                    frac_wall=round(rate(dt / steps * 1e3) / peak, 5))
+        if live and fl_launches:
+            fl = rate(fl_ms / steps)
+            roof.update(achieved_in_flight=round(fl, 3), frac_in_flight=round(fl / peak, 5),
+                        avg_launch_ms_in_flight=round(fl_ms / fl_launches, 5),
+                        in_flight_note='timed region, %d batches in flight: launch durations overlap other streams\' kernels, '
+                                       'their sum (%.3f ms per step) exceeds the wall clock' % (P, fl_ms / steps))
+        if dominant == 'pw':
+            gbs = work['pw_bytes'] / (iso_ms * 1e-3) / 1e9
+            roof.update(hbm_achieved_GBs=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 5),
+                        hbm_note='un-fused layer-wise fp32 traffic of the class (in + out + weights) / class time')
+        roof['traffic'] = None
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as fp:
-                roof['traffic'] = json.load(fp)['classes'][dominant]['hbm_bytes_per_launch']
+            src = os.path.join('profiles', 'r02_pmc_traffic.json')
+            with open(os.path.join(ROOT, src)) as fp:
+                c = json.load(fp)['classes'][dominant]
+            roof.update(traffic=c['hbm_bytes_per_launch'], traffic_per_step=c.get('hbm_bytes_per_step'),
+                        traffic_source='%s (stored rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py --pipeline 1, '
+                                       'reduced by tools/pmc_traffic.py; not re-measured in this run)' % src)
         except Exception:
             pass
-        roof.update(kernel=dominant, launches=dom_launches, avg_launch_ms=round(ms_per_launch, 4),
-                    class_ms_per_step={k: round(v[0], 3) for k, v in per_class.items()})
+        roof['class_ms_per_step_all'] = {k: round(v[0], 4) for k, v in per_class.items()}
         cpu = None
         if world == 1 and args.cpu_sample > 0:
             torch.set_num_threads(min(16, os.cpu_count() or 1))    # batch-1 convs stop scaling (and collapse) beyond this
@@ -266,7 +339,11 @@ def main():
                                batch_per_gpu=B, frame='640x360x3 u8', saliency_map='140x250 u8', network_input='256x416',
                                weights='synthetic seed 0 (weights.make_synthetic_state_dict)',
                                video_frames_per_s=round(value * CP['skip'], 1), batches_in_flight=P,
-                               parallelism='frames sharded, dp%d' % world),
+                               parallelism='frames sharded, dp%d' % world,
+                               world_size_seen_by_rccl=seen_world if dist_on else None,
+                               per_rank_frames_per_s=[round(v, 1) for v in rank_fps],
+                               one_batch_in_flight=dict(latency_ms_per_batch=round(latency_ms, 4),
+                                                        frames_per_s=round(B / latency_ms * 1e3, 1))),
                    roofline=roof, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if dist_on:

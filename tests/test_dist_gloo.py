@@ -54,3 +54,71 @@ def test_gather_boxes_world2_gloo():
 def test_single_process_passthrough():
     local = {0: _boxes(0)}
     assert np.array_equal(D.gather_boxes(local, COUNTS[:1])[0], _boxes(0))
+
+
+# ---- the whole multi-video job (BASELINE config 3's shape) at world 2 on CPUs ------------------------------
+# crop_fn stand-in: the oracle pipeline (CPU restatement of the same path) plays the GPU; sharding, the
+# all_gather of the boxes, the info gather and rank 0's result files are the product's own code (dist.crop_job).
+JOB_COUNTS = [31, 44, 26, 38, 29]
+JOB_NAMES = ['%03d' % v for v in (1, 2, 3, 601, 602)]
+
+
+def _job_video(i):
+    from retargetvid_amd import synth
+    n = JOB_COUNTS[i]
+    return dict(fr=30.0, frame_count=n, w=160, h=90, frames=synth.blob_frames(n, 90, 160, seed=50 + i),
+                trans_inds=[0, 12 + i, n])
+
+
+def _oracle_crop_fn(videos, CP, ratios, workers):
+    from oracle import pipeline_ref as P
+    from retargetvid_amd import weights
+    sd = weights.make_synthetic_state_dict(0)
+    out = []
+    for v in videos:
+        v = v() if callable(v) else v
+        per = {}
+        for r in ratios:
+            VD = P.smart_vid_crop(v, dict(P.init_crop_params(), out_ratio=r, hdbscan_min=5), sd)
+            per[r] = (VD, {'result': 'smart cropped', 'cuts_clust': 0, 't_total': '  0.010s,  1.000%'})
+        out.append(per)
+    return out
+
+
+def _job_worker(rank, world, port, out_dir, q):
+    torch.set_num_threads(2)
+    if world > 1:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    allb, st = D.crop_job(lambda i: (lambda: _job_video(i)), JOB_COUNTS, JOB_NAMES, {}, ('1:3', '3:1'), out_dir=out_dir,
+                          workers=1, crop_fn=_oracle_crop_fn, run_name='oracle_standin')
+    q.put((rank, st['videos_rank'], {r: {i: allb[r][i].tolist() for i in allb[r]} for r in allb}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_crop_job_world2_equals_world1(tmp_path):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    d1, d2 = str(tmp_path / 'w1'), str(tmp_path / 'w2')
+    procs = [ctx.Process(target=_job_worker, args=(r, 2, port, d2, q)) for r in range(2)]
+    procs.append(ctx.Process(target=_job_worker, args=(0, 1, 0, d1, q)))
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    boxes = [b for _, _, b in res]
+    assert boxes[0] == boxes[1] == boxes[2]                       # every rank of both jobs holds all crop windows
+    assert sorted(n for _, n, _ in res) in ([2, 3, 5], [1, 4, 5])
+    run1, run2 = os.path.join(d1, 'oracle_standin'), os.path.join(d2, 'oracle_standin')
+    files = sorted(os.listdir(run1))
+    assert files == sorted(os.listdir(run2)) and len(files) == 4 * len(JOB_NAMES)
+    for f in files:
+        assert open(os.path.join(run1, f)).read() == open(os.path.join(run2, f)).read(), f
+    rows = open(os.path.join(run2, '601_1-3.txt')).read().splitlines()
+    assert len(rows) == JOB_COUNTS[3] and all(len(r.split(',')) == 4 for r in rows)
+    assert 't_total' in open(os.path.join(run2, '601_1-3_info.txt')).read()   # info of a video rank 1 may have owned

@@ -41,11 +41,8 @@ def main():
     counts = [len(annots[0]['1-3'][v]) for v in vids]
     if args.max_frames:
         counts = [min(c, args.max_frames) for c in counts]
-    mine = D.shard_videos(counts, world)[rank]
     CP = S.sc_init_crop_params()
     ratios = ('1:3', '3:1')
-    local_boxes = {r: {} for r in ratios}
-    infos = {}
 
     def make(i):
         def build():
@@ -57,31 +54,18 @@ def main():
         return build
 
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    res_all = S.crop_videos([make(i) for i in mine], CP, ratios, workers=args.workers)
-    n_sal = 0
-    for i, res in zip(mine, res_all):
-        for r in ratios:
-            local_boxes[r][i] = np.asarray(res[r][0]['bbs'], np.int32)
-        infos[i] = {r: res[r][1] for r in ratios}
-        n_sal += res[ratios[0]][0]['fc_sel']
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    allb = {r: D.gather_boxes(local_boxes[r], counts) for r in ratios}
+    allb, st = D.crop_job(make, counts, ['%03d' % v for v in vids], CP, ratios, out_dir=args.out, workers=args.workers,
+                          run_name='synthetic_default')
     if rank == 0:
-        run_dir = os.path.join(args.out, 'synthetic_default')
-        for i, v in enumerate(vids):
-            for r in ratios:
-                S.write_results(run_dir, '%03d' % v, r, {'bbs': allb[r][i].tolist()}, infos.get(i, {}).get(r, {}))
         score = None
         if args.videos == 200 and not args.max_frames:
             rows, _ = E.evaluate(args.out, args.annotations, out_path=os.path.join(args.out, 'eval_current.txt'))
             score = {ar: [round(x, 3) for x in s] for ar, s in rows[0][1].items()}
-        total_frames = sum(counts)
+        dt = st['seconds_rank']
         print(json.dumps(dict(config='RetargetVid-shaped synthetic set', videos=len(vids), world=world,
-                              video_frames=total_frames, saliency_frames_rank0=n_sal, seconds_rank0=round(dt, 2),
-                              video_frames_per_s_rank0=round(sum(counts[i] for i in mine) / dt, 1),
-                              saliency_frames_per_s_rank0=round(n_sal / dt, 1), eval=score)))
+                              video_frames=sum(counts), saliency_frames_rank0=st['saliency_frames_rank'],
+                              seconds_rank0=round(dt, 2), video_frames_per_s_rank0=round(st['video_frames_rank'] / dt, 1),
+                              saliency_frames_per_s_rank0=round(st['saliency_frames_rank'] / dt, 1), eval=score)))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -134,6 +134,12 @@ int svc_profile_read(SvcHandle *h, double *total_ms, int *launches);
 int svc_debug_cluster_state(SvcHandle *h, int frame, int cap, uint32_t *pts_host, uint32_t *core_host,
                             uint32_t *mst_host, int32_t *labels_host, int32_t *hdr_host);
 
+/* Test/diagnostic door: the edge-order routine of the cluster filter (numpy's default argsort, an unstable
+ * introsort, emulated on the device; hdbscan sorts the MST edges with it, call site smartVidCrop.py:1099) on
+ * arbitrary keys: order_host[p] = index of the key that the sort puts at position p.  n <= 65535.  Synchronises.
+ * Returns n (or a negative error). */
+int svc_debug_argsort_u32(SvcHandle *h, const uint32_t *keys_host, int n, int32_t *order_host);
+
 /* Test/diagnostic door: copy an intermediate activation of the LAST svc_saliency_u8
  * call (NHWC fp32, frame 0..n-1) to a HOST buffer.  `which` is one of the SVC_TAP_*
  * ids.  Returns the number of floats per frame (or a negative error).  Synchronises. */

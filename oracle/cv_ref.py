@@ -21,8 +21,12 @@ implementation for 8-bit images:
   * grey CLOSE = dilate then erode with a 5x5 rectangle anchored at the centre;
     samples outside the image are ignored (default morphology border value).
 
-Parity status: UNPINNED (no reference test holds resized or closed images and cv2 is
-not available offline).  Default settings use only the down-scale (ingest, §8(f)-2)
+Parity status: UNPINNED against cv2 itself (no reference test holds resized or closed images and
+cv2 is not available offline).  Cross-checked against second implementations in
+tests/test_oracle_cv_crosscheck.py: CLOSE bit for bit against scipy.ndimage grey morphology,
+INTER_NEAREST bit for bit against torch 'nearest', INTER_LINEAR within one grey level of torch's
+float bilinear (same sample positions and clamping; the 11-bit weights are what differs) and
+exactly (a+b+c+d+2)>>2 at scale 2.  Default settings use only the down-scale (ingest, §8(f)-2)
 and CLOSE.
 """
 import numpy as np

@@ -36,8 +36,10 @@ def gather_points(sal_map):
     return np.stack([rows, cols], axis=1).astype(np.int64), sal_map[rows, cols]
 
 
-def clustering_filt(sal_map, CP, info=None):
-    """smartVidCrop.py:1062-1161 on one [H,W] u8 map; returns a new array."""
+def clustering_filt(sal_map, CP, info=None, labels_fn=None):
+    """smartVidCrop.py:1062-1161 on one [H,W] u8 map; returns a new array.
+    labels_fn(X, min_cluster_size, min_samples) replaces the restated HDBSCAN (used by the tie-order study,
+    tools/make_golden_hdbscan.py, to push another implementation's labels through the same K11-K14)."""
     sal_map = np.array(sal_map, np.uint8, copy=True)
     if np.sum(sal_map) == 0:
         return sal_map
@@ -51,7 +53,7 @@ def clustering_filt(sal_map, CP, info=None):
     if info is not None:
         info['n_points'] = len(X)
     if X.shape[0] > CP['hdbscan_min'] + 1:
-        labels = hdbscan_ref.hdbscan_labels(X, CP['hdbscan_min'], CP['hdbscan_min_samples'])
+        labels = (labels_fn or hdbscan_ref.hdbscan_labels)(X, CP['hdbscan_min'], CP['hdbscan_min_samples'])
         n_clusters = len(set(labels.tolist())) - (1 if -1 in labels else 0)
         if info is not None:
             info['labels'] = labels

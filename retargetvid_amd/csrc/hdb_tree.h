@@ -1,7 +1,10 @@
 // hdb_tree.h — HDBSCAN* hierarchy stage of the cluster filter (K10, second half).
 //
 // Input: the N-1 edges of the mutual-reachability MST in the library's Prim order,
-// stably sorted by weight.  Output: for every point the condensed cluster that
+// sorted by weight the way the library sorts them: numpy's default argsort, an unstable
+// introsort whose order of equal weights is restated in oracle/npsort_ref.py and emulated
+// on the device by k_sort.  (Any order of equal weights is processed correctly; the order
+// decides which components merge first, so it has to be the library's.)  Output: for every point the condensed cluster that
 // absorbed it, the weight at which that happened, and the excess-of-mass selection —
 // enough to label points exactly like hdbscan's generic path
 // (call site smartVidCrop.py:1099; algorithm: SURVEY.md Appendix A steps 6-10).
@@ -216,7 +219,7 @@ SVC_HD bool merge(Tree &t, int i, int n, int mcs, uint32_t w, const Resolved &q)
     return true;
 }
 
-// The sequential pass.  edges must be sorted by w (stable w.r.t. Prim order).
+// The sequential pass.  edges must be sorted by w (ties in the library's order, see the header).
 // Returns false if the per-cluster arrays (cap_clusters) are too small.
 SVC_HD bool build(Tree &t, const Edge *edges, int n, int mcs) {
     t.n = n;
@@ -233,16 +236,27 @@ SVC_HD bool build(Tree &t, const Edge *edges, int n, int mcs) {
 // The same pass the way the device runs it (svc_tail.hip: build_wave), kept here in plain C++ with
 // the lanes as array slots so the CPU harness checks the batching logic against the oracle.
 //
-// Almost every edge of a real map is an ABSORPTION: a small component (usually one pixel) falls into
-// an existing big cluster.  A batch of up to B edges is resolved up front (device: one lane per edge,
-// read-only).  A scan in edge order then patches chains inside the batch -- a side whose root was
-// absorbed by an earlier edge of the batch now belongs to that edge's cluster -- and finds the longest
-// prefix of the batch that consists of absorptions only.  That prefix is applied at once: absorptions
-// touch disjoint small roots, and the only thing they share, the cluster's size and its chain of
-// dendrogram nodes, follows from the edge positions.  The edge that ends the prefix (two small
-// components, a cluster birth or a true split) is applied alone by merge() -- its resolved values are
-// still exact, because absorptions do not change roots or small-component sizes -- and the next batch
-// starts behind it.
+// The edges arrive in numpy's argsort order (oracle/npsort_ref.py: an unstable introsort, so equal weights --
+// nearly all of them on a pixel grid -- come in a scrambled order, not in Prim order).  Nearly every edge of a
+// real map then ATTACHES A FRESH SMALL COMPONENT (usually one pixel) to something: to an existing big cluster
+// (it falls out of that cluster: an absorption), or to another small component while the sum stays below
+// min_cluster_size (a union).  Such edges commute with their neighbours in the sorted list as long as the fresh
+// components are different, so a batch of up to B edges is resolved up front (device: one lane per edge,
+// read-only) and the longest prefix made of them is applied at once.  Per side of an edge, at the start of the batch:
+//   B  big: belongs to a condensed cluster
+//   F  fresh: a small root that no EARLIER edge of the batch contains
+//   L  linked: a small root that an earlier edge k of the batch contains -- at this edge's turn the root is part
+//      of whatever edge k made (k is the first edge containing it, so it was fresh there)
+// and per edge:
+//   F+F  starts a small tree (a union; a cluster birth, which ends the prefix, if the sizes reach min_cluster_size)
+//   F+B  starts / continues the absorption chain of cluster B
+//   F+L  attaches its fresh side to the tree of edge k: the chain of a cluster (an absorption) or a small tree
+//        (a union, as long as the tree's running size stays below min_cluster_size; the edge at which it
+//        reaches it is a cluster birth and ends the prefix)
+//   anything else (two existing things meet: a true split, a batch-made tree reaching a cluster, ...) ends the prefix.
+// The trees are found by pointer jumping along the k links; what the edges of one tree share -- the running
+// dendrogram node, the size, the union-find root -- follows from the lane numbers of its edges.  The edge that ends
+// the prefix is resolved afresh and applied alone by merge(); the next batch starts behind it.
 template <int B>
 inline bool build_batched(Tree &t, const Edge *edges, int n, int mcs) {
     t.n = n;
@@ -250,16 +264,13 @@ inline bool build_batched(Tree &t, const Edge *edges, int n, int mcs) {
     Resolved pre[B];
     int i0 = 0;
     while (i0 < n - 1) {
+#ifdef HDB_COUNT_BATCHES
+        ++HDB_COUNT_BATCHES;
+#endif
         const int m = (n - 1 - i0) < B ? (n - 1 - i0) : B;
         for (int j = 0; j < m; ++j) pre[j] = resolve_ro(t, edges[i0 + j]);
-        // Which sides are big when an edge's turn comes?  A root that is still small at the start of the batch is
-        // absorbed by the FIRST edge of the batch that contains it: at that edge's turn the root's side cannot be big
-        // yet, so the edge either absorbs it (its other side is big) or joins two small components and ends the
-        // prefix.  Hence, for every edge up to the end of the prefix,
-        //     big(side) = big at the start of the batch  ||  first edge containing the side's root < this edge,
-        // with no reference to the order of evaluation: one scatter-min of lane numbers per root (the table lives in
-        // absw[], which is meaningless for un-absorbed roots and is restored to "none" below), then P by a ballot and
-        // the clusters by following the "first edge" links (pointer jumping on the device).
+        // first edge of the batch containing each small root: one scatter-min of lane numbers per root (the table
+        // lives in absw[], which is meaningless for un-absorbed roots and is restored to "none" below)
         for (int j = 0; j < m; ++j) {
             if (pre[j].ca == NONE16 && (uint32_t)j < t.absw[pre[j].ra]) t.absw[pre[j].ra] = (uint32_t)j;
             if (pre[j].cb == NONE16 && (uint32_t)j < t.absw[pre[j].rb]) t.absw[pre[j].rb] = (uint32_t)j;
@@ -273,44 +284,102 @@ inline bool build_batched(Tree &t, const Edge *edges, int n, int mcs) {
             if (pre[j].ca == NONE16) t.absw[pre[j].ra] = NO_LANE;
             if (pre[j].cb == NONE16) t.absw[pre[j].rb] = NO_LANE;
         }
+        // classify, link, find the trees
+        int par[B], root[B];                           // lane of the edge this one attaches to (itself: starts a tree)
+        uint32_t clus[B], add[B];                      // cluster of a chain root (NONE16: a small tree); size this edge brings in
+        bool bad[B];                                   // cannot be part of a prefix
+        for (int j = 0; j < m; ++j) {
+            const bool aB = pre[j].ca != NONE16, bB = pre[j].cb != NONE16;
+            const bool aF = !aB && fa[j] == (uint32_t)j, bF = !bB && fb[j] == (uint32_t)j;
+            par[j] = j; clus[j] = NONE16; add[j] = 0; bad[j] = false;
+            if (aF && bF) add[j] = pre[j].sa + pre[j].sb;
+            else if (aF && bB) { clus[j] = pre[j].cb; add[j] = pre[j].sa; }
+            else if (aB && bF) { clus[j] = pre[j].ca; add[j] = pre[j].sb; }
+            else if (aF && !bB) { par[j] = (int)fb[j]; add[j] = pre[j].sa; }      // F + L
+            else if (bF && !aB) { par[j] = (int)fa[j]; add[j] = pre[j].sb; }      // L + F
+            else bad[j] = true;
+        }
+        uint32_t tot[B];
+        for (int j = 0; j < m; ++j) {                  // links point to earlier lanes: one ascending pass (device: pointer jumping)
+            root[j] = par[j] == j ? j : root[par[j]];
+            if (bad[par[j]] || (par[j] != j && bad[root[j]])) bad[j] = true;   // (only matters behind the end of the prefix)
+            tot[j] = 0;
+        }
+        for (int j = 0; j < m; ++j) if (!bad[j]) tot[root[j]] += add[j];
         int P = m;
         for (int j = 0; j < m; ++j) {
-            const bool abig = pre[j].ca != NONE16 || fa[j] < (uint32_t)j, bbig = pre[j].cb != NONE16 || fb[j] < (uint32_t)j;
-            if (abig == bbig) { P = j; break; }
-        }
-        uint32_t cl[B];                                // cluster an edge of the prefix falls into
-        for (int j = 0; j <= P && j < m; ++j) {
-            // a side absorbed inside the batch takes the cluster of the edge that absorbed it (an earlier lane)
-            if (pre[j].ca == NONE16 && fa[j] < (uint32_t)j) pre[j].ca = cl[fa[j]];
-            if (pre[j].cb == NONE16 && fb[j] < (uint32_t)j) pre[j].cb = cl[fb[j]];
-            if (j < P) cl[j] = pre[j].ca != NONE16 ? pre[j].ca : pre[j].cb;
-        }
-        for (int j = 0; j < P; ++j) {                  // independent per j on the device
-            const Resolved &q = pre[j];
-            const bool abig = q.ca != NONE16;
-            const uint32_t c = abig ? q.ca : q.cb, r = abig ? q.rb : q.ra;
-            const uint32_t s = abig ? q.sb : q.sa, ns = abig ? q.nb : q.na;
-            uint32_t prev = t.cdn[c];                  // node of the cluster before the batch ...
-            for (int k = 0; k < j; ++k) {              // ... or of the previous absorption into it
-                const uint32_t ckk = pre[k].ca != NONE16 ? pre[k].ca : pre[k].cb;
-                if (ckk == c) prev = (uint32_t)(n + i0 + k);
+            // a small tree gives birth to a cluster at the edge where its running size reaches min_cluster_size
+            // (device: a wave-wide prefix sum over the lanes of every tree whose batch total reaches it -- rarely any)
+            bool birth = false;
+            if (!bad[j] && clus[root[j]] == NONE16 && (int)tot[root[j]] >= mcs) {
+                uint32_t run = 0;
+                for (int k = 0; k <= j; ++k) if (!bad[k] && root[k] == root[j]) run += add[k];
+                birth = (int)run >= mcs;
             }
-            const uint32_t node = (uint32_t)(n + i0 + j);
-            t.dparent[abig ? prev : ns] = node << 1;
-            t.dparent[abig ? ns : prev] = (node << 1) | 1u;
-            t.absc[r] = (uint16_t)c; t.absw[r] = edges[i0 + j].w;
-            t.evc[i0 + j] = (uint16_t)c; t.evs[i0 + j] = (uint16_t)s;
+            if (bad[j] || birth) {
+#ifdef HDB_COUNT_STOP
+                HDB_COUNT_STOP(bad[j] ? 0 : 1);
+#endif
+                P = j;
+                break;
+            }
         }
-        for (int j = 0; j < P; ++j) {                  // after all reads of cdn above
+        // apply lanes 0..P-1 (independent per lane on the device, given the per-tree lane sets)
+        for (int j = 0; j < P; ++j) {
             const Resolved &q = pre[j];
-            const bool abig = q.ca != NONE16;
-            const uint32_t c = abig ? q.ca : q.cb;
-            t.csize[c] += abig ? q.sb : q.sa;
-            t.cdn[c] = (uint32_t)(n + i0 + j);
+            const uint32_t node = (uint32_t)(n + i0 + j);
+            const int r0 = root[j];
+            const uint32_t c = clus[r0];
+            int prev = -1;                             // previous edge of the same small tree / of the same cluster's chain
+            for (int k = 0; k < j; ++k)                // (several chains of one batch may feed the same cluster)
+                if (c != NONE16 ? clus[root[k]] == c : root[k] == r0) prev = k;
+            const bool aB = q.ca != NONE16, bB = q.cb != NONE16;
+            const bool aF = !aB && fa[j] == (uint32_t)j, bF = !bB && fb[j] == (uint32_t)j;
+            if (c != NONE16) {                         // absorption into cluster c: the fresh side falls out of it
+                const bool abig = !aF;                 // the a side is the cluster's side
+                const uint32_t r = abig ? q.rb : q.ra, s = abig ? q.sb : q.sa, ns = abig ? q.nb : q.na;
+                const uint32_t pn = prev >= 0 ? (uint32_t)(n + i0 + prev) : t.cdn[c];
+                t.dparent[abig ? pn : ns] = node << 1;
+                t.dparent[abig ? ns : pn] = (node << 1) | 1u;
+                t.absc[r] = (uint16_t)c; t.absw[r] = edges[i0 + j].w;
+                t.evc[i0 + j] = (uint16_t)c; t.evs[i0 + j] = (uint16_t)s;
+            } else {                                   // union inside a small tree; the tree's root is the starter's a side
+                const uint32_t R = pre[r0].ra;
+                t.evc[i0 + j] = (uint16_t)NONE16; t.evs[i0 + j] = 0;
+                if (r0 == j) {
+                    t.dparent[q.na] = node << 1;
+                    t.dparent[q.nb] = (node << 1) | 1u;
+                    t.sp[q.rb] = (uint16_t)R;
+                } else {
+                    const uint32_t pn = (uint32_t)(n + i0 + prev);
+                    const uint32_t rf = aF ? q.ra : q.rb, nf = aF ? q.na : q.nb;
+                    t.dparent[aF ? nf : pn] = node << 1;           // a side = left child
+                    t.dparent[aF ? pn : nf] = (node << 1) | 1u;
+                    t.sp[rf] = (uint16_t)R;
+                }
+            }
+        }
+        for (int j = 0; j < P; ++j) {                  // per tree, after all reads of cdn above: totals and last nodes
+            const int r0 = root[j];
+            const uint32_t c = clus[r0];
+            if (c != NONE16) {
+                t.csize[c] += add[j];
+                t.cdn[c] = (uint32_t)(n + i0 + j);
+            } else {
+                const uint32_t R = pre[r0].ra;
+                if (r0 == j) t.ssz[R] = 0;
+            }
+        }
+        for (int j = 0; j < P; ++j) {
+            const int r0 = root[j];
+            if (clus[r0] != NONE16) continue;
+            const uint32_t R = pre[r0].ra;
+            t.ssz[R] = (uint16_t)(t.ssz[R] + add[j]);
+            t.sdn[R] = (uint32_t)(n + i0 + j);
         }
         i0 += P;
-        if (P < m) {
-            if (!merge(t, i0, n, mcs, edges[i0].w, pre[P])) return false;
+        if (P < m) {                                   // the roots may have moved (unions): resolve afresh
+            if (!merge(t, i0, n, mcs, edges[i0].w, resolve(t, edges[i0]))) return false;
             ++i0;
         }
     }

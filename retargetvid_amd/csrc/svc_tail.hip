@@ -41,6 +41,7 @@ struct FrameWS {
     uint32_t ea, eb;     // Edge[cap]  radix ping-pong (ea = sorted result)
     uint32_t labels;     // i32[cap]
     uint32_t reach;      // u32[cap]   (generic large-N Prim only)
+    uint32_t srt;        // 16 B x cap  working arrays of k_sort when they do not fit in LDS
     uint32_t sp, ssz, absc, absw, sdn, evc, evs, dparent;
     uint32_t cup, ctp, cleft, cright, cbirthw, cminw, csize, cdn, csplit, cspa, cspb, cacc, csel, crep, cweight;
     uint32_t total;
@@ -53,7 +54,7 @@ static FrameWS make_layout(int cap, int mc) {
     L.hdr = take(64);
     L.pts = take(4u * cap); L.core = take(4u * cap);
     L.mst = take(8u * cap); L.ea = take(8u * cap); L.eb = take(8u * cap);
-    L.labels = take(4u * cap); L.reach = take(4u * cap);
+    L.labels = take(4u * cap); L.reach = take(4u * cap); L.srt = take(16u * cap + 128);
     L.sp = take(2u * cap); L.ssz = take(2u * cap); L.absc = take(2u * cap); L.absw = take(4u * cap);
     L.sdn = take(4u * cap); L.evc = take(2u * cap); L.evs = take(2u * cap);
     L.dparent = take(8u * cap);
@@ -722,11 +723,25 @@ struct TreeShared {
     int nsel, best, ok;
 };
 
-// hdb::build_batched<64> on one wavefront (see the comment there): lane j resolves edge j of the batch;
-// a scan in edge order patches absorption chains and finds the prefix of pure absorptions, which all
-// lanes then apply at once; the edge that ends the prefix is applied by lane 0 through hdb::merge.
+// wave-wide inclusive prefix sum (64 lanes)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// hdb::build_batched<64> on one wavefront (see the comment there): lane j resolves edge j of the batch and
+// classifies its sides (big / fresh / linked to an earlier lane); six rounds of pointer jumping along the links
+// give every lane the edge that started its tree (a cluster's absorption chain or a small tree of unions); the
+// longest prefix of attachments is applied by all lanes at once, and the edge that ends it is resolved afresh
+// and applied by lane 0 through hdb::merge.
 __device__ __forceinline__ bool build_wave(hdb::Tree &t, const hdb::Edge *edges, int n, int mcs) {
     const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
     t.n = n;
     t.nclusters = 0;
     int i0 = 0;
@@ -734,17 +749,14 @@ __device__ __forceinline__ bool build_wave(hdb::Tree &t, const hdb::Edge *edges,
         const int m = min(64, n - 1 - i0);
         hdb::Edge e = hdb::Edge{0, 0, 1};
         hdb::Resolved pre = hdb::Resolved{0, 0, hdb::NONE16, hdb::NONE16, 0, 0, 0, 0};
-        if (lane < m) {
+        const bool in = lane < m;
+        if (in) {
             e = edges[i0 + lane];
             pre = hdb::resolve_ro(t, e);
         }
-        const uint32_t v_r = pre.ra | (pre.rb << 16);
-        // Which sides are big at an edge's turn, without walking the batch (hdb::build_batched has the argument): a
-        // root still small at the start of the batch is absorbed by the first edge that contains it, so
-        //     big(side) = big at the start  ||  first lane containing the side's root < this lane.
-        // The "first lane" table is absw[] (unused for un-absorbed roots): a scatter-min of lane numbers, read back
-        // with atomic loads (the minimum is formed in L2 / LDS, not in this CU's vector L1), then restored.
-        const bool in = lane < m;
+        // First lane of the batch that contains each small root: the table is absw[] (unused for un-absorbed roots),
+        // a scatter-min of lane numbers, read back with atomic loads (the minimum is formed in L2 / LDS, not in this
+        // CU's vector L1), then restored.
         const bool a_small = in && pre.ca == hdb::NONE16, b_small = in && pre.cb == hdb::NONE16;
         if (a_small) atomicMin(&t.absw[pre.ra], (uint32_t)lane);
         if (b_small) atomicMin(&t.absw[pre.rb], (uint32_t)lane);
@@ -753,67 +765,98 @@ __device__ __forceinline__ bool build_wave(hdb::Tree &t, const hdb::Edge *edges,
         if (b_small) fb = __hip_atomic_load(&t.absw[pre.rb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a_small) __hip_atomic_store(&t.absw[pre.ra], hdb::NO_LANE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (b_small) __hip_atomic_store(&t.absw[pre.rb], hdb::NO_LANE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool big_a = in && (!a_small || fa < (uint32_t)lane), big_b = in && (!b_small || fb < (uint32_t)lane);
-        const unsigned long long stop = __ballot(in && big_a == big_b);
-        const int P = stop ? min(m, (int)__builtin_ctzll(stop)) : m;
-        // cluster of every edge of the prefix: its own if one side was big from the start, else that of the edge which
-        // absorbed its big side's root -- resolved by six rounds of pointer jumping along those links
-        uint32_t cval = hdb::NONE16, ptr = (uint32_t)lane;
-        if (lane < P) {
-            if (!a_small) cval = pre.ca;
-            else if (!b_small) cval = pre.cb;
-            else ptr = big_a ? fa : fb;
-        }
+        // sides: B big at the start, F fresh small root, L small root that an earlier lane contains
+        const bool aB = in && !a_small, bB = in && !b_small;
+        const bool aF = a_small && fa == (uint32_t)lane, bF = b_small && fb == (uint32_t)lane;
+        uint32_t par = (uint32_t)lane, clus = hdb::NONE16, add = 0;
+        bool bad = false;
+        if (aF && bF) add = pre.sa + pre.sb;                          // starts a small tree
+        else if (aF && bB) { clus = pre.cb; add = pre.sa; }           // starts / continues the chain of cluster cb
+        else if (aB && bF) { clus = pre.ca; add = pre.sb; }
+        else if (aF && b_small) { par = fb; add = pre.sa; }           // F + L: attaches to the tree of lane fb
+        else if (bF && a_small) { par = fa; add = pre.sb; }
+        else bad = in;                                                // two existing things meet: ends the prefix
+        // the lane that started this lane's tree: links point to earlier lanes, six rounds of pointer jumping
+        uint32_t root = par;
 #pragma unroll
-        for (int round = 0; round < 6; ++round) {
-            const uint32_t pv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ptr << 2), (int)cval);
-            const uint32_t pp = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ptr << 2), (int)ptr);
-            if (cval == hdb::NONE16) { cval = pv; ptr = pp; }
+        for (int round = 0; round < 6; ++round) root = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(root << 2), (int)root);
+        const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(root << 2), (int)clus);     // cluster of the chain, NONE16: a small tree
+        const bool small_lane = in && !bad && c == hdb::NONE16;
+        // small trees: running size (a tree gives birth to a cluster where it reaches min_cluster_size: ends the
+        // prefix), previous lane of the tree, lanes of the tree.  Trees of one lane need no loop.
+        uint32_t run = add;
+        unsigned long long mygrp = 1ull << lane;
+        unsigned long long todo = __ballot(small_lane && root != (uint32_t)lane);
+        while (todo) {                                   // once per small tree with attachments
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)root, __builtin_ctzll(todo));
+            const bool mine = small_lane && root == r0;
+            const unsigned long long grp = __ballot(mine);
+            const uint32_t sc = wave_incl_scan_u32(mine ? add : 0u);
+            if (mine) { run = sc; mygrp = grp; }
+            todo &= ~grp;
         }
-        const uint32_t ga = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(min(fa, 63u) << 2), (int)cval);
-        const uint32_t gb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(min(fb, 63u) << 2), (int)cval);
-        const uint32_t cur_a = !a_small ? pre.ca : (fa < (uint32_t)lane ? ga : hdb::NONE16);
-        const uint32_t cur_b = !b_small ? pre.cb : (fb < (uint32_t)lane ? gb : hdb::NONE16);
-        const uint32_t v_c = (cur_a & 0xFFFFu) | (cur_b << 16);
+        const unsigned long long stop = __ballot(bad || (small_lane && (int)run >= mcs));
+        const int P = stop ? min(m, (int)__builtin_ctzll(stop)) : m;
         if (P > 0) {
             const bool act = lane < P;
-            const uint32_t ca = v_c & 0xFFFFu, cb = v_c >> 16;
-            const bool abig = ca != hdb::NONE16;
-            const uint32_t c = abig ? ca : cb, r = abig ? pre.rb : pre.ra;
-            const uint32_t s = abig ? pre.sb : pre.sa, ns = abig ? pre.nb : pre.na;
             const uint32_t node = (uint32_t)(n + i0 + lane);
-            uint32_t prev = 0;
-            unsigned long long todo = P == 64 ? ~0ull : ((1ull << P) - 1ull);
-            while (todo) {                               // once per distinct cluster (nearly always one)
-                const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c, __builtin_ctzll(todo));
-                const unsigned long long grp = __ballot(act && c == c0);
-                const uint32_t before = t.cdn[c0];
-                if (act && c == c0) {
-                    const unsigned long long lower = grp & ((1ull << lane) - 1ull);
-                    prev = lower ? (uint32_t)(n + i0 + 63 - __builtin_clzll(lower)) : before;
+            // absorptions: grouped by cluster (several chains of one batch may feed the same cluster)
+            {
+                const bool actc = act && c != hdb::NONE16;
+                const bool abig = !aF;                   // the non-fresh side is the cluster's side
+                const uint32_t r = abig ? pre.rb : pre.ra, s = abig ? pre.sb : pre.sa, ns = abig ? pre.nb : pre.na;
+                uint32_t prev = 0;
+                unsigned long long todoc = __ballot(actc);
+                while (todoc) {                          // once per distinct cluster (nearly always one)
+                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c, __builtin_ctzll(todoc));
+                    const unsigned long long grp = __ballot(actc && c == c0);
+                    const uint32_t before = t.cdn[c0];
+                    if (actc && c == c0) {
+                        const unsigned long long lower = grp & below;
+                        prev = lower ? (uint32_t)(n + i0 + 63 - __builtin_clzll(lower)) : before;
+                    }
+                    if (lane == 0) t.cdn[c0] = (uint32_t)(n + i0 + 63 - __builtin_clzll(grp));
+                    todoc &= ~grp;
                 }
-                if (lane == 0) t.cdn[c0] = (uint32_t)(n + i0 + 63 - __builtin_clzll(grp));
-                todo &= ~grp;
+                if (actc) {
+                    t.dparent[abig ? prev : ns] = node << 1;
+                    t.dparent[abig ? ns : prev] = (node << 1) | 1u;
+                    t.absc[r] = (uint16_t)c; t.absw[r] = e.w;
+                    t.evc[i0 + lane] = (uint16_t)c; t.evs[i0 + lane] = (uint16_t)s;
+                    atomicAdd(&t.csize[c], s);
+                }
             }
-            if (act) {
-                t.dparent[abig ? prev : ns] = node << 1;
-                t.dparent[abig ? ns : prev] = (node << 1) | 1u;
-                t.absc[r] = (uint16_t)c; t.absw[r] = e.w;
-                t.evc[i0 + lane] = (uint16_t)c; t.evs[i0 + lane] = (uint16_t)s;
-                atomicAdd(&t.csize[c], s);
+            // unions inside small trees; the tree's union-find root is its starter's a side
+            {
+                const bool acts = act && c == hdb::NONE16;
+                const uint32_t R = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(root << 2), (int)pre.ra);
+                const unsigned long long grpP = mygrp & (P == 64 ? ~0ull : ((1ull << P) - 1ull));
+                const int last = grpP ? 63 - __builtin_clzll(grpP) : lane;
+                if (acts) {
+                    t.evc[i0 + lane] = (uint16_t)hdb::NONE16; t.evs[i0 + lane] = 0;
+                    if (root == (uint32_t)lane) {
+                        t.dparent[pre.na] = node << 1;
+                        t.dparent[pre.nb] = (node << 1) | 1u;
+                        t.sp[pre.rb] = (uint16_t)R;
+                    } else {
+                        const unsigned long long lower = mygrp & below;
+                        const uint32_t pn = (uint32_t)(n + i0 + 63 - __builtin_clzll(lower));      // the starter is always below
+                        const uint32_t rf = aF ? pre.ra : pre.rb, nf = aF ? pre.na : pre.nb;
+                        t.dparent[aF ? nf : pn] = node << 1;            // the a side is the left child
+                        t.dparent[aF ? pn : nf] = (node << 1) | 1u;
+                        t.sp[rf] = (uint16_t)R;
+                    }
+                    if (lane == last) { t.ssz[R] = (uint16_t)run; t.sdn[R] = node; }
+                }
             }
             i0 += P;
         }
-        if (P < m) {
-            hdb::Resolved q;
-            const uint32_t rr = (uint32_t)__builtin_amdgcn_readlane((int)v_r, P);
-            const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)v_c, P);
-            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)e.w, P);
-            q.ra = rr & 0xFFFFu; q.rb = rr >> 16;
-            q.ca = cc & 0xFFFFu; q.cb = cc >> 16;
-            q.sa = q.sb = q.na = q.nb = 0;
+        if (P < m) {                                     // the roots may have moved (unions): resolve afresh
             int ok = 1;
-            if (lane == 0) ok = hdb::merge(t, i0, n, mcs, w, q) ? 1 : 0;
+            if (lane == 0) {
+                const hdb::Edge ep = edges[i0];
+                ok = hdb::merge(t, i0, n, mcs, ep.w, hdb::resolve(t, ep)) ? 1 : 0;
+            }
             if (!__builtin_amdgcn_readfirstlane(ok)) return false;
             ++i0;
         }
@@ -986,22 +1029,244 @@ __device__ __forceinline__ int cluster_phase(const TailArgs &A, uint8_t *ws, uin
     return S.best;
 }
 
-// k_sort: stable sort of the MST edges by weight (three 6-bit passes), 1024 threads per map
+// --------------------------------------------------------------------------------------
+// k_sort: the MST edges in the order numpy's default argsort gives them (hdbscan sorts the edge list with
+// np.argsort before the single-linkage pass; call site smartVidCrop.py:1099).  That sort is an UNSTABLE
+// introsort, and on a pixel grid nearly all weights tie, so the order of equal weights is part of the
+// reference's result: it decides which components merge first (oracle/npsort_ref.py has the restatement and
+// what a different order costs).  The sequential routine is emulated exactly, level by level:
+//   * all ranges of more than 16 elements that are alive at one depth of the recursion are partitioned at the same
+//     time.  A range's median-of-three and pivot parking are done by one thread; the Hoare scan is data parallel:
+//     with L = positions (ascending) whose key is >= the pivot and R = positions (descending) whose key is <= it,
+//     the sequential scan swaps L[k] with R[k] while L[k] < R[k] and ends with the left pointer on
+//     min(L[K], R[K-1]) -- two prefix sums over the whole array give every stopper its k, the swaps are disjoint.
+//   * the depth bookkeeping of the explicit stack is kept per range: the larger side is "pushed" and heap-sorted
+//     (by one thread, exactly as numpy's heapsort) if it is reached below the depth limit; the other side
+//     continues without a check.  Only adversarial inputs get there.
+//   * ranges of at most 16 elements are insertion-sorted by numpy: a stable sort of the range, done here as a rank
+//     computation (one thread per element) at the very end.
+// Working arrays (16 bytes per edge) live in LDS for N <= ~6000 and in the frame's workspace above that.
+// --------------------------------------------------------------------------------------
+#define SORT_LDS_BYTES (104 * 1024)
+#define SORT_NONE 0xFFFFu
+#define SORT_SMALL 15            // ranges with hi - lo > 15 are partitioned (npsort_ref.SMALL_QUICKSORT)
+
+struct SortArrays {              // n entries each
+    uint32_t *key, *scan;
+    uint16_t *idx, *seg, *lpos, *rpos;
+};
+struct SortSegs {                // capacity n / 17 + 2 ranges, two generations
+    uint16_t *lo[2], *hi[2], *pi, *ls, *rs;
+    int16_t *dep[2];
+    uint32_t *vp, *K;
+};
+
+__device__ __forceinline__ void sort_swap(const SortArrays &a, int i, int j) {
+    const uint32_t k = a.key[i]; a.key[i] = a.key[j]; a.key[j] = k;
+    const uint16_t x = a.idx[i]; a.idx[i] = a.idx[j]; a.idx[j] = x;
+}
+
+// numpy's aheapsort on positions lo .. lo+n-1 (keys and indices move together)
+__device__ void sort_heapsort(const SortArrays &a, int lo, int n) {
+#define HK(i) a.key[lo + (i) - 1]
+#define HI(i) a.idx[lo + (i) - 1]
+    for (int l = n >> 1; l > 0; --l) {
+        const uint32_t tk = HK(l); const uint16_t ti = HI(l);
+        int i = l, j = l << 1;
+        while (j <= n) {
+            if (j < n && HK(j) < HK(j + 1)) ++j;
+            if (tk < HK(j)) { HK(i) = HK(j); HI(i) = HI(j); i = j; j += j; } else break;
+        }
+        HK(i) = tk; HI(i) = ti;
+    }
+    for (; n > 1;) {
+        const uint32_t tk = HK(n); const uint16_t ti = HI(n);
+        HK(n) = HK(1); HI(n) = HI(1);
+        --n;
+        int i = 1, j = 2;
+        while (j <= n) {
+            if (j < n && HK(j) < HK(j + 1)) ++j;
+            if (tk < HK(j)) { HK(i) = HK(j); HI(i) = HI(j); i = j; j += j; } else break;
+        }
+        HK(i) = tk; HI(i) = ti;
+    }
+#undef HK
+#undef HI
+}
+
+// out[p] = index (into the caller's key order) of the element numpy's argsort puts at position p.
+// a.key[0..n) holds the keys on entry.  All TB threads of the block call this.
+__device__ void np_argsort_block(const SortArrays &a, const SortSegs &st, int n, uint16_t *out, int *sh /* [NW16 + 4] */) {
+    const int tid = threadIdx.x;
+    int *cnt = sh + NW16;                                  // cnt[0], cnt[1]: ranges of the two generations
+    for (int i = tid; i < n; i += TB) { a.idx[i] = (uint16_t)i; a.seg[i] = 0; a.lpos[i] = 0; a.rpos[i] = (uint16_t)(n - 1); }
+    if (tid == 0) {
+        cnt[0] = cnt[1] = 0;
+        if (n - 1 > SORT_SMALL) {
+            int d = 0;
+            for (int v = n >> 1; v; v >>= 1) ++d;          // npy_get_msb(n)
+            st.lo[0][0] = 0; st.hi[0][0] = (uint16_t)(n - 1); st.dep[0][0] = (int16_t)(2 * d);
+            cnt[0] = 1;
+        }
+    }
+    __syncthreads();
+    if (cnt[0] == 0) {                                     // one small range: seg stays "retired" with bounds [0, n-1]
+        for (int i = tid; i < n; i += TB) a.seg[i] = SORT_NONE;
+    }
+    const int C = (n + TB - 1) / TB, c_lo = min(n, tid * C), c_hi = min(n, c_lo + C);
+    int cur = 0;
+    while (true) {
+        const int ns = cnt[cur];
+        if (ns == 0) break;
+        const int nxt = cur ^ 1;
+        // 1. median of three, pivot parked at hi - 1
+        for (int s = tid; s < ns; s += TB) {
+            const int pl = st.lo[cur][s], pr = st.hi[cur][s], pm = pl + ((pr - pl) >> 1);
+            if (a.key[pm] < a.key[pl]) sort_swap(a, pm, pl);
+            if (a.key[pr] < a.key[pm]) sort_swap(a, pr, pm);
+            if (a.key[pm] < a.key[pl]) sort_swap(a, pm, pl);
+            st.vp[s] = a.key[pm];
+            sort_swap(a, pm, pr - 1);
+            st.K[s] = 0;
+        }
+        __syncthreads();
+        // 2. stoppers of the two scans, counted by one prefix sum over the array (L in the low half, R in the high half)
+        uint32_t acc = 0;
+        for (int i = c_lo; i < c_hi; ++i) {
+            const uint32_t sg = a.seg[i];
+            if (sg != SORT_NONE) {
+                const int pl = st.lo[cur][sg], pr = st.hi[cur][sg];
+                const uint32_t vp = st.vp[sg], k = a.key[i];
+                acc += (uint32_t)(i > pl && i <= pr - 1 && k >= vp) | ((uint32_t)(i <= pr - 2 && k <= vp) << 16);
+            }
+            a.scan[i] = acc;
+        }
+        int tot;
+        const uint32_t off = (uint32_t)block_excl_scan((int)acc, sh, &tot);
+        for (int i = c_lo; i < c_hi; ++i) a.scan[i] += off;
+        __syncthreads();
+        // 3. L[k] ascending, R[k] descending, into the range's own slice of the position arrays
+        for (int i = tid; i < n; i += TB) {
+            const uint32_t sg = a.seg[i];
+            if (sg == SORT_NONE) continue;
+            const int pl = st.lo[cur][sg], pr = st.hi[cur][sg];
+            const uint32_t vp = st.vp[sg], k = a.key[i], sc = a.scan[i], base = pl > 0 ? a.scan[pl - 1] : 0u;
+            if (i > pl && i <= pr - 1 && k >= vp) a.lpos[pl + (int)((sc & 0xFFFFu) - (base & 0xFFFFu)) - 1] = (uint16_t)i;
+            if (i <= pr - 2 && k <= vp) a.rpos[pl + (int)((a.scan[pr - 2] >> 16) - (sc >> 16))] = (uint16_t)i;
+        }
+        __syncthreads();
+        // 4. the swaps of the scan: L[k] <-> R[k] while L[k] < R[k]
+        for (int i = tid; i < n; i += TB) {
+            const uint32_t sg = a.seg[i];
+            if (sg == SORT_NONE) continue;
+            const int pl = st.lo[cur][sg], pr = st.hi[cur][sg], k = i - pl;
+            const uint32_t base = pl > 0 ? a.scan[pl - 1] : 0u;
+            const int nL = (int)((a.scan[pr - 1] & 0xFFFFu) - (base & 0xFFFFu)), nR = (int)((a.scan[pr - 2] >> 16) - (base >> 16));
+            if (k < nL && k < nR) {
+                const int l = a.lpos[pl + k], r = a.rpos[pl + k];
+                if (l < r) { sort_swap(a, l, r); atomicMax(&st.K[sg], (uint32_t)(k + 1)); }
+            }
+        }
+        __syncthreads();
+        // 5. where the left pointer ends, the pivot goes there, the two sides become ranges of the next generation
+        for (int s = tid; s < ns; s += TB) {
+            const int pl = st.lo[cur][s], pr = st.hi[cur][s], K = (int)st.K[s];
+            const uint32_t base = pl > 0 ? a.scan[pl - 1] : 0u;
+            const int nL = (int)((a.scan[pr - 1] & 0xFFFFu) - (base & 0xFFFFu));
+            const int rprev = K >= 1 ? (int)a.rpos[pl + K - 1] : pr;
+            int pi = rprev;
+            if (K < nL && (int)a.lpos[pl + K] < rprev) pi = a.lpos[pl + K];
+            sort_swap(a, pi, pr - 1);
+            st.pi[s] = (uint16_t)pi;
+            const int d = st.dep[cur][s] - 1;
+            const bool push_right = (pi - pl) < (pr - pi);          // the larger side goes on numpy's stack
+            uint16_t slot[2];
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int lo = side ? pi + 1 : pl, hi = side ? pr : pi - 1;
+                const bool popped = side ? push_right : !push_right;
+                slot[side] = SORT_NONE;
+                if (hi < lo) continue;
+                if (popped && d < 0) {                               // depth limit: numpy heap-sorts a popped range
+                    sort_heapsort(a, lo, hi - lo + 1);
+                    for (int e = lo; e <= hi; ++e) { a.lpos[e] = (uint16_t)e; a.rpos[e] = (uint16_t)e; }
+                } else if (hi - lo > SORT_SMALL) {
+                    const int q = atomicAdd(&cnt[nxt], 1);
+                    st.lo[nxt][q] = (uint16_t)lo; st.hi[nxt][q] = (uint16_t)hi; st.dep[nxt][q] = (int16_t)d;
+                    slot[side] = (uint16_t)q;
+                } else {
+                    for (int e = lo; e <= hi; ++e) { a.lpos[e] = (uint16_t)lo; a.rpos[e] = (uint16_t)hi; }
+                }
+            }
+            a.lpos[pi] = (uint16_t)pi; a.rpos[pi] = (uint16_t)pi;
+            st.ls[s] = slot[0]; st.rs[s] = slot[1];
+        }
+        __syncthreads();
+        // 6. every element moves to its side's range
+        for (int i = tid; i < n; i += TB) {
+            const uint32_t sg = a.seg[i];
+            if (sg == SORT_NONE) continue;
+            const int pi = st.pi[sg];
+            a.seg[i] = i < pi ? st.ls[sg] : (i > pi ? st.rs[sg] : (uint16_t)SORT_NONE);
+        }
+        if (tid == 0) cnt[cur] = 0;
+        cur = nxt;
+        __syncthreads();
+    }
+    // insertion sort of every remaining range = a stable sort of the range: rank of each element
+    for (int i = tid; i < n; i += TB) {
+        const int lo = a.lpos[i], hi = a.rpos[i];
+        const uint32_t k = a.key[i];
+        int rank = 0;
+        for (int j = lo; j <= hi; ++j) {
+            const uint32_t kj = a.key[j];
+            rank += (kj < k || (kj == k && j < i)) ? 1 : 0;
+        }
+        out[lo + rank] = a.idx[i];
+    }
+    __syncthreads();
+}
+
+// carve the working arrays of np_argsort_block: in LDS when they fit, else in the caller's global scratch
+__device__ __forceinline__ void sort_carve(uint8_t *lds, uint8_t *glob, int n, SortArrays &a, SortSegs &st, int *&sh) {
+    uint8_t *p = lds;
+    sh = carve<int>(p, NW16 + 4);
+    const int nseg = n / 17 + 2;
+    for (int g = 0; g < 2; ++g) { st.lo[g] = carve<uint16_t>(p, nseg); st.hi[g] = carve<uint16_t>(p, nseg); st.dep[g] = carve<int16_t>(p, nseg); }
+    st.pi = carve<uint16_t>(p, nseg); st.ls = carve<uint16_t>(p, nseg); st.rs = carve<uint16_t>(p, nseg);
+    st.vp = carve<uint32_t>(p, nseg); st.K = carve<uint32_t>(p, nseg);
+    uint8_t *q = ((size_t)(p - lds) + (size_t)n * 16 + 6 * 16 <= SORT_LDS_BYTES) ? p : glob;
+    a.key = carve<uint32_t>(q, n); a.scan = carve<uint32_t>(q, n);
+    a.idx = carve<uint16_t>(q, n); a.seg = carve<uint16_t>(q, n); a.lpos = carve<uint16_t>(q, n); a.rpos = carve<uint16_t>(q, n);
+}
+
 __global__ __launch_bounds__(TB) void k_sort(TailArgs A) {
     const int f = blockIdx.x;
     if (A.depth[f] != A.round) return;
     uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
     int32_t *hdr = (int32_t *)(ws + A.L.hdr);
     if (!hdr[3]) return;
-    const int N = hdr[0];
-    __shared__ int hist[64], run[64];
-    __shared__ uint16_t wcnt[NW16 * 64];
+    const int n = hdr[0] - 1;
+    extern __shared__ uint8_t sm_sort[];
     const long long t0 = wall_clock64();
-    hdb::Edge *mst = (hdb::Edge *)(ws + A.L.mst), *ea = (hdb::Edge *)(ws + A.L.ea), *eb = (hdb::Edge *)(ws + A.L.eb);
-    radix_pass(mst, ea, N - 1, 0, hist, run, wcnt);
-    radix_pass(ea, eb, N - 1, 6, hist, run, wcnt);
-    radix_pass(eb, ea, N - 1, 12, hist, run, wcnt);
+    const hdb::Edge *mst = (const hdb::Edge *)(ws + A.L.mst);
+    hdb::Edge *ea = (hdb::Edge *)(ws + A.L.ea);
+    SortArrays a; SortSegs st; int *sh;
+    sort_carve(sm_sort, ws + A.L.srt, n, a, st, sh);
+    for (int i = threadIdx.x; i < n; i += TB) a.key[i] = mst[i].w;
+    uint16_t *perm = (uint16_t *)(ws + A.L.eb);            // sorted position -> Prim position
+    np_argsort_block(a, st, n, perm, sh);
+    for (int i = threadIdx.x; i < n; i += TB) ea[i] = mst[perm[i]];
     if (threadIdx.x == 0) hdr[8] = (int)(wall_clock64() - t0);
+}
+
+// test door (svc_debug_argsort_u32): the same routine on arbitrary keys
+__global__ __launch_bounds__(TB) void k_argsort_test(const uint32_t *keys, int n, uint16_t *out, uint8_t *scratch) {
+    extern __shared__ uint8_t sm_sort[];
+    SortArrays a; SortSegs st; int *sh;
+    sort_carve(sm_sort, scratch, n, a, st, sh);
+    for (int i = threadIdx.x; i < n; i += TB) a.key[i] = keys[i];
+    np_argsort_block(a, st, n, out, sh);
 }
 
 // k_tree: hierarchy + excess of mass + labels + cluster weights + the kept cluster.  The build is a
@@ -1280,6 +1545,7 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
         SVC_HIP(hipFuncSetAttribute((const void *)k_prim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_tree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_sort, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_BYTES));
     }
     for (int r = 0; r <= maxd; ++r) {
         A.round = r;
@@ -1310,7 +1576,7 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
         {
             ProfScope ps(h, SVC_K_FINISH, s);
             if (params->clust_filt) {
-                k_sort<<<n, TB, 0, s>>>(A);
+                k_sort<<<n, TB, SORT_LDS_BYTES, s>>>(A);
                 SVC_CHECK_LAUNCH();
                 k_tree<<<n, 64, FIN_LDS_BYTES, s>>>(A);
                 SVC_CHECK_LAUNCH();
@@ -1331,6 +1597,25 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
         SVC_CHECK_LAUNCH();
     }
     return SVC_OK;
+}
+
+extern "C" int svc_debug_argsort_u32(SvcHandle *h, const uint32_t *keys_host, int n, int32_t *order_host) {
+    if (!h || !keys_host || !order_host || n < 1 || n > 65535) { svc_set_error("svc_debug_argsort_u32: invalid argument"); return SVC_E_INVALID; }
+    SVC_HIP(hipSetDevice(h->device));
+    DevBuf keys, out, scratch;
+    int rc;
+    if ((rc = keys.ensure((size_t)n * 4)) || (rc = out.ensure((size_t)n * 2)) || (rc = scratch.ensure((size_t)n * 16 + 128))) return rc;
+    SVC_HIP(hipMemcpy(keys.p, keys_host, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (h->lds_attr_done.insert((const void *)k_argsort_test).second)
+        SVC_HIP(hipFuncSetAttribute((const void *)k_argsort_test, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_BYTES));
+    k_argsort_test<<<1, TB, SORT_LDS_BYTES, 0>>>((const uint32_t *)keys.p, n, (uint16_t *)out.p, (uint8_t *)scratch.p);
+    SVC_CHECK_LAUNCH();
+    SVC_HIP(hipDeviceSynchronize());
+    std::vector<uint16_t> o(n);
+    SVC_HIP(hipMemcpy(o.data(), out.p, (size_t)n * 2, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) order_host[i] = o[i];
+    keys.release(); out.release(); scratch.release();
+    return n;
 }
 
 extern "C" int svc_debug_cluster_state(SvcHandle *h, int frame, int cap, uint32_t *pts_host, uint32_t *core_host,

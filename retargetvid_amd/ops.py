@@ -117,6 +117,14 @@ class Engine:
         _lib.check(self.lib.svc_profile_read(self._h, ctypes.byref(ms), ctypes.byref(cnt)))
         return ms.value, cnt.value
 
+    def argsort_u32(self, keys):
+        """Test door: the device's emulation of numpy's default argsort on uint32 keys -> int32 order."""
+        keys = np.ascontiguousarray(keys, np.uint32)
+        out = np.empty(keys.size, np.int32)
+        vp = ctypes.c_void_p
+        _lib.check(self.lib.svc_debug_argsort_u32(self._h, keys.ctypes.data_as(vp), keys.size, out.ctypes.data_as(vp)))
+        return out
+
     def cluster_state(self, frame, cap):
         pts = np.zeros(cap, np.uint32)
         core = np.zeros(cap, np.uint32)

@@ -89,10 +89,20 @@ def _loess_design(n, window, degree):
     and, for degree > 1, the operator pinv(X^T W X) X^T W of every point (pyloess.py:60-83)."""
     with np.errstate(all='ignore'):
         nx = np.arange(n, dtype=np.float64) / (n - 1)
-        h = window // 2
+        h = (window - 1) // 2
         j = np.arange(n)
-        # neighbourhood chosen by get_min_range: grow right on ties, clamp at the ends
-        lo = np.clip(j - h, 0, n - window)
+        # neighbourhood chosen by get_min_range (pyloess.py:27-48): the nearer of the two outer neighbours joins next,
+        # the right one on a tie, clamped at the ends -> the symmetric 2h+1 points around j; an even window (never
+        # produced by sc_smoothing, :1668-1670) takes one more point, decided by the same float64 comparison
+        lo = np.clip(j - h, 0, n - (2 * h + 1))
+        if window % 2 == 0:
+            hi = lo + 2 * h
+            dl = np.abs(nx[np.maximum(lo - 1, 0)] - nx[j])
+            dr = np.abs(nx[np.minimum(hi + 1, n - 1)] - nx[j])
+            left = (hi == n - 1) | ((lo > 0) & (dl < dr))
+            left &= (j != 0)                                          # argmin at an end: arange(0, window) / arange(n - window, n)
+            left |= (j == n - 1)
+            lo = np.where(left, lo - 1, lo)
         idx = lo[:, None] + np.arange(window)[None, :]                # [n, window]
         dist = np.abs(nx[idx] - nx[j][:, None])
         r = dist / dist.max(axis=1, keepdims=True)

@@ -2,7 +2,11 @@
 // inlines).  Built by tests/ only (g++), never loaded by the product.
 #include <algorithm>
 #include <vector>
+static int g_batches = 0;                      // batches (= serial steps of the device's one-wavefront pass) of the last batched run
+#define HDB_COUNT_BATCHES g_batches
 #include "../../retargetvid_amd/csrc/hdb_tree.h"
+
+extern "C" int tree_last_batches(void) { return g_batches; }
 
 static int run(const uint16_t *a, const uint16_t *b, const uint32_t *w, int n, int mcs, int32_t *labels, int batched);
 
@@ -14,6 +18,7 @@ extern "C" int tree_labels(const uint16_t *a, const uint16_t *b, const uint32_t 
 // the batched form of the pass (what the GPU runs): batch of 64 edges resolved up front
 extern "C" int tree_labels_batched(const uint16_t *a, const uint16_t *b, const uint32_t *w, int n, int mcs,
                                    int32_t *labels) {
+    g_batches = 0;
     return run(a, b, w, n, mcs, labels, 1);
 }
 

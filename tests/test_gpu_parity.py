@@ -278,3 +278,18 @@ def test_iou_bit_exact(engine):
     assert np.array_equal(got, ref)
     from retargetvid_amd import smartVidCrop as S
     assert S.bb_intersection_over_union([0, 0, 9, 9], [5, 0, 14, 9]) == T.iou([0, 0, 9, 9], [5, 0, 14, 9])
+
+
+def test_device_edge_order_equals_numpy_argsort(engine, golden_dir):
+    """k_sort's routine (numpy's default argsort -- an unstable introsort -- emulated in parallel) against numpy's own
+    permutations: tie-heavy, sorted, reversed, random and adversarial arrays (the latter reach the depth limit, i.e. the
+    heapsort fall-back), the LDS and the global-memory form (n > ~6000), bit for bit."""
+    from oracle import npsort_ref
+    g = np.load(os.path.join(golden_dir, 'npsort_golden.npz'))
+    for i in range(int(g['n'])):
+        w, o = g['w_%d' % i], g['o_%d' % i]
+        assert np.array_equal(engine.argsort_u32(w.astype(np.uint32)), o), (i, len(w))
+    rng = np.random.RandomState(11)
+    for n, hi in ((6500, 12), (20000, 40), (34999, 7), (34999, 100000)):
+        w = rng.randint(1, hi, n).astype(np.uint32)
+        assert np.array_equal(engine.argsort_u32(w), np.array(npsort_ref.argsort(w.tolist()))), (n, hi)

@@ -723,14 +723,19 @@ struct TreeShared {
     int nsel, best, ok;
 };
 
-// wave-wide inclusive prefix sum (64 lanes)
+// wave-wide inclusive prefix sum (64 lanes) as six DPP-fused additions: a Hillis-Steele scan inside every row of 16
+// lanes (row_shr 1, 2, 4, 8; lanes without a source add 0), then the row totals are carried into the rows above
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add_u32(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)v, o);
-        if (lane >= o) v += t;
-    }
+    v = dpp_add_u32<0x111, 0xF>(v);
+    v = dpp_add_u32<0x112, 0xF>(v);
+    v = dpp_add_u32<0x114, 0xF>(v);
+    v = dpp_add_u32<0x118, 0xF>(v);
+    v = dpp_add_u32<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_add_u32<0x143, 0xC>(v);      // row_bcast:31 into rows 2 and 3
     return v;
 }
 
@@ -753,6 +758,11 @@ __device__ __forceinline__ bool build_wave(hdb::Tree &t, const hdb::Edge *edges,
         if (in) {
             e = edges[i0 + lane];
             pre = hdb::resolve_ro(t, e);
+            // the walk to the top cluster is not compressed by resolve_ro; with numpy's edge order a map has dozens of
+            // clusters whose union-find chains grow with every split, so shorten them here: the cluster that absorbed
+            // a root now points straight to its top (lanes race with equal or equally valid ancestors)
+            if (pre.ca != hdb::NONE16) { const uint16_t c0 = t.absc[pre.ra]; if (c0 != pre.ca) t.cup[c0] = (uint16_t)pre.ca; }
+            if (pre.cb != hdb::NONE16) { const uint16_t c0 = t.absc[pre.rb]; if (c0 != pre.cb) t.cup[c0] = (uint16_t)pre.cb; }
         }
         // First lane of the batch that contains each small root: the table is absw[] (unused for un-absorbed roots),
         // a scatter-min of lane numbers, read back with atomic loads (the minimum is formed in L2 / LDS, not in this
@@ -778,8 +788,11 @@ __device__ __forceinline__ bool build_wave(hdb::Tree &t, const hdb::Edge *edges,
         else bad = in;                                                // two existing things meet: ends the prefix
         // the lane that started this lane's tree: links point to earlier lanes, six rounds of pointer jumping
         uint32_t root = par;
-#pragma unroll
-        for (int round = 0; round < 6; ++round) root = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(root << 2), (int)root);
+        for (int round = 0; round < 6; ++round) {         // links point to earlier lanes: at most six rounds, usually one or two
+            const uint32_t up = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(root << 2), (int)root);
+            if (!__ballot(up != root)) break;
+            root = up;
+        }
         const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(root << 2), (int)clus);     // cluster of the chain, NONE16: a small tree
         const bool small_lane = in && !bad && c == hdb::NONE16;
         // small trees: running size (a tree gives birth to a cluster where it reaches min_cluster_size: ends the

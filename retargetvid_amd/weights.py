@@ -162,6 +162,81 @@ def make_synthetic_state_dict(seed=0, carrier=True, gain=0.5, noise=0.02):
     return sd
 
 
+def make_reference_init_state_dict(seed=7, bn_stats=None):
+    """A checkpoint initialised the way the reference class initialises itself, from a NumPy seed.
+
+    Same keys and the same DISTRIBUTIONS as a freshly constructed ``UNISAL`` (no carrier channel, no structure):
+    backbone and decoder InvertedResidual convs N(0, sqrt(2 / (k*k*out_channels))) (MobileNetV2.py:85-98,:175-188),
+    BatchNorm gamma 1 / beta 0, the skip / adaptation convs PyTorch's default kaiming-uniform
+    U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias (model.py:208-246,:257-262), the smoothing kernel the
+    normalised Gaussian of model.py:264-272 and the 16 manual Gaussian priors of model.py:323-331.  The values come
+    from NumPy (torch's own RNG stream cannot be reproduced without the reference's constructor), so the big
+    tensors are reproducible anywhere from the seed.
+
+    ``bn_stats``: {'<bn prefix>.running_mean' / '.running_var': array} -- running statistics calibrated by the
+    REFERENCE model itself in the build container (BatchNorm layers in train mode over seeded frames,
+    tools/make_golden_unisal.py) and stored with the golden vectors (small); without it the statistics are the
+    constructor's (0, 1)."""
+    rng = np.random.RandomState(seed)
+    sd = {}
+
+    def conv_he(key, cout, cin, k):
+        sd[key] = (rng.normal(0, 1, (cout, cin, k, k)) * np.sqrt(2.0 / (k * k * cout))).astype(np.float32)
+
+    def conv_default(key, cout, cin, k, bias):
+        bound = 1.0 / np.sqrt(cin * k * k)
+        sd[key + '.weight'] = rng.uniform(-bound, bound, (cout, cin, k, k)).astype(np.float32)
+        if bias:
+            sd[key + '.bias'] = rng.uniform(-bound, bound, cout).astype(np.float32)
+
+    def bn(prefix, c, dsbn):
+        p = prefix + ('.bn_SALICON' if dsbn else '')
+        sd[p + '.weight'] = np.ones(c, np.float32)
+        sd[p + '.bias'] = np.zeros(c, np.float32)
+        sd[p + '.running_mean'] = np.zeros(c, np.float32)
+        sd[p + '.running_var'] = np.ones(c, np.float32)
+
+    def inv_res(prefix, inp, oup, expand, dsbn):
+        hidden = round(inp * expand)
+        if expand == 1:
+            conv_he(prefix + '.0.weight', hidden, 1, 3); bn(prefix + '.1', hidden, dsbn)
+            conv_he(prefix + '.3.weight', oup, hidden, 1); bn(prefix + '.4', oup, dsbn)
+        else:
+            conv_he(prefix + '.0.weight', hidden, inp, 1); bn(prefix + '.1', hidden, dsbn)
+            conv_he(prefix + '.3.weight', hidden, 1, 3); bn(prefix + '.4', hidden, dsbn)
+            conv_he(prefix + '.6.weight', oup, hidden, 1); bn(prefix + '.7', oup, dsbn)
+
+    conv_he('cnn.features.0.0.weight', 32, 3, 3)
+    bn('cnn.features.0.1', 32, False)
+    for idx, inp, oup, stride, expand in backbone_blocks():
+        inv_res('cnn.features.%d.conv' % idx, inp, oup, expand, False)
+    conv_he('cnn.features.18.0.weight', 1280, 320, 1)
+    bn('cnn.features.18.1', 1280, False)
+    inv_res('post_cnn.inv_res.conv', 1296, 256, 1, False)      # plain BatchNorm (model.py:192-200)
+    for name, cin, cout in (('skip_2x', 160, 128), ('skip_4x', 64, 64)):
+        conv_default(name + '.expansion.0', cin * 2, cin, 1, False)
+        bn(name + '.expansion.1', cin * 2, True)
+        conv_default(name + '.reduction.0', cout, cin * 2, 1, True)
+        bn(name + '.reduction.1', cout, True)
+    inv_res('upsampling_2.inv_res.conv', 384, 128, 2, True)
+    inv_res('post_upsampling_2.inv_res.conv', 192, 64, 2, True)
+    conv_default('adaptation_salicon.0', 1, 64, 1, True)
+    ax = np.linspace(0, 1, 41)
+    g1 = np.exp(-((ax - 0.5) / np.exp(-2.0)) ** 2 / 2)
+    k = np.outer(g1, g1)
+    sd['smoothing_salicon.weight'] = (k / k.sum()).astype(np.float32).reshape(1, 1, 41, 41)
+    mus = ([(a, b) for a in (0.25, 0.5, 0.75) for b in (0.25, 0.5, 0.75)] +
+           [(0.5, 0.25), (0.5, 0.5), (0.5, 0.75), (0.25, 0.5), (0.5, 0.5), (0.75, 0.5), (0.5, 0.5)])
+    ls = [(-1.5, -1.5)] * 9 + [(0, -1.5)] * 3 + [(-1.5, 0)] * 3 + [(0, 0)]
+    sd['coarse_gaussians_salicon'] = np.stack([np.array(mus, np.float32), np.array(ls, np.float32)], axis=2)
+    if bn_stats is not None:
+        for kname, v in bn_stats.items():
+            if kname not in sd:
+                raise KeyError('bn_stats key %s is not a BatchNorm statistic of the static SALICON slice' % kname)
+            sd[kname] = np.asarray(v, np.float32)
+    return sd
+
+
 def to_numpy_state_dict(sd):
     """Accept a torch or numpy state-dict (e.g. torch.load('weights_best.pth'))."""
     out = {}

@@ -50,6 +50,44 @@ def test_forward_matches_reference_model(golden_dir, synthetic_sd):
         assert np.abs(lp - g['logp_%d' % i]).max() < 1e-4
 
 
+def _golden2_checkpoint(g, ck):
+    from retargetvid_amd import weights
+    if ck == 'nc':
+        return weights.make_synthetic_state_dict(3, carrier=False)
+    stats = {k[3:]: g[k] for k in g.files if k.startswith('bn/')}
+    return weights.make_reference_init_state_dict(7, stats)
+
+
+def test_forward_matches_reference_model_without_carrier_all_geometries(golden_dir):
+    """tests/golden/unisal_golden2.npz (tools/make_golden_unisal2.py): the reference model on a non-carrier random
+    checkpoint and on a reference-initialised one (BatchNorm statistics calibrated by the reference model itself),
+    at the 16:9, 4:3 and portrait network geometries, every frame: log-softmax maps, u8 maps, taps of frame 0."""
+    torch.set_num_threads(4)
+    g = np.load(os.path.join(golden_dir, 'unisal_golden2.npz'))
+    for ck in ('nc', 'ri'):
+        sd = _golden2_checkpoint(g, ck)
+        for gname in ('16x9', '4x3', 'port'):
+            frames = g['frames_' + gname]
+            h, w = frames.shape[1:3]
+            taps = {}
+            maps = U.saliency_u8(sd, frames, taps)
+            for i in range(frames.shape[0]):
+                tag = '%s_%s_%d' % (ck, gname, i)
+                t = taps['frames'][i]
+                lp = torch.log_softmax(t['pre'].reshape(1, -1), 1).reshape(h, w).numpy()
+                assert np.abs(lp - g['logp_' + tag]).max() < 2e-5, tag
+                d = np.abs(maps[:, :, i].astype(int) - g['u8_' + tag].astype(int))
+                assert d.max() <= 1 and (d > 0).mean() < 2e-3, tag
+                if i == 0:
+                    for k in ('feat_2x', 'post_cnn'):
+                        ref = g['%s_%s' % (k, tag)]
+                        assert np.allclose(t[k][0].numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max()), (k, tag)
+                    ref = g['adapt_' + tag]
+                    assert np.allclose(t['adapt'][0].numpy(), ref[0], rtol=1e-4, atol=1e-5 * np.abs(ref).max()), tag
+    # the reference-initialised maps are not flat: the u8 map spans well over 100 grey levels
+    assert np.ptp(g['u8_ri_16x9_0']) > 100
+
+
 def test_quantise_is_floor_of_scaled_softmax():
     x = torch.randn(2, 140, 250)
     q = U.quantise_u8(x)

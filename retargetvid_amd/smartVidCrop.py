@@ -196,10 +196,70 @@ def _select_frames(n_frames, frame_count, trans_inds, skip, read_batch):
     return true_inds, map2orig, batches
 
 
+_STAGE_BYTES = 96 << 20        # pinned / device staging buffer size of the host-fed ingest (two of each per engine)
+
+
+class _HostFeed:
+    """Host frames -> saliency-size frames on the device, selection applied BEFORE the copy, with the copies off the
+    critical path: two pinned host buffers and two device buffers per engine, H2D on a side stream, the down-scale
+    (svc_resize_frames_u8) on the caller's stream.  While chunk c is being copied and down-scaled the host gathers
+    chunk c+1 into the other pinned buffer; an event per buffer keeps a pinned slot from being refilled before its
+    copy has run and a device slot from being overwritten before its down-scale has read it.  Replaces the reference's
+    per-frame cv2.resize on the host inside the read loop (smartVidCrop.py:333-335, :633-635) for inputs that live in
+    host memory; the 4K stream of BASELINE config 5 is bound by this copy (24.9 MB per frame over PCIe)."""
+
+    def __init__(self, engine):
+        import torch
+        self.engine = engine
+        self.dev = engine.device
+        self.copy_stream = torch.cuda.Stream(device=self.dev)
+        self.shape = None
+
+    def _buffers(self, h, w):
+        import torch
+        if self.shape != (h, w):
+            k = max(1, min(32, _STAGE_BYTES // (h * w * 3)))
+            self.pinned = [torch.empty((k, h, w, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self.staged = [torch.empty((k, h, w, 3), dtype=torch.uint8, device=self.dev) for _ in range(2)]
+            self.copied = [torch.cuda.Event(), torch.cuda.Event()]       # H2D of the slot has run
+            self.consumed = [torch.cuda.Event(), torch.cuda.Event()]     # the down-scale has read the device slot
+            self.used = [False, False]
+            self.shape, self.k = (h, w), k
+        return self.k
+
+    def downscale(self, frames, idx, sal_h, sal_w):
+        """frames: host ndarray [n,h,w,3] u8 (or anything numpy can index); idx: selected frame numbers.
+        -> uint8 CUDA tensor [len(idx), sal_h, sal_w, 3], produced on the caller's current stream."""
+        import torch
+        h, w = int(frames.shape[1]), int(frames.shape[2])
+        k = self._buffers(h, w)
+        out = torch.empty((len(idx), sal_h, sal_w, 3), dtype=torch.uint8, device=self.dev)
+        compute = torch.cuda.current_stream(self.dev)
+        for c, s in enumerate(range(0, len(idx), k)):
+            part = idx[s:s + k]
+            slot = c & 1
+            if self.used[slot]:
+                self.copied[slot].synchronize()                 # the pinned slot's previous copy has run
+            host = self.pinned[slot][:len(part)]
+            np.take(frames, part, axis=0, out=host.numpy(), mode='clip')     # selection before the copy: only these frames cross PCIe
+            with torch.cuda.stream(self.copy_stream):
+                if self.used[slot]:
+                    self.copy_stream.wait_event(self.consumed[slot])    # the device slot's previous reader is done
+                self.staged[slot][:len(part)].copy_(host, non_blocking=True)
+                self.copied[slot].record(self.copy_stream)
+            compute.wait_event(self.copied[slot])
+            out[s:s + len(part)] = self.engine.resize_frames(self.staged[slot][:len(part)], sal_h, sal_w)
+            self.consumed[slot].record(compute)
+            self.used[slot] = True
+        return out
+
+
 def ingest_frames(video, crop_params, engine=None, verbose=False):
     """Counterpart of ingest_pickle (smartVidCrop.py:560-836) for an in-memory video dict.
     The down-scale to saliency size and the UNISAL forward run on the device.  Keeps the
-    reference's off-by-one: the last selected frame of each read batch gets an all-zero map."""
+    reference's off-by-one: the last selected frame of each read batch gets an all-zero map.
+    Host frames (ndarray) go through the pinned, double-buffered feed above; CUDA tensors and
+    on-device generators (``.select``) are used where they are."""
     import torch
     engine = engine or get_engine()
     t = time.perf_counter()
@@ -220,12 +280,17 @@ def ingest_frames(video, crop_params, engine=None, verbose=False):
         if cnt > 1:
             idx = true_inds[first:first + cnt - 1]
             if hasattr(frames, 'select'):
-                sel = frames.select(idx).to(dev)
-            elif torch.is_tensor(frames):
-                sel = frames[torch.as_tensor(idx, device=frames.device)].to(dev)
+                small = engine.resize_frames(frames.select(idx).to(dev).contiguous(), sal_h, sal_w)
+            elif torch.is_tensor(frames) and frames.is_cuda:
+                small = engine.resize_frames(frames[torch.as_tensor(idx, device=frames.device)].to(dev).contiguous(), sal_h, sal_w)
             else:
-                sel = torch.from_numpy(np.ascontiguousarray(np.asarray(frames)[idx])).to(dev)
-            small = engine.resize_frames(sel.contiguous(), sal_h, sal_w)
+                host = frames.numpy() if torch.is_tensor(frames) else np.asarray(frames)
+                if host.dtype != np.uint8 or host.ndim != 4 or host.shape[3] != 3:
+                    raise TypeError('frames must be uint8 [n,h,w,3] RGB')
+                feed = getattr(engine, '_host_feed', None)
+                if feed is None:
+                    feed = engine._host_feed = _HostFeed(engine)
+                small = feed.downscale(host, idx, sal_h, sal_w)
             smaps[first:first + cnt - 1] = engine.saliency(small)
     torch.cuda.current_stream(dev).synchronize()      # the caller's stream only: other videos may be in flight on theirs
     sc_register_time(t, '_read_sal_det')

@@ -279,10 +279,10 @@ def ingest_frames(video, crop_params, engine=None, verbose=False):
     for first, cnt in batches:
         if cnt > 1:
             idx = true_inds[first:first + cnt - 1]
-            if hasattr(frames, 'select'):
-                small = engine.resize_frames(frames.select(idx).to(dev).contiguous(), sal_h, sal_w)
-            elif torch.is_tensor(frames) and frames.is_cuda:
+            if torch.is_tensor(frames) and frames.is_cuda:
                 small = engine.resize_frames(frames[torch.as_tensor(idx, device=frames.device)].to(dev).contiguous(), sal_h, sal_w)
+            elif not torch.is_tensor(frames) and hasattr(frames, 'select'):       # an on-device generator (synth.LazyBlobVideo)
+                small = engine.resize_frames(frames.select(idx).to(dev).contiguous(), sal_h, sal_w)
             else:
                 host = frames.numpy() if torch.is_tensor(frames) else np.asarray(frames)
                 if host.dtype != np.uint8 or host.ndim != 4 or host.shape[3] != 3:

@@ -233,7 +233,11 @@ def main():
     eng = slots[0].eng
     iso = max(1, args.iso_steps)
     per_class = {}
+    plain = os.environ.get('BENCH_PLAIN', '0') == '1'            # counter passes (tools/refresh_profiles.sh): only warm-up + timed steps run
     for k in eng.KERNEL_CLASSES:
+        if plain:
+            per_class[k] = (1.0 if k == 'pw' else 0.0, 1.0)
+            continue
         eng.profile_enable(k)
         for _ in range(iso):
             slots[0].enqueue()
@@ -243,12 +247,12 @@ def main():
     eng.profile_enable(None)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for _ in range(10):
+    for _ in range(0 if plain else 10):
         slots[0].enqueue()
         slots[0].finish()
     latency_ms = (time.perf_counter() - t1) / 10 * 1e3
     dominant = max(per_class, key=lambda k: per_class[k][0])
-    live = os.environ.get('BENCH_LIVE_PROFILE', '1') != '0'      # diagnostic: cost of the in-library events
+    live = os.environ.get('BENCH_LIVE_PROFILE', '1') != '0' and not plain      # diagnostic: cost of the in-library events
     for sl in slots:
         sl.eng.profile_enable(dominant if live else None)
         sl.eng.profile_read()

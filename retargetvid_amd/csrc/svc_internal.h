@@ -120,8 +120,11 @@ struct SvcHandle {
     int pw_min_wg = 1024;              // k_pw narrows its column tile until the grid has this many workgroups (SVC_PW_MIN_WG)
     bool pw_sk = true;                 // split-K pointwise kernel for long-K small-M layers (SVC_PW_SK=0 disables)
     int pw_tr = 2;                     // k_pw with swapped MFMA operands (a lane owns one pixel, float4 epilogue): 0 never, 1 always, 2 for wave tiles of 2+ column tiles and up-sample-add launches (single-tile launches store whole 128 B lines with the scalar form)
-    int pw_sk_max = 1024;              // ... when row blocks x column tiles (at the nominal batch) do not exceed this (SVC_PW_SK_MAX)
+    int pw_sk_max = 2048;              // ... when row blocks x column tiles (at the nominal batch) do not exceed this (SVC_PW_SK_MAX)
     int pw_small = 0;                  // small-M pointwise layers on 16-row wave tiles (SVC_PW_SMALL: 0 off, 1: 16x32, 2: 16x64, 3: 32x32)
+    bool pwr = true;                   // short-K pointwise layers with the activations resident in registers and the weight chunk in LDS (SVC_PWR=0: k_pw)
+    int pwr_nt = 2;                    // ... column tiles (of 32) per workgroup (measured at B = 32: 1 / 2 / 3 / 4 -> 1.735 / 1.692 / 1.726 / 1.767 ms per pass); 0 = as many as leave pwr_min_wg workgroups (SVC_PWR_NT)
+    int pwr_min_wg = 512;              // (SVC_PWR_MIN_WG)
     bool pw16 = true;                  // 16x16x4 MFMA pointwise kernel for narrow short-K layers (SVC_PW16=0: always 32x32x2)
     int fuse_max = 7;                  // backbone blocks 1..fuse_max run as the fused inverted-residual kernel (SVC_FUSE_MAX, 0..13)
     bool split_up = true;              // decoder expansions as conv(skip) + up-sample(conv(low-res part)) (SVC_SPLIT_UP=0: up-sample, concatenate, one GEMM)

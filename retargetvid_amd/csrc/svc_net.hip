@@ -517,6 +517,95 @@ __global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx
 }
 
 // --------------------------------------------------------------------------------------
+// Short-K pointwise layers (K <= 160: the 6x expansions of blocks 8-17, the skips, the decoder expansions) with the
+// activations RESIDENT IN REGISTERS.  k_pw feeds both MFMA operands from global memory per k-step: every column tile
+// re-reads the activation rows, the four waves of a workgroup each re-read the same weight rows, one load pair is in
+// flight per wave, and a load instruction touches 32 cache lines for 1 KB -- the CU's vector-memory path is as busy as
+// its matrix pipes and the waves sit in s_waitcnt (SQ_WAIT_ANY 59 %).  Here a wave loads its 32 rows x K ONCE, all
+// k-steps in flight together (KS float4 per lane), the workgroup's weight chunk (NTW column tiles x K) is staged once
+// in LDS and shared by the four waves, and the wave then walks the NTW column tiles with the activations in registers:
+// per tile K/2 MFMAs fed by one ds_read_b128 per four MFMAs, and a float4 epilogue (operands swapped: a lane owns one
+// pixel).  Global loads per MFMA drop by 2 NTW x; the k order of every sum is k_pw's, so results are bit-identical.
+// --------------------------------------------------------------------------------------
+template <int KS>     // K = 8 * KS
+__global__ __launch_bounds__(256) void k_pwr(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
+                                             const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N,
+                                             int Npad, int ntw, int relu6, UpsAdd ups) {
+    constexpr int K = 8 * KS, WS = K + 4;                  // LDS row stride of the weight chunk (floats): conflict-free b128 rows
+    extern __shared__ float sm_pwr[];                      // [ntw * 32][WS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int m0 = blockIdx.x * 128 + wave * 32;
+    const int n0 = blockIdx.y * (32 * ntw);
+    const int ncols = min(32 * ntw, Npad - n0);            // multiple of 32
+    // activations of this lane's pixel: every k-step in flight at once
+    const int rr = m0 + r;
+    const float *xp = X + (size_t)min(rr, M - 1) * ldx + 4 * hh;
+    float4 A[KS];
+#pragma unroll
+    for (int p = 0; p < KS; ++p) A[p] = *(const float4 *)(xp + 8 * p);
+    // weight chunk -> LDS (coalesced float4 rows)
+    constexpr int K4 = K / 4;
+    for (int i = tid; i < ncols * K4; i += 256) {
+        const int row = i / K4, c4 = i - row * K4;
+        *(float4 *)(sm_pwr + row * WS + c4 * 4) = *(const float4 *)(Wt + (size_t)(n0 + row) * ldw + c4 * 4);
+    }
+    __syncthreads();
+    if (m0 >= M) return;
+    // the up-sample-add term: taps and weights of this pixel (shared by all its channels)
+    const float *u00 = nullptr, *u01 = nullptr, *u10 = nullptr, *u11 = nullptr;
+    float lx0 = 0.f, lx1 = 0.f, ly0 = 0.f, ly1 = 0.f;
+    if (ups.U && rr < M) {
+        uint32_t ox, oy;
+        const uint32_t f = fdivmod(fdivmod((uint32_t)rr, ups.dOW, ox), ups.dOH, oy);
+        const float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ox + 0.5f) - 0.5f, 0.f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < ups.UH - 1 ? 1 : 0), x1 = x0 + (x0 < ups.UW - 1 ? 1 : 0);
+        ly1 = sy - y0; lx1 = sx - x0; ly0 = 1.f - ly1; lx0 = 1.f - lx1;
+        const float *uf = ups.U + (size_t)f * ups.UH * ups.UW * ups.ldu;
+        u00 = uf + ((size_t)y0 * ups.UW + x0) * ups.ldu; u01 = uf + ((size_t)y0 * ups.UW + x1) * ups.ldu;
+        u10 = uf + ((size_t)y1 * ups.UW + x0) * ups.ldu; u11 = uf + ((size_t)y1 * ups.UW + x1) * ups.ldu;
+    }
+    const int nt = ncols >> 5;
+    for (int t = 0; t < nt; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float *bq = sm_pwr + (t * 32 + r) * WS + 4 * hh;
+#pragma unroll
+        for (int p = 0; p < KS; ++p) {
+            const float4 b = *(const float4 *)(bq + 8 * p);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, A[p].x, acc, 0, 0, 0);      // swapped: lane = pixel
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, A[p].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, A[p].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, A[p].w, acc, 0, 0, 0);
+        }
+        if (rr >= M) continue;
+        // accumulator i = channel n0 + 32t + 8(i>>2) + 4hh + (i&3)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = n0 + t * 32 + 8 * g + 4 * hh;
+            if (col >= N) continue;
+            float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+            if (bias) { const float4 bv = *(const float4 *)(bias + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+            if (ups.U) {
+                const float4 a0 = *(const float4 *)(u00 + col), a1 = *(const float4 *)(u01 + col);
+                const float4 c0 = *(const float4 *)(u10 + col), c1 = *(const float4 *)(u11 + col);
+                v.x += ly0 * (lx0 * a0.x + lx1 * a1.x) + ly1 * (lx0 * c0.x + lx1 * c1.x);
+                v.y += ly0 * (lx0 * a0.y + lx1 * a1.y) + ly1 * (lx0 * c0.y + lx1 * c1.y);
+                v.z += ly0 * (lx0 * a0.z + lx1 * a1.z) + ly1 * (lx0 * c0.z + lx1 * c1.z);
+                v.w += ly0 * (lx0 * a0.w + lx1 * a1.w) + ly1 * (lx0 * c0.w + lx1 * c1.w);
+            }
+            if (relu6) {
+                v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
+                v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
+            }
+            *(float4 *)(Y + (size_t)rr * ldy + col) = v;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
 // Pointwise conv on v_mfma_f32_16x16x4_f32 (K % 16 == 0): the four 16-lane groups of a wave
 // carry four k slots, so one float4 load instruction covers 16 rows x 64 contiguous bytes
 // (16 cache lines) instead of 32 rows x 32 bytes (32 lines) — these layers are bound by the
@@ -1164,6 +1253,36 @@ static int launch_pw_ex(SvcHandle *h, hipStream_t s, const float *X, int ldx, co
     // any sum order.
     const int rb_nom = ceil_div((M / n) * 32, 128);
 #define PW16_ARGS X, ldx, Wt, ldw, bias, R, ldr, Y, ldy, M, N, Npad, K, relu6v
+    // short K, no residual: activations resident in registers, weight chunk shared through LDS (k_pwr)
+    if (h->pwr && !R && (K == 64 || K == 96 || K == 128 || K == 160) && (N % 4) == 0) {
+        // column tiles per workgroup: enough workgroups (at the nominal batch) to put two or three on every CU
+        int ntw = h->pwr_nt;
+        if (ntw <= 0) {
+            ntw = 4;
+            while (ntw > 1 && rb_nom * ceil_div(tiles, ntw) < h->pwr_min_wg) --ntw;
+        }
+        ntw = std::min(ntw, tiles);
+        const dim3 g(rb, ceil_div(tiles, ntw));
+        const size_t lds = (size_t)ntw * 32 * (K + 4) * sizeof(float);
+#define PWR_ARGS X, ldx, Wt, ldw, bias, Y, ldy, M, N, Npad, ntw, relu6v, ua
+#define PWR_CASE(KSv)                                                                                                   \
+    {                                                                                                                   \
+        auto kfn = k_pwr<KSv>;                                                                                          \
+        if (h->lds_attr_done.insert((const void *)kfn).second)                                                          \
+            SVC_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));     \
+        kfn<<<g, 256, lds, s>>>(PWR_ARGS);                                                                              \
+    }
+        switch (K) {
+            case 64: PWR_CASE(8) break;
+            case 96: PWR_CASE(12) break;
+            case 128: PWR_CASE(16) break;
+            default: PWR_CASE(20) break;
+        }
+#undef PWR_CASE
+#undef PWR_ARGS
+        SVC_CHECK_LAUNCH();
+        return SVC_OK;
+    }
     if (!ups && h->pw_sk && K >= 256 && rb_nom * tiles <= h->pw_sk_max) {   // long K, few workgroups: split K over the four waves
         const int tn = (tiles % 2 == 0) ? 2 : 1;
         dim3 g(ceil_div(M, 32), ceil_div(tiles, tn));
@@ -2105,6 +2224,12 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->pw_small = atoi(env);
     env = getenv("SVC_PW16");
     if (env) h->pw16 = atoi(env) != 0;
+    env = getenv("SVC_PWR");
+    if (env) h->pwr = atoi(env) != 0;
+    env = getenv("SVC_PWR_NT");
+    if (env) h->pwr_nt = atoi(env);
+    env = getenv("SVC_PWR_MIN_WG");
+    if (env && atoi(env) > 0) h->pwr_min_wg = atoi(env);
     env = getenv("SVC_FUSE_MAX");
     if (env) h->fuse_max = std::min(13, std::max(0, atoi(env)));
     env = getenv("SVC_SPLIT_UP");

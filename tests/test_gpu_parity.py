@@ -95,7 +95,10 @@ def test_saliency_batch_and_chunk_independence(engine):
     {'SVC_DWPW': '0'},                                      # depthwise and project as two kernels
     {'SVC_DWPW': '0', 'SVC_DW_TILE': '0'},                  # ... with the one-output-per-thread depthwise
     {'SVC_DWPW_MIN_PX': '1'},                               # fused depthwise+project on the 8x13 level too
-    {'SVC_PW_SK': '0', 'SVC_PW16': '0'},                    # no split-K, no 16x16x4 pointwise form
+    {'SVC_PWR': '0'},                                       # short-K layers through k_pw (operands from global memory) instead of k_pwr
+    {'SVC_PWR_NT': '1'},                                    # k_pwr with one column tile per workgroup
+    {'SVC_PWR_NT': '4', 'SVC_PW_SK': '0'},                  # ... with four; long-K layers without split-K
+    {'SVC_PWR': '0', 'SVC_PW_SK': '0', 'SVC_PW16': '0'},    # no k_pwr, no split-K, no 16x16x4 pointwise form
     {'SVC_PW_SMALL': '1'},                                  # 16x16x4 wave tiles for the small-M levels (three shapes)
     {'SVC_PW_SMALL': '2'},
     {'SVC_PW_SMALL': '3', 'SVC_PW_TR': '1'},               # ... and the float4 epilogue for every k_pw launch

@@ -139,6 +139,7 @@ struct SvcHandle {
     int prim_pt = 2;                   // k_prim: smallest points-per-thread variant (SVC_PRIM_PT: 2, 4, 8, 16)
     // per-kernel-class event log (svc_profile_*)
     int prof_class = -1;
+    hipStream_t prof_stream = nullptr;          // stream of the last recorded launch (the empty-pair calibration of svc_profile_read runs on it)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
 };
 
@@ -148,7 +149,7 @@ struct ProfScope {
     ProfScope(SvcHandle *h_, int cls, hipStream_t s_) : h(h_), s(s_), on(h_->prof_class == cls) {
         if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
     }
-    ~ProfScope() { if (on) { (void)hipEventRecord(b, s); h->prof_events.emplace_back(a, b); } }
+    ~ProfScope() { if (on) { (void)hipEventRecord(b, s); h->prof_events.emplace_back(a, b); h->prof_stream = s; } }
 };
 
 int svc_net_release(SvcHandle *h);

@@ -527,20 +527,27 @@ __global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx
 // per tile K/2 MFMAs fed by one ds_read_b128 per four MFMAs, and a float4 epilogue (operands swapped: a lane owns one
 // pixel).  Global loads per MFMA drop by 2 NTW x; the k order of every sum is k_pw's, so results are bit-identical.
 // --------------------------------------------------------------------------------------
+// The epilogue goes through a per-wave LDS slab: the accumulator layout gives a lane 16 B pieces of ONE pixel's row, so a
+// direct float4 store instruction touches 32 cache lines for 1 KB and the CU's store path, not HBM, limits the kernel
+// (tools/micro/pw_phases.hip: the stores of a 64 -> 384 layer alone take 6.6 us = 5 B/clk/CU, as long as its MFMAs and
+// loads together, and nothing overlaps them).  Transposed through the slab, a store instruction writes 8 rows x 128 B:
+// eight whole lines.
+#define PWR_SLAB 36            // floats per slab row: 32 channels + 4 pad
 template <int KS>     // K = 8 * KS
 __global__ __launch_bounds__(256) void k_pwr(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
                                              const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N,
                                              int Npad, int ntw, int relu6, UpsAdd ups) {
     constexpr int K = 8 * KS, WS = K + 4;                  // LDS row stride of the weight chunk (floats): conflict-free b128 rows
-    extern __shared__ float sm_pwr[];                      // [ntw * 32][WS]
+    extern __shared__ float sm_pwr[];                      // [4 waves][32][PWR_SLAB] epilogue slabs | [ntw * 32][WS] weight chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
+    float *slab = sm_pwr + wave * (32 * PWR_SLAB);
+    float *wch = sm_pwr + 4 * 32 * PWR_SLAB;
     const int m0 = blockIdx.x * 128 + wave * 32;
     const int n0 = blockIdx.y * (32 * ntw);
     const int ncols = min(32 * ntw, Npad - n0);            // multiple of 32
     // activations of this lane's pixel: every k-step in flight at once
-    const int rr = m0 + r;
-    const float *xp = X + (size_t)min(rr, M - 1) * ldx + 4 * hh;
+    const float *xp = X + (size_t)min(m0 + r, M - 1) * ldx + 4 * hh;
     float4 A[KS];
 #pragma unroll
     for (int p = 0; p < KS; ++p) A[p] = *(const float4 *)(xp + 8 * p);
@@ -548,30 +555,18 @@ __global__ __launch_bounds__(256) void k_pwr(const float *__restrict__ X, int ld
     constexpr int K4 = K / 4;
     for (int i = tid; i < ncols * K4; i += 256) {
         const int row = i / K4, c4 = i - row * K4;
-        *(float4 *)(sm_pwr + row * WS + c4 * 4) = *(const float4 *)(Wt + (size_t)(n0 + row) * ldw + c4 * 4);
+        *(float4 *)(wch + row * WS + c4 * 4) = *(const float4 *)(Wt + (size_t)(n0 + row) * ldw + c4 * 4);
     }
     __syncthreads();
     if (m0 >= M) return;
-    // the up-sample-add term: taps and weights of this pixel (shared by all its channels)
-    const float *u00 = nullptr, *u01 = nullptr, *u10 = nullptr, *u11 = nullptr;
-    float lx0 = 0.f, lx1 = 0.f, ly0 = 0.f, ly1 = 0.f;
-    if (ups.U && rr < M) {
-        uint32_t ox, oy;
-        const uint32_t f = fdivmod(fdivmod((uint32_t)rr, ups.dOW, ox), ups.dOH, oy);
-        const float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ox + 0.5f) - 0.5f, 0.f);
-        const int y0 = (int)sy, x0 = (int)sx;
-        const int y1 = y0 + (y0 < ups.UH - 1 ? 1 : 0), x1 = x0 + (x0 < ups.UW - 1 ? 1 : 0);
-        ly1 = sy - y0; lx1 = sx - x0; ly0 = 1.f - ly1; lx0 = 1.f - lx1;
-        const float *uf = ups.U + (size_t)f * ups.UH * ups.UW * ups.ldu;
-        u00 = uf + ((size_t)y0 * ups.UW + x0) * ups.ldu; u01 = uf + ((size_t)y0 * ups.UW + x1) * ups.ldu;
-        u10 = uf + ((size_t)y1 * ups.UW + x0) * ups.ldu; u11 = uf + ((size_t)y1 * ups.UW + x1) * ups.ldu;
-    }
+    // store role of the lane: rows (lane >> 3) + 8 it, channels 4 (lane & 7) .. + 3 of the tile
+    const int srow = lane >> 3, sc = (lane & 7) * 4;
     const int nt = ncols >> 5;
     for (int t = 0; t < nt; ++t) {
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        const float *bq = sm_pwr + (t * 32 + r) * WS + 4 * hh;
+        const float *bq = wch + (t * 32 + r) * WS + 4 * hh;
 #pragma unroll
         for (int p = 0; p < KS; ++p) {
             const float4 b = *(const float4 *)(bq + 8 * p);
@@ -580,17 +575,31 @@ __global__ __launch_bounds__(256) void k_pwr(const float *__restrict__ X, int ld
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, A[p].z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, A[p].w, acc, 0, 0, 0);
         }
-        if (rr >= M) continue;
-        // accumulator i = channel n0 + 32t + 8(i>>2) + 4hh + (i&3)
+        // accumulator i = channel 32t + 8(i>>2) + 4hh + (i&3) of pixel r -> slab[r][channel]
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int col = n0 + t * 32 + 8 * g + 4 * hh;
-            if (col >= N) continue;
-            float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-            if (bias) { const float4 bv = *(const float4 *)(bias + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
-            if (ups.U) {
-                const float4 a0 = *(const float4 *)(u00 + col), a1 = *(const float4 *)(u01 + col);
-                const float4 c0 = *(const float4 *)(u10 + col), c1 = *(const float4 *)(u11 + col);
+        for (int g = 0; g < 4; ++g)
+            *(float4 *)(slab + r * PWR_SLAB + 8 * g + 4 * hh) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the slab is private to the wave
+        __builtin_amdgcn_wave_barrier();
+        const int col = n0 + t * 32 + sc;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias && col < N) bv = *(const float4 *)(bias + col);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = srow + 8 * it, rr = m0 + row;
+            float4 v = *(const float4 *)(slab + row * PWR_SLAB + sc);
+            if (rr >= M || col >= N) continue;
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (ups.U) {                                    // + the 2x bilinear up-sampling of the low-resolution product (see UpsAdd)
+                uint32_t ox, oy;
+                const uint32_t f = fdivmod(fdivmod((uint32_t)rr, ups.dOW, ox), ups.dOH, oy);
+                const float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ox + 0.5f) - 0.5f, 0.f);
+                const int y0 = (int)sy, x0 = (int)sx;
+                const int y1 = y0 + (y0 < ups.UH - 1 ? 1 : 0), x1 = x0 + (x0 < ups.UW - 1 ? 1 : 0);
+                const float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+                const float *uf = ups.U + (size_t)f * ups.UH * ups.UW * ups.ldu + col;
+                const float4 a0 = *(const float4 *)(uf + ((size_t)y0 * ups.UW + x0) * ups.ldu), a1 = *(const float4 *)(uf + ((size_t)y0 * ups.UW + x1) * ups.ldu);
+                const float4 c0 = *(const float4 *)(uf + ((size_t)y1 * ups.UW + x0) * ups.ldu), c1 = *(const float4 *)(uf + ((size_t)y1 * ups.UW + x1) * ups.ldu);
                 v.x += ly0 * (lx0 * a0.x + lx1 * a1.x) + ly1 * (lx0 * c0.x + lx1 * c1.x);
                 v.y += ly0 * (lx0 * a0.y + lx1 * a1.y) + ly1 * (lx0 * c0.y + lx1 * c1.y);
                 v.z += ly0 * (lx0 * a0.z + lx1 * a1.z) + ly1 * (lx0 * c0.z + lx1 * c1.z);
@@ -602,6 +611,7 @@ __global__ __launch_bounds__(256) void k_pwr(const float *__restrict__ X, int ld
             }
             *(float4 *)(Y + (size_t)rr * ldy + col) = v;
         }
+        __builtin_amdgcn_wave_barrier();                    // the next tile overwrites the slab
     }
 }
 
@@ -1263,7 +1273,7 @@ static int launch_pw_ex(SvcHandle *h, hipStream_t s, const float *X, int ldx, co
         }
         ntw = std::min(ntw, tiles);
         const dim3 g(rb, ceil_div(tiles, ntw));
-        const size_t lds = (size_t)ntw * 32 * (K + 4) * sizeof(float);
+        const size_t lds = ((size_t)ntw * 32 * (K + 4) + 4 * 32 * PWR_SLAB) * sizeof(float);
 #define PWR_ARGS X, ldx, Wt, ldw, bias, Y, ldy, M, N, Npad, ntw, relu6v, ua
 #define PWR_CASE(KSv)                                                                                                   \
     {                                                                                                                   \
@@ -2326,11 +2336,29 @@ extern "C" int svc_profile_read(SvcHandle *h, double *total_ms, int *launches) {
     if (!h || !total_ms || !launches) { svc_set_error("svc_profile_read: invalid argument"); return SVC_E_INVALID; }
     SVC_HIP(hipSetDevice(h->device));
     SVC_HIP(hipDeviceSynchronize());
+    // An event pair around a launch also times the two event packets themselves: calibrate that on the same stream with
+    // empty pairs (median of 15) and take it off every launch, so that the sum agrees with a profiler's kernel durations.
+    double overhead = 0.0;
+    if (!h->prof_events.empty()) {
+        std::vector<float> emp;
+        for (int i = 0; i < 15; ++i) {
+            hipEvent_t a, b;
+            SVC_HIP(hipEventCreate(&a)); SVC_HIP(hipEventCreate(&b));
+            SVC_HIP(hipEventRecord(a, h->prof_stream)); SVC_HIP(hipEventRecord(b, h->prof_stream));
+            SVC_HIP(hipEventSynchronize(b));
+            float ms = 0.f;
+            SVC_HIP(hipEventElapsedTime(&ms, a, b));
+            emp.push_back(ms);
+            (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        }
+        std::sort(emp.begin(), emp.end());
+        overhead = emp[emp.size() / 2];
+    }
     double tot = 0.0;
     for (auto &e : h->prof_events) {
         float ms = 0.f;
         SVC_HIP(hipEventElapsedTime(&ms, e.first, e.second));
-        tot += ms;
+        tot += std::max(0.0, (double)ms - overhead);
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }

@@ -21,7 +21,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 cd $R
 cp $(ls $O/p4/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats_pipeline4.csv
 cp $(ls $O/p1/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats_pipeline1.csv
-tail -1 $O/p1.log > $O/${TAG}_bench_line_pipeline1_under_rocprof.json
+grep "^{\"metric\"" $O/p1.log | tail -1 > $O/${TAG}_bench_line_pipeline1_under_rocprof.json
 python tools/pmc_traffic.py $O/fetch $O/write $O/${TAG}_pmc_traffic.json --steps 6 --note "bench.py --steps 5 --warmup 1 --pipeline 1 --cpu-sample 0 with BENCH_PLAIN=1 (6 steps of 32 frames)" > /dev/null
 python tools/pmc_sq_table.py $O/sq $O/${TAG}_pmc_sq_network.json > $O/${TAG}_pmc_sq_network.txt
 rm -rf $O/p4 $O/p1 $O/fetch $O/write $O/sq

@@ -538,27 +538,36 @@ __global__ __launch_bounds__(256) void k_pwr(const float *__restrict__ X, int ld
                                              const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N,
                                              int Npad, int ntw, int relu6, UpsAdd ups) {
     constexpr int K = 8 * KS, WS = K + 4;                  // LDS row stride of the weight chunk (floats): conflict-free b128 rows
-    extern __shared__ float sm_pwr[];                      // [4 waves][32][PWR_SLAB] epilogue slabs | [ntw * 32][WS] weight chunk
+    extern __shared__ float sm_pwr[];                      // [4 waves][32][PWR_SLAB] epilogue slabs | [128] bias chunk | [ntw * 32][WS] weight chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     float *slab = sm_pwr + wave * (32 * PWR_SLAB);
-    float *wch = sm_pwr + 4 * 32 * PWR_SLAB;
+    float *bch = sm_pwr + 4 * 32 * PWR_SLAB;
+    float *wch = bch + 128;
     const int m0 = blockIdx.x * 128 + wave * 32;
     const int n0 = blockIdx.y * (32 * ntw);
-    const int ncols = min(32 * ntw, Npad - n0);            // multiple of 32
+    const int ncols = min(32 * ntw, Npad - n0);            // multiple of 32, at most 128
     // activations of this lane's pixel: every k-step in flight at once
     const float *xp = X + (size_t)min(m0 + r, M - 1) * ldx + 4 * hh;
     float4 A[KS];
 #pragma unroll
     for (int p = 0; p < KS; ++p) A[p] = *(const float4 *)(xp + 8 * p);
-    // weight chunk -> LDS (coalesced float4 rows)
+    // weight chunk and bias chunk -> LDS (coalesced float4 rows)
     constexpr int K4 = K / 4;
     for (int i = tid; i < ncols * K4; i += 256) {
         const int row = i / K4, c4 = i - row * K4;
         *(float4 *)(wch + row * WS + c4 * 4) = *(const float4 *)(Wt + (size_t)(n0 + row) * ldw + c4 * 4);
     }
+    if (tid < ncols) bch[tid] = (bias && n0 + tid < N) ? bias[n0 + tid] : 0.f;
     __syncthreads();
     if (m0 >= M) return;
+    // Every load of this wave has landed (the barrier above waited for the weight chunk, requested after the
+    // activations).  Saying so explicitly empties the compiler's vector-memory scoreboard in front of the tile loop, and
+    // the loop itself issues no global load (the bias comes from LDS): otherwise hipcc puts an s_waitcnt vmcnt(0) at the
+    // loop head -- the activation registers count as "possibly pending" on the back edge -- or in front of the first use
+    // of a bias value, and because loads and stores retire in order every tile then waits for the STORES of the tile
+    // before it: the chip alternates between an MFMA phase and a store phase (tools/micro/pw_phases.hip).
+    __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0)
     // store role of the lane: rows (lane >> 3) + 8 it, channels 4 (lane & 7) .. + 3 of the tile
     const int srow = lane >> 3, sc = (lane & 7) * 4;
     const int nt = ncols >> 5;
@@ -582,8 +591,7 @@ __global__ __launch_bounds__(256) void k_pwr(const float *__restrict__ X, int ld
         __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the slab is private to the wave
         __builtin_amdgcn_wave_barrier();
         const int col = n0 + t * 32 + sc;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias && col < N) bv = *(const float4 *)(bias + col);
+        const float4 bv = *(const float4 *)(bch + t * 32 + sc);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = srow + 8 * it, rr = m0 + row;
@@ -1273,7 +1281,7 @@ static int launch_pw_ex(SvcHandle *h, hipStream_t s, const float *X, int ldx, co
         }
         ntw = std::min(ntw, tiles);
         const dim3 g(rb, ceil_div(tiles, ntw));
-        const size_t lds = ((size_t)ntw * 32 * (K + 4) + 4 * 32 * PWR_SLAB) * sizeof(float);
+        const size_t lds = ((size_t)ntw * 32 * (K + 4) + 4 * 32 * PWR_SLAB + 128) * sizeof(float);
 #define PWR_ARGS X, ldx, Wt, ldw, bias, Y, ldy, M, N, Npad, ntw, relu6v, ua
 #define PWR_CASE(KSv)                                                                                                   \
     {                                                                                                                   \
@@ -1420,25 +1428,57 @@ __global__ __launch_bounds__(64 * NWV) void k_dwpw(const float *__restrict__ X, 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     const int nchunks = (C + 31) >> 5;
+    // Latency, not bandwidth, bounds this kernel (round-1 form: every tap load in its own bounds-check branch followed by
+    // s_waitcnt vmcnt(0), and the project weights of a k-step requested only when its MFMAs were next: a full L2 round
+    // trip per 8-deep k-step).  So: (1) the chunk's slice of the project weights is requested FIRST and parked in
+    // registers through the depthwise phase (NT <= 2: the whole 32-deep slice; wider tiles keep one k-step in flight
+    // ahead of the MFMAs); (2) the 18 tap loads are unconditional -- coordinates clamped into the image, out-of-image
+    // taps zeroed by a select -- so they are issued back to back.  A zeroed tap adds 0 * w: the sums are unchanged.
+    constexpr bool PRE = false;        // (the whole 32-deep slice in registers costs the second wave per SIMD: 22 -> 33 us at NT = 2)
+    const float *wrow[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wrow[t] = Wp + (size_t)min(n0 + t * 32 + r, Npad - 1) * C + 4 * hh;
     for (int ch = wave; ch < nchunks; ch += NWV) {
+        const int kend = min(32, C - ch * 32);
+        float4 Bw[PRE ? NT : 1][4];
+        if (PRE) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    Bw[PRE ? t : 0][q] = *(const float4 *)(wrow[t] + ch * 32 + min(8 * q, kend - 8));      // (a short last chunk re-reads its last k-step: unused)
+        }
         const int c = ch * 32 + c4 * 4;
+        const bool cok = c < C;
+        const int cc = cok ? c : 0;
         float4 o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < C) {
+        {
             float4 w[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) w[t] = *(const float4 *)(Wd + (size_t)t * C + c);
+            for (int t = 0; t < 9; ++t) w[t] = *(const float4 *)(Wd + (size_t)t * C + cc);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const int iy = oy - 1 + ky;
-                if (iy < 0 || iy >= H) continue;
+                const int iy = oy - 1 + ky, iyc = min(max(iy, 0), H - 1);
+                const bool yok = iy >= 0 && iy < H;
                 float4 row[6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    const int ix = ox0 - 1 + j;
-                    row[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (ix >= 0 && ix < W) row[j] = *(const float4 *)(xf + ((size_t)iy * W + ix) * C + c);
+                    const int ix = ox0 - 1 + j, ixc = min(max(ix, 0), W - 1);
+                    if (NT >= 5) {                          // five accumulator tiles: keep the loads conditional (fewer live registers: 108 instead of 187 VGPRs)
+                        row[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (yok && ix >= 0 && ix < W) row[j] = *(const float4 *)(xf + ((size_t)iy * W + ix) * C + cc);
+                    } else {
+                        row[j] = *(const float4 *)(xf + ((size_t)iyc * W + ixc) * C + cc);
+                    }
+                }
+                if (NT < 5) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const int ix = ox0 - 1 + j;
+                        if (!(yok && ix >= 0 && ix < W)) row[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -1451,13 +1491,13 @@ __global__ __launch_bounds__(64 * NWV) void k_dwpw(const float *__restrict__ X, 
                         o[j].w = fmaf(x.w, ww.w, o[j].w);
                     }
             }
-            const float4 b = *(const float4 *)(bd + c);
+            const float4 b = *(const float4 *)(bd + cc);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                o[j].x = fminf(fmaxf(o[j].x + b.x, 0.f), 6.f);
-                o[j].y = fminf(fmaxf(o[j].y + b.y, 0.f), 6.f);
-                o[j].z = fminf(fmaxf(o[j].z + b.z, 0.f), 6.f);
-                o[j].w = fminf(fmaxf(o[j].w + b.w, 0.f), 6.f);
+                o[j].x = cok ? fminf(fmaxf(o[j].x + b.x, 0.f), 6.f) : 0.f;
+                o[j].y = cok ? fminf(fmaxf(o[j].y + b.y, 0.f), 6.f) : 0.f;
+                o[j].z = cok ? fminf(fmaxf(o[j].z + b.z, 0.f), 6.f) : 0.f;
+                o[j].w = cok ? fminf(fmaxf(o[j].w + b.w, 0.f), 6.f) : 0.f;
             }
         }
 #pragma unroll
@@ -1465,17 +1505,54 @@ __global__ __launch_bounds__(64 * NWV) void k_dwpw(const float *__restrict__ X, 
         // the slab is private to the wave: its own LDS writes are visible to it once they have completed
         __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
-        const int kend = min(32, C - ch * 32);
         const float *ap = D + r * IRB_ES + 4 * hh;
-        for (int k = 0; k < kend; k += 8) {
-            const float4 a = *(const float4 *)(ap + k);
+        if (PRE) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float4 b = *(const float4 *)(Wp + (size_t)min(n0 + t * 32 + r, Npad - 1) * C + ch * 32 + 4 * hh + k);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc[t], 0, 0, 0);   // swapped: lane = pixel
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc[t], 0, 0, 0);
+            for (int q = 0; q < 4; ++q) {
+                if (8 * q < kend) {
+                    const float4 a = *(const float4 *)(ap + 8 * q);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const float4 b = Bw[PRE ? t : 0][q];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc[t], 0, 0, 0);   // swapped: lane = pixel
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        } else if (NT >= 5) {                               // five tiles: weights requested per k-step (no second register set)
+            for (int k = 0; k < kend; k += 8) {
+                const float4 a = *(const float4 *)(ap + k);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float4 b = *(const float4 *)(wrow[t] + ch * 32 + k);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc[t], 0, 0, 0);
+                }
+            }
+        } else {
+            float4 nb[NT];                                  // the next k-step's weights, requested before this step's MFMAs
+#pragma unroll
+            for (int t = 0; t < NT; ++t) nb[t] = *(const float4 *)(wrow[t] + ch * 32);
+            for (int k = 0; k < kend; k += 8) {
+                const float4 a = *(const float4 *)(ap + k);
+                float4 b[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b[t] = nb[t];
+                if (k + 8 < kend) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) nb[t] = *(const float4 *)(wrow[t] + ch * 32 + k + 8);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].x, a.x, acc[t], 0, 0, 0);   // swapped: lane = pixel
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].y, a.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].z, a.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].w, a.w, acc[t], 0, 0, 0);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();                    // the next chunk overwrites the slab

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_ablate(const float *__restrict__ X, int
             float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
             v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
             v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
-            if (MODE == 1) { if (never && v.x == 12345.f) *(float4 *)(Y + (size_t)rr * ldy + col) = v; }
+            if (MODE == 1) { if (v.x == 12345.f + (float)never) *(float4 *)(Y + (size_t)rr * ldy + col) = v; }      // the MFMAs stay (the test needs their result), the store never happens
             else *(float4 *)(Y + (size_t)rr * ldy + col) = v;
         }
     }
@@ -100,7 +100,7 @@ static void study(int M, int N) {
         const float t1 = time_us([&] { k_ablate<KS, 1><<<g, 256, lds, 0>>>(X, K, W, K, B, Y, N, M, N, Npad, ntw, 1, 0); });
         const float t2 = time_us([&] { k_ablate<KS, 2><<<g, 256, lds, 0>>>(X, K, W, K, B, Y, N, M, N, Npad, ntw, 1, 0); });
         const float t3 = time_us([&] { k_ablate<KS, 3><<<g, 256, lds, 0>>>(X, K, W, K, B, Y, N, M, N, Npad, ntw, 1, 0); });
-        printf("  ntw=%d (%4d workgroups): full %6.1f us | no stores (MFMAs may be sunk with them) %6.1f | no global loads %6.1f | stores only %6.1f\n",
+        printf("  ntw=%d (%4d workgroups): full %6.1f us | no stores %6.1f | no global loads %6.1f | stores only %6.1f\n",
                ntw, g.x * g.y, t0, t1, t2, t3);
     }
     hipFree(X); hipFree(W); hipFree(B); hipFree(Y);

@@ -40,6 +40,26 @@ def class_ms(eng, fn, classes):
     return out
 
 
+def touched_bytes(h, w, sh, sw, sector=32):
+    """Bytes of ONE source frame the INTER_LINEAR down-scale actually reads: the four taps of every output pixel
+    (exact), and the distinct 32-byte sectors they fall into (what the memory system moves at least)."""
+    def taps(src, dst):
+        f = (np.arange(dst) + 0.5) * (src / dst) - 0.5
+        s0 = np.clip(np.floor(f).astype(np.int64), 0, src - 1)
+        return s0, np.minimum(s0 + 1, src - 1)
+    x0, x1 = taps(w, sw)
+    y0, y1 = taps(h, sh)
+    rows = np.unique(np.concatenate([y0, y1]))
+    cols = np.unique(np.concatenate([x0, x1]))
+    exact = len(rows) * len(cols) * 3
+    sect = set()
+    for c in cols:
+        sect.add((3 * c) // sector)
+        sect.add((3 * c + 2) // sector)
+    # a row of w*3 bytes starts at an arbitrary sector phase; the count per row is the same up to one sector
+    return exact, len(rows) * len(sect) * sector
+
+
 def npts(eng, frames, CP):
     maps = eng.saliency(eng.resize_frames(frames, 140, 250))
     eng.threshold_(maps, CP['t_threshold'])
@@ -70,10 +90,12 @@ def config4(batch, chunk, steps, warm):
                pw_frac_of_f32_mfma_peak=round(work['pw_flops'] / (per['pw'] * 1e-3) / 1e12 / bench.MFMA_F32_PEAK_TFLOPS, 4),
                mean_points_per_map=npts(eng, frames, CP),
                resize_source_GB=round(src_bytes / 1e9, 3),
-               resize_GBs_of_source=round(src_bytes / (per['resize'] * 1e-3) / 1e9, 1),
-               resize_frac_of_hbm_peak=round(src_bytes / (per['resize'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-               note='source bytes / down-scale time; INTER_LINEAR at 7.68:1 touches 2 of every ~7.7 rows, so the '
-                    'kernel moves less than the full frame')
+               resize_touched_GB=round(batch * touched_bytes(1080, 1920, 140, 250)[1] / 1e9, 4),
+               resize_GBs_touched=round(batch * touched_bytes(1080, 1920, 140, 250)[1] / (per['resize'] * 1e-3) / 1e9, 1),
+               resize_frac_of_hbm_peak=round(batch * touched_bytes(1080, 1920, 140, 250)[1] / (per['resize'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               note='touched = the distinct 32-byte sectors holding the four taps of every output pixel (INTER_LINEAR at '
+                    '7.68:1 reads 2 of every ~7.7 rows and 2 of every ~7.7 pixels) + the output; the source frames '
+                    'themselves are %.3f GB' % (src_bytes / 1e9))
     eng.close()
     return res
 
@@ -104,26 +126,17 @@ def config5(batch, steps, warm):
 
     ms_host = timed(fed, steps, warm)
 
-    # the same with the next batch's H2D copy overlapping the current batch's compute (two staging buffers)
-    stages = [stage, torch.empty_like(dev)]
-    copy_s, comp_s = torch.cuda.Stream(), torch.cuda.Stream()
-    ready = [torch.cuda.Event(), torch.cuda.Event()]
-    freed = [torch.cuda.Event(), torch.cuda.Event()]
-    state = {'i': 0}
-    for e in freed:
-        e.record(comp_s)
+    # the product's host-fed ingest (smartVidCrop._HostFeed: pinned double buffers, H2D on a side stream, selection
+    # before the copy, down-scale per chunk on the compute stream) followed by the rest of the chain
+    feed = S._HostFeed(eng)
+    host_np = host.numpy()
+    idx = list(range(batch))
 
     def fed_overlapped():
-        k = state['i'] & 1
-        state['i'] += 1
-        with torch.cuda.stream(copy_s):
-            copy_s.wait_event(freed[k])
-            stages[k].copy_(host, non_blocking=True)
-            ready[k].record(copy_s)
-        with torch.cuda.stream(comp_s):
-            comp_s.wait_event(ready[k])
-            tail(stages[k])
-            freed[k].record(comp_s)
+        small = feed.downscale(host_np, idx, 140, 250)
+        maps = eng.saliency(small)
+        eng.threshold_(maps, CP['t_threshold'])
+        return eng.cluster_center_(maps, flags, CP)
 
     ms_ovl = timed(fed_overlapped, steps, warm)
     ms_copy = timed(lambda: stage.copy_(host, non_blocking=True), steps, warm)
@@ -133,11 +146,13 @@ def config5(batch, steps, warm):
                frames_in_hbm=dict(ms_per_step=round(ms_dev, 3), frames_per_s=round(batch / ms_dev * 1e3, 1)),
                frames_from_pinned_host=dict(ms_per_step=round(ms_host, 3), frames_per_s=round(batch / ms_host * 1e3, 1),
                                             h2d_ms=round(ms_copy, 3), h2d_GBs=round(nbytes / (ms_copy * 1e-3) / 1e9, 1)),
-               frames_from_pinned_host_copy_overlapped=dict(ms_per_step=round(ms_ovl, 3),
+               frames_from_host_product_ingest=dict(ms_per_step=round(ms_ovl, 3),
                                                             frames_per_s=round(batch / ms_ovl * 1e3, 1)),
-               resize_ms=per['resize'], resize_GBs_of_source=round(nbytes / (per['resize'] * 1e-3) / 1e9, 1),
+               resize_ms=per['resize'],
+               resize_GBs_touched=round(batch * touched_bytes(2160, 3840, 140, 250)[1] / (per['resize'] * 1e-3) / 1e9, 1),
                mean_points_per_map=npts(eng, dev, CP),
-               note='fed from the host the stream is bound by PCIe (24.9 MB per frame)')
+               note='fed from the host the stream is bound by PCIe (24.9 MB per frame); product ingest = pinned double '
+                    'buffers of 96 MB (3 frames of 4K each), copies on a side stream')
     eng.close()
     return res
 

@@ -102,8 +102,8 @@ int svc_iou_i32(const int32_t *a, const int32_t *b, size_t n, double *out, void 
 
 /* Measurement door (bench.py): record HIP events around every launch of one kernel class on
  * the stream it is launched on.  kernel_class = one of SVC_K_*, or -1 to switch recording off.
- * svc_profile_read synchronises the device, returns the summed duration (ms; the cost of an empty event pair on the
- * same stream, measured at read time, is taken off every launch) and the number of launches recorded since the last
+ * svc_profile_read synchronises the device, returns the summed duration (ms; 3/4 of the cost of an empty event pair on
+ * the same stream, measured at read time, is taken off every launch: calibrated against rocprofv3 kernel durations) and the number of launches recorded since the last
  * read, and resets the log.  Nothing like it exists in the
  * reference (its timers are host wall-clock accumulators, smartVidCrop.py:98-127). */
 #define SVC_K_RESIZE 0

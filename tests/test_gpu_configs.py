@@ -137,6 +137,7 @@ def test_config5_4k_frames_resize_and_chain(engine, synthetic_sd):
     CPs = dict(S.sc_init_crop_params(), out_ratio='1:1', skip=1)
     VD, _ = S.smart_vid_crop(video, CPs, save_vid=False, engine=engine)
     VH, _ = S.smart_vid_crop(dict(video, frames=frames.cpu().numpy()), CPs, save_vid=False, engine=engine)
-    assert VD['bbs'] == VH['bbs'] and len(VD['bbs']) == 6 and (VD['h_process'], VD['w_process']) == (140, 250)
+    VP, _ = S.smart_vid_crop(dict(video, frames=frames.cpu().pin_memory()), CPs, save_vid=False, engine=engine)   # pinned source: no staging copy
+    assert VD['bbs'] == VH['bbs'] == VP['bbs'] and len(VD['bbs']) == 6 and (VD['h_process'], VD['w_process']) == (140, 250)
     b = np.array(VD['bbs'])
     assert (b[:, 2] - b[:, 0] == 2160).all() and (b[:, 3] - b[:, 1] == 2160).all() and (b[:, 0] >= 0).all() and (b[:, 2] <= 3840).all()

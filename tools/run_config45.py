@@ -132,13 +132,14 @@ def config5(batch, steps, warm):
     host_np = host.numpy()
     idx = list(range(batch))
 
-    def fed_overlapped():
-        small = feed.downscale(host_np, idx, 140, 250)
+    def fed_product(src):
+        small = feed.downscale(src, idx, 140, 250)
         maps = eng.saliency(small)
         eng.threshold_(maps, CP['t_threshold'])
         return eng.cluster_center_(maps, flags, CP)
 
-    ms_ovl = timed(fed_overlapped, steps, warm)
+    ms_ovl = timed(lambda: fed_product(host_np), steps, warm)      # pageable-style source: gathered into the pinned slots
+    ms_pin = timed(lambda: fed_product(host), steps, warm)         # pinned source: copied from where it lies
     ms_copy = timed(lambda: stage.copy_(host, non_blocking=True), steps, warm)
     per = class_ms(eng, lambda: tail(dev), ('resize', 'pw'))
     nbytes = dev.numel()
@@ -146,8 +147,8 @@ def config5(batch, steps, warm):
                frames_in_hbm=dict(ms_per_step=round(ms_dev, 3), frames_per_s=round(batch / ms_dev * 1e3, 1)),
                frames_from_pinned_host=dict(ms_per_step=round(ms_host, 3), frames_per_s=round(batch / ms_host * 1e3, 1),
                                             h2d_ms=round(ms_copy, 3), h2d_GBs=round(nbytes / (ms_copy * 1e-3) / 1e9, 1)),
-               frames_from_host_product_ingest=dict(ms_per_step=round(ms_ovl, 3),
-                                                            frames_per_s=round(batch / ms_ovl * 1e3, 1)),
+               frames_from_host_product_ingest=dict(ms_per_step=round(ms_ovl, 3), frames_per_s=round(batch / ms_ovl * 1e3, 1)),
+               frames_from_pinned_host_product_ingest=dict(ms_per_step=round(ms_pin, 3), frames_per_s=round(batch / ms_pin * 1e3, 1)),
                resize_ms=per['resize'],
                resize_GBs_touched=round(batch * touched_bytes(2160, 3840, 140, 250)[1] / (per['resize'] * 1e-3) / 1e9, 1),
                mean_points_per_map=npts(eng, dev, CP),

@@ -1400,6 +1400,9 @@ static int launch_dw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer
 // the end and are added in wave order, so the result is deterministic and independent of the batch.
 // --------------------------------------------------------------------------------------
 #define IRB_ES 36      // LDS row stride (floats) of 32-channel tiles: 32 + 4 pad (conflict-free float4 rows)
+#ifndef IRB_STAMP
+#define IRB_STAMP(i)   // phase stamps of k_irb: defined by tools/micro/irb_phases.hip only (no code in the product)
+#endif
 
 template <int NT, int PW, int NWV>     // NWV = waves per workgroup = ways of the K split (8 was measured: no gain)
 __global__ __launch_bounds__(64 * NWV) void k_dwpw(const float *__restrict__ X, int H, int W, int C,
@@ -1645,10 +1648,11 @@ struct IrbGeom {
     // floats of LDS; rows NPX..MT*32-1 of Xs are never written: the expand MFMA reads whatever lies behind them
     // (the E array, so still inside the allocation) into accumulator rows that are discarded.  Every byte counts:
     // three workgroups per CU need <= 53 KB each.
-    static size_t lds_floats(int Cin, int CoutP, bool expand) {
+    static size_t lds_floats(int Cin, int CoutP, bool expand, int Ce = 0) {
         const size_t XS = Cin + 4;
         size_t n = (size_t)NPX * XS + (expand ? (size_t)NPX * IRB_ES : 0) + (size_t)NOUT * IRB_ES;
         n += (expand ? 32 * XS : 0) + (size_t)CoutP * IRB_ES + 9 * 32;
+        n += 2 * (size_t)((Ce + 31) / 32 * 32);             // expand / depthwise biases of every chunk
         return n;
     }
 };
@@ -1677,6 +1681,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     float *Wes = D + NOUT * IRB_ES;                         // [32][XS]        expand weights of the chunk
     float *Wps = Wes + (EXPAND ? 32 * XS : 0);              // [CoutP][IRB_ES] project weights of the chunk
     float *Wds = Wps + CoutP * IRB_ES;                      // [9][32]         depthwise weights of the chunk
+    float *Bes = Wds + 9 * 32;                              // [CeP]           expand biases (all chunks): no global load inside the chunk loop
+    float *Bds = Bes + ((Ce + 31) / 32 * 32);               // [CeP]           depthwise biases
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     int bid = blockIdx.x;
     const int tx = bid % tiles_x;
@@ -1783,6 +1789,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         for (int q = 0; q < 3; ++q) store_we(q, load_we(0, q));
         if (wd_mine) *(float4 *)(Wds + wd_t * 32 + wd_c4 * 4) = load_wd(0);
     }
+    for (int i = tid; i < ((Ce + 31) / 32 * 32); i += 256) {
+        if (EXPAND) Bes[i] = i < Ce ? be[i] : 0.f;
+        Bds[i] = i < Ce ? bd[i] : 0.f;
+    }
     __syncthreads();
     f32x16 acc[2];
 #pragma unroll
@@ -1809,7 +1819,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         row_ok[u] = mt < MT && rr < NPX;
         in_img[u] = row_ok[u] && (unsigned)(iy0 + hy) < (unsigned)H && (unsigned)(ix0 + hx) < (unsigned)W;
     }
+    IRB_STAMP(0);
     for (int ch = 0; ch < nchunks; ++ch) {
+        IRB_STAMP(1);
         const int kend = min(32, Ce - ch * 32);
         // requests for the slices needed one phase (Wp) or one chunk (We, Wd) from now
         float4 s_wp[4];
@@ -1848,7 +1860,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                         const int c = ch * 32 + 8 * g + 4 * hh;
                         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (in && c < Ce) {                 // channels beyond Ce (zero weight rows) stay 0, like out-of-image pixels
-                            const float4 bv = *(const float4 *)(be + c);
+                            const float4 bv = *(const float4 *)(Bes + c);
                             v.x = fminf(fmaxf(e[4 * g] + bv.x, 0.f), 6.f);
                             v.y = fminf(fmaxf(e[4 * g + 1] + bv.y, 0.f), 6.f);
                             v.z = fminf(fmaxf(e[4 * g + 2] + bv.z, 0.f), 6.f);
@@ -1858,7 +1870,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                     }
                 }
             }
+            IRB_STAMP(2);
             __syncthreads();                                // barrier 1: E complete; expand(ch), project(ch-1) retired
+            IRB_STAMP(3);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1888,7 +1902,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                         a4.z = fmaf(x.z, w.z, a4.z);
                         a4.w = fmaf(x.w, w.w, a4.w);
                     }
-                const float4 b = *(const float4 *)(bd + c);
+                const float4 b = *(const float4 *)(Bds + c);
                 o.x = fminf(fmaxf(a4.x + b.x, 0.f), 6.f);
                 o.y = fminf(fmaxf(a4.y + b.y, 0.f), 6.f);
                 o.z = fminf(fmaxf(a4.z + b.z, 0.f), 6.f);
@@ -1896,7 +1910,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             }
             *(float4 *)(D + px * IRB_ES + c4 * 4) = o;
         }
+        IRB_STAMP(4);
         __syncthreads();                                    // barrier 2: D and the Wp slice complete; depthwise(ch) retired
+        IRB_STAMP(5);
         if (wd_mine && more) *(float4 *)(Wds + wd_t * 32 + wd_c4 * 4) = s_wd;
         // project: acc[tile] += D . Wp^T over this wave's share of the chunk's channels
         const int k_lo = ks * kw, k_hi = min(kend, k_lo + kw);
@@ -1917,8 +1933,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 }
             }
         }
+        IRB_STAMP(6);
         if (!EXPAND) __syncthreads();
     }
+    IRB_STAMP(7);
     if (KS > 1) {
         // k-split partials -> LDS (over the dead Xs / E arrays), summed in split order; then bias (+ residual),
         // one float4 of channels per thread
@@ -1990,7 +2008,7 @@ static int launch_irb(SvcHandle *h, hipStream_t s, const float *X, int n, int H,
 #define IRB_LAUNCH3(S_, TOH_, TOW_, EXP_, STEM_, CI_, CE_, CO_)                                                      \
     do {                                                                                                             \
         const int tx = ceil_div(OW, TOW_), ty = ceil_div(OH, TOH_);                                                  \
-        const size_t lds = IrbGeom<S_, TOH_, TOW_>::lds_floats(Cin, CoutP, EXP_) * 4;                                \
+        const size_t lds = IrbGeom<S_, TOH_, TOW_>::lds_floats(Cin, CoutP, EXP_, Ce) * 4;                                \
         auto kfn = k_irb<S_, TOH_, TOW_, EXP_, STEM_, CI_, CE_, CO_>;                                                \
         /* tiles of the 96-channel blocks need more than the default 64 KB of dynamic LDS; the attribute is per  */  \
         /* device, so the once-flag lives in the handle (one handle = one device), not in the process            */  \

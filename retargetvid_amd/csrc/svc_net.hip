@@ -713,18 +713,44 @@ __global__ __launch_bounds__(256) void k_pw_sk(const float *__restrict__ X, int 
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     const int nsteps = K >> 3;
     const int s_lo = (wave * nsteps) >> 2, s_hi = ((wave + 1) * nsteps) >> 2;
-#pragma unroll 2
-    for (int st = s_lo; st < s_hi; ++st) {
-        const float4 a = *(const float4 *)(xp + 8 * st);
-#pragma unroll
-        for (int t = 0; t < TN; ++t) {
-            const float4 b = *(const float4 *)(wp[t] + 8 * st);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc[t], 0, 0, 0);       // swapped: lane = row
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc[t], 0, 0, 0);
-        }
+    // The grid of these layers puts two waves on a SIMD, not enough to hide an L2 round trip per k-step (the plain loop
+    // compiles to: three loads, s_waitcnt vmcnt(0), eight MFMAs).  Software pipeline, two k-steps deep, written as
+    // straight-line code (no condition inside the loop: the prefetch index is clamped to the wave's last step, so the
+    // compiler keeps counted waits instead of draining the queue on every branch); an odd last step runs on its own.
+#define SK_LOAD(A_, B_, st_)                                                                     \
+    {                                                                                            \
+        A_ = *(const float4 *)(xp + 8 * (st_));                                                  \
+        _Pragma("unroll") for (int t = 0; t < TN; ++t) B_[t] = *(const float4 *)(wp[t] + 8 * (st_)); \
     }
+#define SK_MFMA(A_, B_)                                                                          \
+    _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                             \
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(B_[t].x, A_.x, acc[t], 0, 0, 0);           \
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(B_[t].y, A_.y, acc[t], 0, 0, 0);           \
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(B_[t].z, A_.z, acc[t], 0, 0, 0);           \
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(B_[t].w, A_.w, acc[t], 0, 0, 0);           \
+    }
+    if (s_hi > s_lo) {
+        const int last = s_hi - 1, pairs = (s_hi - s_lo) >> 1;
+        float4 A0, A1, B0[TN], B1[TN];
+        SK_LOAD(A0, B0, s_lo)
+        SK_LOAD(A1, B1, min(s_lo + 1, last))
+        int st = s_lo;
+        for (int q = 0; q < pairs; ++q, st += 2) {
+            float4 a = A0, b[TN];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[t] = B0[t];
+            SK_LOAD(A0, B0, min(st + 2, last))
+            SK_MFMA(a, b)
+            a = A1;
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[t] = B1[t];
+            SK_LOAD(A1, B1, min(st + 3, last))
+            SK_MFMA(a, b)
+        }
+        if ((s_hi - s_lo) & 1) SK_MFMA(A0, B0)          // A0 / B0 hold step s_hi - 1 by now
+    }
+#undef SK_LOAD
+#undef SK_MFMA
 #pragma unroll
     for (int t = 0; t < TN; ++t)
 #pragma unroll

@@ -9,7 +9,7 @@ O=$R/gpurun_out/profiles_new
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # kernel statistics: the default bench (4 batches in flight) and one batch in flight
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/p4 -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 > $O/p4.log 2>&1
+BENCH_PLAIN=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p4 -- python3 $R/bench.py --steps 60 --warmup 5 --cpu-sample 0 > $O/p4.log 2>&1      # BENCH_PLAIN: only warm-up + timed steps run, all of them pipelined
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p1 -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 --pipeline 1 > $O/p1.log 2>&1
 # HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes; BENCH_PLAIN=1 -> exactly warmup + steps = 1 + 5 steps run
 export BENCH_PLAIN=1

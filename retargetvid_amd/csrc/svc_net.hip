@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx
 // loads together, and nothing overlaps them).  Transposed through the slab, a store instruction writes 8 rows x 128 B:
 // eight whole lines.
 #define PWR_SLAB 36            // floats per slab row: 32 channels + 4 pad
-template <int KS>     // K = 8 * KS
+template <int KS, bool UPS>     // K = 8 * KS; UPS: the up-sample-add term (its taps are requested in front of every tile's MFMAs)
 __global__ __launch_bounds__(256) void k_pwr(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
                                              const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N,
                                              int Npad, int ntw, int relu6, UpsAdd ups) {
@@ -571,7 +571,35 @@ __global__ __launch_bounds__(256) void k_pwr(const float *__restrict__ X, int ld
     // store role of the lane: rows (lane >> 3) + 8 it, channels 4 (lane & 7) .. + 3 of the tile
     const int srow = lane >> 3, sc = (lane & 7) * 4;
     const int nt = ncols >> 5;
+    // up-sample-add: the four taps and weights of each of the lane's four rows do not depend on the tile
+    uint32_t uo[UPS ? 4 : 1][4];
+    float uw[UPS ? 4 : 1][4];
+    if (UPS) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rr = min(m0 + srow + 8 * it, M - 1);
+            uint32_t ox, oy;
+            const uint32_t f = fdivmod(fdivmod((uint32_t)rr, ups.dOW, ox), ups.dOH, oy);
+            const float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ox + 0.5f) - 0.5f, 0.f);
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < ups.UH - 1 ? 1 : 0), x1 = x0 + (x0 < ups.UW - 1 ? 1 : 0);
+            const float ly1 = sy - y0, lx1 = sx - x0;
+            const uint32_t fb = f * (uint32_t)(ups.UH * ups.UW);
+            uo[UPS ? it : 0][0] = (fb + y0 * ups.UW + x0) * (uint32_t)ups.ldu; uo[UPS ? it : 0][1] = (fb + y0 * ups.UW + x1) * (uint32_t)ups.ldu;
+            uo[UPS ? it : 0][2] = (fb + y1 * ups.UW + x0) * (uint32_t)ups.ldu; uo[UPS ? it : 0][3] = (fb + y1 * ups.UW + x1) * (uint32_t)ups.ldu;
+            uw[UPS ? it : 0][0] = 1.f - lx1; uw[UPS ? it : 0][1] = lx1; uw[UPS ? it : 0][2] = 1.f - ly1; uw[UPS ? it : 0][3] = ly1;
+        }
+    }
     for (int t = 0; t < nt; ++t) {
+        const int col = n0 + t * 32 + sc;
+        float4 tap[UPS ? 4 : 1][4];
+        if (UPS) {                                          // requested now, used behind the tile's MFMAs
+            const int cc = min(col, N - 4);
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tap[UPS ? it : 0][q] = *(const float4 *)(ups.U + uo[UPS ? it : 0][q] + cc);
+        }
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -590,7 +618,6 @@ __global__ __launch_bounds__(256) void k_pwr(const float *__restrict__ X, int ld
             *(float4 *)(slab + r * PWR_SLAB + 8 * g + 4 * hh) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
         __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the slab is private to the wave
         __builtin_amdgcn_wave_barrier();
-        const int col = n0 + t * 32 + sc;
         const float4 bv = *(const float4 *)(bch + t * 32 + sc);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -598,16 +625,9 @@ __global__ __launch_bounds__(256) void k_pwr(const float *__restrict__ X, int ld
             float4 v = *(const float4 *)(slab + row * PWR_SLAB + sc);
             if (rr >= M || col >= N) continue;
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-            if (ups.U) {                                    // + the 2x bilinear up-sampling of the low-resolution product (see UpsAdd)
-                uint32_t ox, oy;
-                const uint32_t f = fdivmod(fdivmod((uint32_t)rr, ups.dOW, ox), ups.dOH, oy);
-                const float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ox + 0.5f) - 0.5f, 0.f);
-                const int y0 = (int)sy, x0 = (int)sx;
-                const int y1 = y0 + (y0 < ups.UH - 1 ? 1 : 0), x1 = x0 + (x0 < ups.UW - 1 ? 1 : 0);
-                const float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-                const float *uf = ups.U + (size_t)f * ups.UH * ups.UW * ups.ldu + col;
-                const float4 a0 = *(const float4 *)(uf + ((size_t)y0 * ups.UW + x0) * ups.ldu), a1 = *(const float4 *)(uf + ((size_t)y0 * ups.UW + x1) * ups.ldu);
-                const float4 c0 = *(const float4 *)(uf + ((size_t)y1 * ups.UW + x0) * ups.ldu), c1 = *(const float4 *)(uf + ((size_t)y1 * ups.UW + x1) * ups.ldu);
+            if (UPS) {                                      // + the 2x bilinear up-sampling of the low-resolution product (see UpsAdd)
+                const float lx0 = uw[UPS ? it : 0][0], lx1 = uw[UPS ? it : 0][1], ly0 = uw[UPS ? it : 0][2], ly1 = uw[UPS ? it : 0][3];
+                const float4 a0 = tap[UPS ? it : 0][0], a1 = tap[UPS ? it : 0][1], c0 = tap[UPS ? it : 0][2], c1 = tap[UPS ? it : 0][3];
                 v.x += ly0 * (lx0 * a0.x + lx1 * a1.x) + ly1 * (lx0 * c0.x + lx1 * c1.x);
                 v.y += ly0 * (lx0 * a0.y + lx1 * a1.y) + ly1 * (lx0 * c0.y + lx1 * c1.y);
                 v.z += ly0 * (lx0 * a0.z + lx1 * a1.z) + ly1 * (lx0 * c0.z + lx1 * c1.z);
@@ -1311,7 +1331,7 @@ static int launch_pw_ex(SvcHandle *h, hipStream_t s, const float *X, int ldx, co
 #define PWR_ARGS X, ldx, Wt, ldw, bias, Y, ldy, M, N, Npad, ntw, relu6v, ua
 #define PWR_CASE(KSv)                                                                                                   \
     {                                                                                                                   \
-        auto kfn = k_pwr<KSv>;                                                                                          \
+        auto kfn = ups ? k_pwr<KSv, true> : k_pwr<KSv, false>;                                                          \
         if (h->lds_attr_done.insert((const void *)kfn).second)                                                          \
             SVC_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));     \
         kfn<<<g, 256, lds, s>>>(PWR_ARGS);                                                                              \

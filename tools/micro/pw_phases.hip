@@ -86,7 +86,7 @@ static void study(int M, int N) {
     float *X, *W, *B, *Y;
     hipMalloc(&X, (size_t)M * K * 4); hipMalloc(&W, (size_t)Npad * K * 4); hipMalloc(&B, Npad * 4); hipMalloc(&Y, (size_t)M * N * 4);
     hipMemset(X, 0, (size_t)M * K * 4); hipMemset(W, 0, (size_t)Npad * K * 4); hipMemset(B, 0, Npad * 4);
-    hipFuncSetAttribute((const void *)k_pwr<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipFuncSetAttribute((const void *)k_pwr<KS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipFuncSetAttribute((const void *)k_ablate<KS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipFuncSetAttribute((const void *)k_ablate<KS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipFuncSetAttribute((const void *)k_ablate<KS, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -96,7 +96,7 @@ static void study(int M, int N) {
     for (int ntw = 1; ntw <= 4; ++ntw) {
         const dim3 g((M + 127) / 128, (tiles + ntw - 1) / ntw);
         const size_t lds = (size_t)ntw * 32 * (K + 4) * 4;
-        const float t0 = time_us([&] { k_pwr<KS><<<g, 256, lds, 0>>>(X, K, W, K, B, Y, N, M, N, Npad, ntw, 1, ua); });
+        const float t0 = time_us([&] { k_pwr<KS, false><<<g, 256, lds, 0>>>(X, K, W, K, B, Y, N, M, N, Npad, ntw, 1, ua); });
         const float t1 = time_us([&] { k_ablate<KS, 1><<<g, 256, lds, 0>>>(X, K, W, K, B, Y, N, M, N, Npad, ntw, 1, 0); });
         const float t2 = time_us([&] { k_ablate<KS, 2><<<g, 256, lds, 0>>>(X, K, W, K, B, Y, N, M, N, Npad, ntw, 1, 0); });
         const float t3 = time_us([&] { k_ablate<KS, 3><<<g, 256, lds, 0>>>(X, K, W, K, B, Y, N, M, N, Npad, ntw, 1, 0); });

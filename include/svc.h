@@ -152,6 +152,12 @@ int svc_debug_argsort_u32(SvcHandle *h, const uint32_t *keys_host, int n, int32_
 #define SVC_TAP_DEC 5       /* [32][52][64]   post_upsampling_2 output          */
 #define SVC_TAP_PRE 6       /* [h][w]         pre-softmax map at saliency size  */
 int svc_debug_tap(SvcHandle *h, int which, int frame, float *out_host, size_t cap_floats);
+/* SVC_TAP_INPUT with the fused front kernel (the default): the input is written to memory only by handles created
+ * with SVC_KEEP_INPUT=1 in the environment; otherwise the call fails with SVC_E_INVALID.
+ * svc_front_fused: 1 when the last svc_saliency_u8 call ran LANCZOS + features.0 + features.1 as one kernel
+ * (k_front), 0 when as three (SVC_FRONT=0, or a source size whose tiles do not fit in LDS).  bench.py uses it to
+ * attribute features.1's FLOPs to the right kernel class. */
+int svc_front_fused(const SvcHandle *h);
 
 #ifdef __cplusplus
 }

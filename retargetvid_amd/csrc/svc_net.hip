@@ -344,6 +344,269 @@ __global__ __launch_bounds__(256) void k_stem_mfma(const float *__restrict__ X, 
 }
 
 // --------------------------------------------------------------------------------------
+// The front of the network in one kernel: Pillow LANCZOS + normalise (k_lanczos_norm) -> features.0 (k_stem_mfma) ->
+// features.1 (3x3 depthwise + ReLU6 -> 1x1 project 32 -> 16; the t = 1 case of k_irb) for a tile of 8 x 16 pixels of
+// features.1's output.  As three kernels the 1.3 MB normalised input and the 3.4 MB stem output of every frame are
+// written to memory and read back (46 + 45 + 69 us per 32 frames, the stem and block 1 at 2.4-3.3 TB/s); here the
+// only traffic is the u8 frame in and the 16-channel tensor out.  Per tile:
+//   source patch (u8) -> horizontal pass -> vertical pass + LUT -> 21 x 37 x 3 input patch          (integer, in LDS)
+//   180 halo pixels of features.0 = 6 MFMA tiles of 32 pixels, K = 27 taps padded to 32             (S, in LDS)
+//   depthwise 3x3 on the 128 pixels, one thread = one pixel x 4 channels, weights in registers      (D, in LDS)
+//   project: one 32-pixel tile per wave, the k range in two halves summed afterwards                 (16 channels out)
+// Every stage keeps the operation order of the kernel it replaces (the resampling is integer arithmetic; the MFMA
+// sequences, the tap order of the depthwise sum and the two-way k split of block 1's project are the same), so the
+// result is bit-identical to the three-kernel path.
+// --------------------------------------------------------------------------------------
+#define FR_TH 8
+#define FR_TW 16
+#define FR_HH (FR_TH + 2)           // stem rows of a tile incl. the depthwise halo
+#define FR_HW (FR_TW + 2)
+#define FR_NPX (FR_HH * FR_HW)      // 180
+#define FR_PR (2 * FR_HH + 1)       // 21 input rows
+#define FR_PC (2 * FR_HW + 1)       // 37 input columns
+#define FR_PRS 112                  // floats (bytes for the u8 intermediate) per patch row: 37 x 3 = 111
+#define FR_ES 36                    // floats per pixel of S / D (32 channels + 4: conflict-free float4 rows)
+#define FR_D_BYTES (FR_TH * FR_TW * FR_ES * 4)
+#define FR_S_BYTES (FR_NPX * FR_ES * 4)
+
+#define FR_MAXT 32                  // tiles per frame side (NH, NW <= 416: at most 26 x 13)
+
+struct FrontArgs {
+    const uint8_t *frames;          // [n][h][w][3]
+    int h, w, NH, NW, OH, OW, tiles_x, tiles_y;
+    const int *hb, *hk, *vb, *vk;   // LANCZOS tables (lanczos_tab); coefficient rows are zero-padded to hks / vks
+    int hks, vks;
+    const float *lut;               // [3][256]
+    const float *Wstem, *bstem;     // [32 out][32 taps], [32]
+    const float *Wd, *bd;           // [9][32], [32]
+    const float *Wp, *bp;           // [16][32], [16]
+    float *Y;                       // [n][OH][OW][16]
+    float *in_dbg;                  // optional: the normalised network input [n][NH][NW][3] (debug tap)
+    int nr_cap, nc_cap;             // source rows / columns a tile needs at most
+    int region_a;                   // bytes of the resampling arrays (>= FR_D_BYTES: D lies over them)
+    // first source row / column and their number, per tile row / tile column (in the kernel arguments: the first
+    // global loads of a workgroup then depend on nothing but its block index)
+    short row_lo[FR_MAXT], row_n[FR_MAXT], col_lo[FR_MAXT], col_n[FR_MAXT];
+};
+
+// bytes per source-patch row in LDS: whole aligned 32-bit words around the nc * 3 bytes of a row
+__host__ __device__ static inline int front_src_stride(int nc_cap) { return ((nc_cap * 3 + 6) >> 2) << 2; }
+__host__ __device__ static inline int front_in_offset(int nr_cap, int nc_cap) {
+    return (nr_cap * (front_src_stride(nc_cap) + FR_PRS) + 15) & ~15;
+}
+// bytes of the resampling arrays (source patch, horizontal-pass rows, input patch, vertical coefficient rows, LUT)
+static inline int front_region_a(int nr_cap, int nc_cap) {
+    const int a = front_in_offset(nr_cap, nc_cap) + (FR_PR * FR_PRS + FR_PR * 8 + 24 + 768) * 4;
+    return (std::max(a, (int)FR_D_BYTES) + 15) & ~15;
+}
+
+__global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
+    extern __shared__ uint8_t sm_fr[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    int bid = blockIdx.x;
+    const int tx = bid % A.tiles_x;
+    bid /= A.tiles_x;
+    const int ty = bid % A.tiles_y, f = bid / A.tiles_y;
+    const int oy0 = ty * FR_TH, ox0 = tx * FR_TW, py0 = 2 * oy0 - 3, px0 = 2 * ox0 - 3;
+    const int srs = front_src_stride(A.nc_cap);
+    uint8_t *src_s = sm_fr;                                     // [nr_cap][srs]      source patch (rows start at an aligned word)
+    uint8_t *tile_s = src_s + A.nr_cap * srs;                   // [nr_cap][FR_PRS]   after the horizontal pass
+    float *IN_s = (float *)(sm_fr + front_in_offset(A.nr_cap, A.nc_cap));   // [FR_PR][FR_PRS]  normalised input patch, 0 outside the image
+    int *vk_s = (int *)(IN_s + FR_PR * FR_PRS);                 // [FR_PR][8]         vertical coefficient rows
+    int *vb_s = vk_s + FR_PR * 8;                               // [FR_PR]            first source row of every patch row
+    float *lut_s = (float *)(vb_s + 24);                        // [768]
+    float *D = (float *)sm_fr;                                  // [128][FR_ES]  over the arrays above once they are dead
+    float *S = (float *)(sm_fr + A.region_a);                   // [180][FR_ES]
+    // 1. every global load of the workgroup is requested here, before anything waits: weights of the three layers
+    //    (first used two to four phases later), the source patch as aligned words, coefficients, LUT
+    float4 wv[4], wd[9], wq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wv[q] = *(const float4 *)(A.Wstem + r * 32 + 8 * q + 4 * hh);
+    const int c4 = tid & 7;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wd[t] = *(const float4 *)(A.Wd + t * 32 + c4 * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wq[q] = r < 16 ? *(const float4 *)(A.Wp + r * 32 + 8 * q + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ya = max(py0, 0), yb = min(py0 + FR_PR, A.NH), xa = max(px0, 0), xb = min(px0 + FR_PC, A.NW);
+    const int r_lo = A.row_lo[ty], nr = A.row_n[ty], c_lo = A.col_lo[tx], nc3 = A.col_n[tx] * 3, ncol3 = (xb - xa) * 3;
+    const uintptr_t g0 = (uintptr_t)A.frames + (((size_t)f * A.h + r_lo) * A.w + c_lo) * 3;     // first byte of the patch
+    const int rstep = A.w * 3, gm0 = (int)(g0 & 3), rs3 = rstep & 3;
+    const int srow = tid >> 5, swi = tid & 31;                  // source words: 8 rows x 32 words per round
+    uint32_t sv[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = srow + 8 * it;
+        const uintptr_t ga = g0 + (size_t)row * rstep;
+        const int nwords = ((int)(ga & 3) + nc3 + 3) >> 2;
+        sv[it] = (row < nr && swi < nwords) ? *(const uint32_t *)((ga & ~(uintptr_t)3) + 4 * swi) : 0u;
+    }
+    // a thread owns one (column, channel) of the patch in both passes, and every second row
+    const int ci = tid & 127, half = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const bool col_ok = ci < ncol3;
+    const int xi = ci / 3, cc = ci - 3 * xi, x = min(xa + xi, A.NW - 1), pcol = (x - px0) * 3 + cc;
+    const int xmin = A.hb[2 * x];
+    int kh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kh[j] = j < A.hks ? A.hk[x * A.hks + j] : 0;
+    int vkv = 0, vbv = 0;
+    if (tid < FR_PR * 8) {
+        const int y = ya + (tid >> 3), j = tid & 7;
+        if (y < yb && j < A.vks) vkv = A.vk[y * A.vks + j];
+    } else if (tid < FR_PR * 8 + FR_PR) {
+        const int y = ya + tid - FR_PR * 8;
+        if (y < yb) vbv = A.vb[2 * y];
+    }
+    float lv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) lv[i] = A.lut[tid + 256 * i];
+    for (int i = tid; i < FR_PR * FR_PRS / 4; i += 256) ((float4 *)IN_s)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = srow + 8 * it;
+        if (row < nr && swi < (srs >> 2)) ((uint32_t *)src_s)[row * (srs >> 2) + swi] = sv[it];
+    }
+    if (tid < FR_PR * 8) vk_s[tid] = vkv;
+    else if (tid < FR_PR * 8 + FR_PR) vb_s[tid - FR_PR * 8] = vbv;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) lut_s[tid + 256 * i] = lv[i];
+    __syncthreads();
+    // 2. horizontal pass: the column's (at most eight) coefficients are in registers; taps past the end of the row of
+    //    coefficients carry 0 (their bytes are whatever follows in LDS), so the eight reads of a row are independent
+    if (col_ok) {
+        const uint8_t *p = src_s + (xmin - c_lo) * 3 + cc;
+        for (int row = half; row < nr; row += 2) {
+            const uint8_t *q = p + row * srs + ((gm0 + row * rs3) & 3);
+            int acc = 1 << (LZ_PREC - 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += (int)q[3 * j] * kh[j];
+            tile_s[row * FR_PRS + pcol] = (uint8_t)min(max(acc >> LZ_PREC, 0), 255);
+        }
+    }
+    __syncthreads();
+    // 3. vertical pass + normalisation LUT
+    if (col_ok) {
+        const float *lc = lut_s + cc * 256;
+        const bool dbg_col = A.in_dbg && x >= 2 * ox0 && x < 2 * ox0 + 2 * FR_TW;
+        for (int y = ya + half; y < yb; y += 2) {
+            const int vrow = y - ya;
+            const int4 k0 = *(const int4 *)(vk_s + vrow * 8), k1 = *(const int4 *)(vk_s + vrow * 8 + 4);
+            const uint8_t *q = tile_s + (vb_s[vrow] - r_lo) * FR_PRS + pcol;
+            int acc = 1 << (LZ_PREC - 1);
+            acc += (int)q[0] * k0.x + (int)q[FR_PRS] * k0.y + (int)q[2 * FR_PRS] * k0.z + (int)q[3 * FR_PRS] * k0.w;
+            acc += (int)q[4 * FR_PRS] * k1.x + (int)q[5 * FR_PRS] * k1.y + (int)q[6 * FR_PRS] * k1.z + (int)q[7 * FR_PRS] * k1.w;
+            const float v = lc[min(max(acc >> LZ_PREC, 0), 255)];
+            IN_s[(y - py0) * FR_PRS + pcol] = v;
+            if (dbg_col && y >= 2 * oy0 && y < 2 * oy0 + 2 * FR_TH) A.in_dbg[(((size_t)f * A.NH + y) * A.NW + x) * 3 + cc] = v;
+        }
+    }
+    __syncthreads();
+    // 4. features.0 on the 180 halo pixels (k_stem_mfma's operand roles and tap order); zero outside the image
+    for (int t = wave; t < (FR_NPX + 31) / 32; t += 4) {
+        const int hp = t * 32 + r, hq = min(hp, FR_NPX - 1);
+        const int hy = hq / FR_HW, hx = hq - hy * FR_HW;
+        const float *src = IN_s + (2 * hy) * FR_PRS + (2 * hx) * 3;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float tp[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 8 * q + 4 * hh + e;                // tap (ky, kx, ci) = (k / 9, (k % 9) / 3, k % 3)
+                const int ky = (k * 57) >> 9;
+                tp[e] = k < 27 ? src[k + (FR_PRS - 9) * ky] : 0.f;
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[q].x, tp[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[q].y, tp[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[q].z, tp[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[q].w, tp[3], acc, 0, 0, 0);
+        }
+        if (hp < FR_NPX) {
+            const bool in = (unsigned)(oy0 - 1 + hy) < (unsigned)A.OH && (unsigned)(ox0 - 1 + hx) < (unsigned)A.OW;
+            float *sp = S + hp * FR_ES + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (in) {
+                    const float4 b = *(const float4 *)(A.bstem + 8 * g + 4 * hh);
+                    v.x = fminf(fmaxf(acc[4 * g] + b.x, 0.f), 6.f);
+                    v.y = fminf(fmaxf(acc[4 * g + 1] + b.y, 0.f), 6.f);
+                    v.z = fminf(fmaxf(acc[4 * g + 2] + b.z, 0.f), 6.f);
+                    v.w = fminf(fmaxf(acc[4 * g + 3] + b.w, 0.f), 6.f);
+                }
+                *(float4 *)(sp + 8 * g) = v;
+            }
+        }
+    }
+    __syncthreads();
+    // 5. depthwise 3x3 + bias + ReLU6 (k_irb's tap order): thread = channels 4 c4 .. + 3 of pixels tid / 8 + 32 i
+    {
+        const float4 b = *(const float4 *)(A.bd + c4 * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = (tid >> 3) + 32 * i, oy = px >> 4, ox = px & 15;
+            float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float4 xv = *(const float4 *)(S + ((oy + ky) * FR_HW + ox + kx) * FR_ES + c4 * 4);
+                    const float4 w = wd[ky * 3 + kx];
+                    a4.x = fmaf(xv.x, w.x, a4.x);
+                    a4.y = fmaf(xv.y, w.y, a4.y);
+                    a4.z = fmaf(xv.z, w.z, a4.z);
+                    a4.w = fmaf(xv.w, w.w, a4.w);
+                }
+            float4 o;
+            o.x = fminf(fmaxf(a4.x + b.x, 0.f), 6.f);
+            o.y = fminf(fmaxf(a4.y + b.y, 0.f), 6.f);
+            o.z = fminf(fmaxf(a4.z + b.z, 0.f), 6.f);
+            o.w = fminf(fmaxf(a4.w + b.w, 0.f), 6.f);
+            *(float4 *)(D + px * FR_ES + c4 * 4) = o;
+        }
+    }
+    __syncthreads();
+    // 6. project 32 -> 16: wave = pixels 32 wave .. + 31; k = 0..15 and 16..31 accumulate apart and are added afterwards,
+    //    like the two k-split partials of k_irb on this block
+    {
+        f32x16 a0, a1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+        const int px = 32 * wave + r;
+        const float *dp = D + px * FR_ES + 4 * hh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a = *(const float4 *)(dp + 8 * q);
+            if (q < 2) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q].x, a.x, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q].y, a.y, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q].z, a.z, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q].w, a.w, a0, 0, 0, 0);
+            } else {
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q].x, a.x, a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q].y, a.y, a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q].z, a.z, a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q].w, a.w, a1, 0, 0, 0);
+            }
+        }
+        const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
+        if (oy < A.OH && ox < A.OW) {
+            float *yp = A.Y + (((size_t)f * A.OH + oy) * A.OW + ox) * 16;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int col = 8 * g + 4 * hh;
+                const float4 b = *(const float4 *)(A.bp + col);
+                float4 v = make_float4(a0[4 * g] + a1[4 * g], a0[4 * g + 1] + a1[4 * g + 1], a0[4 * g + 2] + a1[4 * g + 2],
+                                       a0[4 * g + 3] + a1[4 * g + 3]);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                *(float4 *)(yp + col) = v;
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
 // pointwise conv as a GEMM on the f32 MFMA:  Y[M,N] = act(X[M,K] * W[N,K]^T + b) (+ R)
 // Block = 4 waves; wave v owns rows m0+32v..+31 and TN column tiles of 32.
 // Lane l (r = l&31, hh = l>>5) feeds A[r][k] and B[k][r] with k = kk + 4*hh + s for the
@@ -1158,8 +1421,12 @@ struct NetPlan {
     DevBuf ws, fmax, lut, gauss;
     DevBuf hb, hk, vb, vk;
     int hks = 0, vks = 0, lz_rows = 8, lz_tile_cap = 0;       // output rows per workgroup of k_lanczos_norm (SVC_LZ_ROWS)
+    int fr_nr = 0, fr_nc = 0;                                 // source rows / columns one tile of k_front needs at most
+    bool fr_ok = false;                                       // the geometry can run k_front
+    short fr_row_lo[32], fr_row_n[32], fr_col_lo[32], fr_col_n[32];
     int sd_rows = 7, sd_tile_cap = 0;                         // output rows per workgroup of k_smooth_down (SVC_SD_ROWS)
     int last_n = 0;
+    bool last_front = false;       // the last pass ran k_front (the network input is then kept only under SVC_KEEP_INPUT=1)
     int gauss_filled = 0;          // frames of the workspace whose Gaussian-prior channels of CAT1 are already written
     float *buf(int b) const { return (float *)ws.p + off[b] * (size_t)nb; }
     size_t per_frame(int b) const { return off[b + 1] - off[b]; }
@@ -1232,6 +1499,26 @@ static int build_plan(SvcHandle *h, int height, int width, int nb) {
         cap = std::max(cap, vb[2 * (y1 - 1)] + vb[2 * (y1 - 1) + 1] - vb[2 * y0]);
     }
     p->lz_tile_cap = cap;
+    // k_front: source rows / columns of every tile row / column.  The kernel serves up-scaling geometries (at most
+    // eight taps per pass) whose source patch is at most 32 rows of 32 words; anything else runs the three kernels.
+    p->fr_nr = p->fr_nc = 0;
+    const int fty = ceil_div(NH / 2, FR_TH), ftx = ceil_div(NW / 2, FR_TW);
+    p->fr_ok = p->hks <= 8 && p->vks <= 8 && fty <= FR_MAXT && ftx <= FR_MAXT;
+    for (int t = 0; t < FR_MAXT; ++t) p->fr_row_lo[t] = p->fr_row_n[t] = p->fr_col_lo[t] = p->fr_col_n[t] = 0;
+    for (int t = 0; t < fty && p->fr_ok; ++t) {
+        const int ya = std::max(2 * t * FR_TH - 3, 0), yb = std::min(2 * t * FR_TH - 3 + FR_PR, NH);
+        p->fr_row_lo[t] = (short)vb[2 * ya];
+        p->fr_row_n[t] = (short)(vb[2 * (yb - 1)] + vb[2 * (yb - 1) + 1] - vb[2 * ya]);
+        p->fr_nr = std::max(p->fr_nr, (int)p->fr_row_n[t]);
+    }
+    for (int t = 0; t < ftx && p->fr_ok; ++t) {
+        const int xa = std::max(2 * t * FR_TW - 3, 0), xb = std::min(2 * t * FR_TW - 3 + FR_PC, NW);
+        p->fr_col_lo[t] = (short)hb[2 * xa];
+        p->fr_col_n[t] = (short)(hb[2 * (xb - 1)] + hb[2 * (xb - 1) + 1] - hb[2 * xa]);
+        p->fr_nc = std::max(p->fr_nc, (int)p->fr_col_n[t]);
+    }
+    p->fr_ok = p->fr_ok && p->fr_nr <= 32 && front_src_stride(p->fr_nc) <= 128 &&
+               front_region_a(p->fr_nr, p->fr_nc) + FR_S_BYTES <= 64 * 1024;
     if ((rc = p->hb.ensure(hb.size() * 4)) || (rc = p->hk.ensure(hk.size() * 4)) || (rc = p->vb.ensure(vb.size() * 4)) ||
         (rc = p->vk.ensure(vk.size() * 4)))
         return rc;
@@ -2093,8 +2380,12 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     size_t li = 0;
     auto next = [&]() -> const SvcLayer & { return h->layers[li++]; };
     float *IN = p->buf(B_IN), *P[2] = {p->buf(B_P0), p->buf(B_P1)}, *E0 = p->buf(B_E0), *E1 = p->buf(B_E1);
+    // the front of the network (LANCZOS, features.0, features.1) as one kernel where a tile's resampling arrays fit in LDS
+    const int fr_lds = front_region_a(p->fr_nr, p->fr_nc) + FR_S_BYTES;
+    const bool front = h->front && h->stem_mfma && !h->stem_fused && h->fuse_max >= 1 && p->fr_ok;
+    p->last_front = front;
     // K0
-    {
+    if (!front) {
         ProfScope ps(h, SVC_K_LANCZOS, s);
         dim3 grid(ceil_div(NH, p->lz_rows), n);
         size_t lds = ((size_t)p->lz_tile_cap * p->w * 3 + 15) / 16 * 16 + ((size_t)p->lz_tile_cap * NW * 3 + 15) / 16 * 16 +
@@ -2107,7 +2398,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     // stem: on its own, or inside the kernel of backbone block 1 (which then reads the network input directly)
     const SvcLayer &Lstem = next();
     const bool stem_fused = h->stem_fused && h->fuse_max >= 1;
-    if (!stem_fused) {
+    if (!stem_fused && !front) {
         ProfScope ps(h, SVC_K_STEM, s);
         if (h->stem_mfma) {
             const int tx = ceil_div(W, STEM_TW), ty = ceil_div(H, STEM_TH);
@@ -2134,7 +2425,26 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
             int OH = H / dws, OW = W / dws;
             float *y = tap ? p->buf(idx == 7 ? B_F4X : B_F2X) : P[cur ^ 1];
             // the first fuse_max blocks (of 1..13: Cin <= 96, Cout <= 128) run as one fused kernel; the rest un-fused
-            if (idx <= h->fuse_max && (t != 1 || inp == 32)) {
+            if (front && idx == 1) {
+                ProfScope ps(h, SVC_K_STEM, s);
+                const SvcLayer &Ld = next();
+                const SvcLayer &Lp = next();
+                FrontArgs A;
+                A.frames = frames; A.h = p->h; A.w = p->w; A.NH = NH; A.NW = NW; A.OH = H; A.OW = W;
+                A.tiles_x = ceil_div(W, FR_TW); A.tiles_y = ceil_div(H, FR_TH);
+                A.hb = (const int *)p->hb.p; A.hk = (const int *)p->hk.p; A.vb = (const int *)p->vb.p; A.vk = (const int *)p->vk.p;
+                A.hks = p->hks; A.vks = p->vks; A.lut = (const float *)p->lut.p;
+                A.Wstem = (const float *)h->stem_wt.p; A.bstem = Lstem.b.dev;
+                A.Wd = Ld.w.dev; A.bd = Ld.b.dev; A.Wp = Lp.w.dev; A.bp = Lp.b.dev;
+                A.Y = y; A.in_dbg = h->keep_input ? IN : nullptr;
+                A.nr_cap = p->fr_nr; A.nc_cap = p->fr_nc; A.region_a = front_region_a(p->fr_nr, p->fr_nc);
+                for (int i = 0; i < FR_MAXT; ++i) {
+                    A.row_lo[i] = p->fr_row_lo[i]; A.row_n[i] = p->fr_row_n[i];
+                    A.col_lo[i] = p->fr_col_lo[i]; A.col_n[i] = p->fr_col_n[i];
+                }
+                k_front<<<dim3((unsigned)(n * A.tiles_x * A.tiles_y)), 256, fr_lds, s>>>(A);
+                SVC_CHECK_LAUNCH();
+            } else if (idx <= h->fuse_max && (t != 1 || inp == 32)) {
                 const SvcLayer *Le = (t != 1) ? &next() : nullptr;
                 const SvcLayer &Ld = next();
                 const SvcLayer &Lp = next();
@@ -2306,11 +2616,17 @@ extern "C" int svc_debug_tap(SvcHandle *h, int which, int frame, float *out_host
         default: count = (size_t)p->h * p->w; break;
     }
     if (count > cap_floats) { svc_set_error("svc_debug_tap: buffer too small (%zu needed)", count); return SVC_E_INVALID; }
+    if (which == SVC_TAP_INPUT && p->last_front && !h->keep_input) {
+        svc_set_error("svc_debug_tap: the fused front kernel keeps the network input on chip; create the handle with SVC_KEEP_INPUT=1 (or SVC_FRONT=0)");
+        return SVC_E_INVALID;
+    }
     SVC_HIP(hipSetDevice(h->device));
     SVC_HIP(hipDeviceSynchronize());
     SVC_HIP(hipMemcpy(out_host, p->buf(map[which]) + (size_t)frame * count, count * sizeof(float), hipMemcpyDeviceToHost));
     return (int)count;
 }
+
+extern "C" int svc_front_fused(const SvcHandle *h) { return h && h->plan && h->plan->last_front ? 1 : 0; }
 
 // --------------------------------------------------------------------------------------
 // create / destroy
@@ -2393,6 +2709,10 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->stem_mfma = atoi(env);
     env = getenv("SVC_STEM_FUSED");
     if (env) h->stem_fused = atoi(env) != 0;
+    env = getenv("SVC_FRONT");
+    if (env) h->front = atoi(env) != 0;
+    env = getenv("SVC_KEEP_INPUT");
+    if (env) h->keep_input = atoi(env) != 0;
     env = getenv("SVC_DWPW");
     if (env) h->dwpw = atoi(env) != 0;
     env = getenv("SVC_DWPW_MIN_PX");

@@ -117,6 +117,10 @@ class Engine:
         _lib.check(self.lib.svc_profile_read(self._h, ctypes.byref(ms), ctypes.byref(cnt)))
         return ms.value, cnt.value
 
+    def front_fused(self):
+        """True when the last saliency call ran LANCZOS + features.0 + features.1 as the one kernel k_front."""
+        return bool(self.lib.svc_front_fused(self._h))
+
     def argsort_u32(self, keys):
         """Test door: the device's emulation of numpy's default argsort on uint32 keys -> int32 order."""
         keys = np.ascontiguousarray(keys, np.uint32)

@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+# the fused front kernel keeps the normalised network input on chip; the tests read it back through svc_debug_tap
+os.environ.setdefault('SVC_KEEP_INPUT', '1')
 
 
 def pytest_configure(config):

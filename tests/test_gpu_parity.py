@@ -108,6 +108,7 @@ def test_saliency_batch_and_chunk_independence(engine):
     {'SVC_IRB_FIXED': '0'},                                 # generic (run-time shaped) fused block instead of the fixed-shape instances
     {'SVC_STEM_MFMA': '0', 'SVC_SMOOTH_MFMA': '0'},          # features.0 and the 41x41 smoothing as FMA kernels                                 # features.0 as the FMA kernel
     {'SVC_STEM_FUSED': '1'},                                # features.0 inside the kernel of block 1 (MFMA im2col form)
+    {'SVC_FRONT': '0'},                                     # LANCZOS, features.0 and features.1 as three kernels instead of k_front
     {'SVC_CHUNK': '5'},                                     # ragged chunks of the batch
 ])
 def test_saliency_kernel_families_agree(engine, synthetic_sd, knobs):
@@ -136,6 +137,38 @@ def test_saliency_kernel_families_agree(engine, synthetic_sd, knobs):
         assert np.abs(dec - ref_dec).max() <= 2e-4 * np.abs(ref_dec).max()
     d = np.abs(maps.astype(int) - ref_maps.astype(int))
     assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+@pytest.mark.parametrize('shape', [(140, 250), (187, 250), (250, 140), (360, 640), (97, 131)])
+def test_front_kernel_bit_identical_to_three_kernels(engine, synthetic_sd, shape):
+    """k_front (LANCZOS + features.0 + features.1 in one kernel) keeps the operation order of the three kernels it
+    replaces: network input, feature taps and maps are bit-identical, at up-scaling, down-scaling and odd source sizes."""
+    h, w = shape
+    NH, NW = U.get_optimal_out_size((h, w))
+    fr = torch.from_numpy(np.random.RandomState(h * w).randint(0, 256, (5, h, w, 3)).astype(np.uint8)).cuda()
+    maps = engine.saliency(fr).cpu().numpy()
+    taps = [engine.tap(ops.TAP_INPUT, 4, (NH, NW, 3)), engine.tap(ops.TAP_FEAT4X, 4, (NH // 8, NW // 8, 64)),
+            engine.tap(ops.TAP_DEC, 4, (NH // 8, NW // 8, 64))]
+    assert engine.front_fused() == (h <= NH and w <= NW)      # down-scaling geometries run the three kernels
+    old = os.environ.get('SVC_FRONT')
+    os.environ['SVC_FRONT'] = '0'
+    try:
+        other = ops.Engine(synthetic_sd)
+    finally:
+        if old is None:
+            os.environ.pop('SVC_FRONT', None)
+        else:
+            os.environ['SVC_FRONT'] = old
+    try:
+        maps0 = other.saliency(fr).cpu().numpy()
+        taps0 = [other.tap(ops.TAP_INPUT, 4, (NH, NW, 3)), other.tap(ops.TAP_FEAT4X, 4, (NH // 8, NW // 8, 64)),
+                 other.tap(ops.TAP_DEC, 4, (NH // 8, NW // 8, 64))]
+        assert not other.front_fused()
+    finally:
+        other.close()
+    for a, b in zip(taps, taps0):
+        assert np.array_equal(a, b)
+    assert np.array_equal(maps, maps0)
 
 
 def test_tail_bit_exact_default_settings(engine, golden_dir):

@@ -11,7 +11,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # the last complete pass: from the last k_lanczos_norm to the k_quantise after it
-starts = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('k_lanczos')]
+starts = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith(('k_lanczos', 'void k_front', 'k_front'))]
 i0 = starts[-1]
 i1 = next(i for i in range(i0, len(rows)) if rows[i]['Kernel_Name'].startswith('k_quantise'))
 t_prev = None

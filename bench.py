@@ -85,9 +85,10 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA
 
 
-def layer_work(batch, nh=256, nw=416, h=140, w=250):
+def layer_work(batch, nh=256, nw=416, h=140, w=250, front_fused=False):
     """Algorithmic FLOPs / bytes per step for the kernel classes.  Spatial sizes of
-    the static SALICON graph for a 16:9 input."""
+    the static SALICON graph for a 16:9 input.  front_fused: features.1 runs inside k_front, which
+    is timed under the 'stem' class, so its depthwise and project leave the 'dw' / 'pw' work."""
     sp = {1: (nh // 2, nw // 2), 2: (nh // 4, nw // 4), 3: (nh // 8, nw // 8), 4: (nh // 16, nw // 16), 5: (nh // 32, nw // 32)}
     pw = []      # (pixels, cin, cout)
     dw = []      # (in pixels, out pixels, channels)
@@ -104,8 +105,9 @@ def layer_work(batch, nh=256, nw=416, h=140, w=250):
             tap = idx in (7, 14)
             out_level = level + 1 if stride == 2 else level
             opx = px if (stride == 1 or tap) else sp[out_level][0] * sp[out_level][1]
-            dw.append((px, opx, inp * t))
-            pw.append((opx, inp * t, c))
+            if not (front_fused and idx == 1):
+                dw.append((px, opx, inp * t))
+                pw.append((opx, inp * t, c))
             level, inp, idx = out_level, c, idx + 1
     p5, p4, p3 = sp[5][0] * sp[5][1], sp[4][0] * sp[4][1], sp[3][0] * sp[3][1]
     pw += [(p5, 320, 1280), (p4, 160, 320), (p4, 320, 128), (p3, 64, 128), (p3, 128, 64), (p5, 1296, 256),
@@ -282,7 +284,8 @@ def main():
         rank_fps = [B * args.steps / float(t.item()) for t in tl]
 
     if rank == 0:
-        work = layer_work(B)
+        front_fused = eng.front_fused()
+        work = layer_work(B, front_fused=front_fused)
         steps = max(args.steps, 1)
         iso_ms, iso_n = per_class[dominant]
         byte_work = {'pw': work['pw_bytes'], 'dw': work['dw_bytes'], 'lanczos': B * (140 * 250 * 3 + 256 * 416 * 12.0),
@@ -322,6 +325,9 @@ def main():
         except Exception:
             pass
         roof['class_ms_per_step_all'] = {k: round(v[0], 4) for k, v in per_class.items()}
+        if front_fused:
+            roof['class_note'] = ("'stem' = k_front: LANCZOS + features.0 + features.1 in one kernel; features.1's project is not in "
+                                  "the 'pw' FLOPs")
         cpu = None
         if world == 1 and args.cpu_sample > 0:
             torch.set_num_threads(min(16, os.cpu_count() or 1))    # batch-1 convs stop scaling (and collapse) beyond this

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_lanczos_norm(
         const uint8_t *p = in_s + xmin * 3 + c;
         for (int r = 0; r < nr; ++r, p += w * 3) {
             int acc = 1 << (LZ_PREC - 1);
-            for (int j = 0; j < cnt; ++j) acc += (int)p[j * 3] * k[j];
+            for (int j = 0; j < cnt; ++j) acc += __mul24((int)p[j * 3], k[j]);      // |coefficient| < 2^23: exact, full-rate
             tile[r * rowlen + i] = (uint8_t)min(max(acc >> LZ_PREC, 0), 255);
         }
     }
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_lanczos_norm(
             const int *k = vk + y * vks;
             const uint8_t *p = tile + (ymin - r_lo) * rowlen + i;
             int acc = 1 << (LZ_PREC - 1);
-            for (int j = 0; j < cnt; ++j) acc += (int)p[j * rowlen] * k[j];
+            for (int j = 0; j < cnt; ++j) acc += __mul24((int)p[j * rowlen], k[j]);
             dst[(size_t)(y - y0) * rowlen + i] = lc[min(max(acc >> LZ_PREC, 0), 255)];
         }
     }
@@ -351,11 +351,20 @@ __global__ __launch_bounds__(256) void k_stem_mfma(const float *__restrict__ X, 
 // only traffic is the u8 frame in and the 16-channel tensor out.  Per tile:
 //   source patch (u8) -> horizontal pass -> vertical pass + LUT -> 21 x 37 x 3 input patch          (integer, in LDS)
 //   180 halo pixels of features.0 = 6 MFMA tiles of 32 pixels, K = 27 taps padded to 32             (S, in LDS)
-//   depthwise 3x3 on the 128 pixels, one thread = one pixel x 4 channels, weights in registers      (D, in LDS)
+//   depthwise 3x3 on the 128 pixels, one thread = one pixel x 4 channels                            (D, in LDS)
 //   project: one 32-pixel tile per wave, the k range in two halves summed afterwards                 (16 channels out)
 // Every stage keeps the operation order of the kernel it replaces (the resampling is integer arithmetic; the MFMA
 // sequences, the tap order of the depthwise sum and the two-way k split of block 1's project are the same), so the
 // result is bit-identical to the three-kernel path.
+// Measured on MI355X, 32 frames (6656 workgroups, three per CU): 116 us against 160 for the three kernels.  The first
+// form took 154: a tile's time was mostly round trips to memory in series (table look-ups for the patch bounds, then
+// the source bytes, then per-row coefficient loads inside the vertical pass, 17 weight float4 per thread).  Now the patch
+// bounds arrive with the kernel arguments, every global load of the workgroup is issued before the first wait (the
+// source patch as aligned 32-bit words, the weights as one or two float4 per thread parked in LDS until their phase),
+// and the passes read coefficients from registers / LDS.  What is left (skipping one phase at a time): features.0 29 us
+// (six 32-pixel tiles on four waves), vertical pass 17, depthwise 14, project 14 (16 of the 32 MFMA columns are padding),
+// horizontal pass 10, source words 6, workgroup start-up 23.  A persistent variant (one workgroup walking a run of
+// tiles with the next tile's loads in flight) was slower (143 us): fewer independent workgroups hide less.
 // --------------------------------------------------------------------------------------
 #define FR_TH 8
 #define FR_TW 16
@@ -367,7 +376,7 @@ __global__ __launch_bounds__(256) void k_stem_mfma(const float *__restrict__ X, 
 #define FR_PRS 112                  // floats (bytes for the u8 intermediate) per patch row: 37 x 3 = 111
 #define FR_ES 36                    // floats per pixel of S / D (32 channels + 4: conflict-free float4 rows)
 #define FR_D_BYTES (FR_TH * FR_TW * FR_ES * 4)
-#define FR_S_BYTES (FR_NPX * FR_ES * 4)
+#define FR_S_BYTES ((FR_NPX * FR_ES + 48 * FR_ES + 9 * 32) * 4)      // S + the weights of the three layers
 
 #define FR_MAXT 32                  // tiles per frame side (NH, NW <= 416: at most 26 x 13)
 
@@ -417,16 +426,16 @@ __global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
     float *lut_s = (float *)(vb_s + 24);                        // [768]
     float *D = (float *)sm_fr;                                  // [128][FR_ES]  over the arrays above once they are dead
     float *S = (float *)(sm_fr + A.region_a);                   // [180][FR_ES]
-    // 1. every global load of the workgroup is requested here, before anything waits: weights of the three layers
-    //    (first used two to four phases later), the source patch as aligned words, coefficients, LUT
-    float4 wv[4], wd[9], wq[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) wv[q] = *(const float4 *)(A.Wstem + r * 32 + 8 * q + 4 * hh);
+    // 1. every global load of the workgroup is requested here, before anything waits: the weights of the three layers
+    //    (one float4 or two per thread, parked in LDS until their phase), the source patch as aligned words,
+    //    coefficients, LUT
+    float *Wst_s = S + FR_NPX * FR_ES;                          // [32][FR_ES]  features.0, rows = output channels
+    float *Wp_s = Wst_s + 32 * FR_ES;                           // [16][FR_ES]  project
+    float *Wd_s = Wp_s + 16 * FR_ES;                            // [9][32]      depthwise
+    const float4 w_st = *(const float4 *)(A.Wstem + tid * 4);
+    const float4 w_p = tid < 128 ? *(const float4 *)(A.Wp + tid * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 w_d = tid < 72 ? *(const float4 *)(A.Wd + tid * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     const int c4 = tid & 7;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wd[t] = *(const float4 *)(A.Wd + t * 32 + c4 * 4);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) wq[q] = r < 16 ? *(const float4 *)(A.Wp + r * 32 + 8 * q + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
     const int ya = max(py0, 0), yb = min(py0 + FR_PR, A.NH), xa = max(px0, 0), xb = min(px0 + FR_PC, A.NW);
     const int r_lo = A.row_lo[ty], nr = A.row_n[ty], c_lo = A.col_lo[tx], nc3 = A.col_n[tx] * 3, ncol3 = (xb - xa) * 3;
     const uintptr_t g0 = (uintptr_t)A.frames + (((size_t)f * A.h + r_lo) * A.w + c_lo) * 3;     // first byte of the patch
@@ -460,6 +469,9 @@ __global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) lv[i] = A.lut[tid + 256 * i];
     for (int i = tid; i < FR_PR * FR_PRS / 4; i += 256) ((float4 *)IN_s)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    *(float4 *)(Wst_s + (tid >> 3) * FR_ES + (tid & 7) * 4) = w_st;
+    if (tid < 128) *(float4 *)(Wp_s + (tid >> 3) * FR_ES + (tid & 7) * 4) = w_p;
+    if (tid < 72) *(float4 *)(Wd_s + tid * 4) = w_d;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int row = srow + 8 * it;
@@ -478,7 +490,7 @@ __global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
             const uint8_t *q = p + row * srs + ((gm0 + row * rs3) & 3);
             int acc = 1 << (LZ_PREC - 1);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc += (int)q[3 * j] * kh[j];
+            for (int j = 0; j < 8; ++j) acc += __mul24((int)q[3 * j], kh[j]);     // |coefficient| < 2^23: the 24-bit multiply is exact and full-rate
             tile_s[row * FR_PRS + pcol] = (uint8_t)min(max(acc >> LZ_PREC, 0), 255);
         }
     }
@@ -492,8 +504,8 @@ __global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
             const int4 k0 = *(const int4 *)(vk_s + vrow * 8), k1 = *(const int4 *)(vk_s + vrow * 8 + 4);
             const uint8_t *q = tile_s + (vb_s[vrow] - r_lo) * FR_PRS + pcol;
             int acc = 1 << (LZ_PREC - 1);
-            acc += (int)q[0] * k0.x + (int)q[FR_PRS] * k0.y + (int)q[2 * FR_PRS] * k0.z + (int)q[3 * FR_PRS] * k0.w;
-            acc += (int)q[4 * FR_PRS] * k1.x + (int)q[5 * FR_PRS] * k1.y + (int)q[6 * FR_PRS] * k1.z + (int)q[7 * FR_PRS] * k1.w;
+            acc += __mul24((int)q[0], k0.x) + __mul24((int)q[FR_PRS], k0.y) + __mul24((int)q[2 * FR_PRS], k0.z) + __mul24((int)q[3 * FR_PRS], k0.w);
+            acc += __mul24((int)q[4 * FR_PRS], k1.x) + __mul24((int)q[5 * FR_PRS], k1.y) + __mul24((int)q[6 * FR_PRS], k1.z) + __mul24((int)q[7 * FR_PRS], k1.w);
             const float v = lc[min(max(acc >> LZ_PREC, 0), 255)];
             IN_s[(y - py0) * FR_PRS + pcol] = v;
             if (dbg_col && y >= 2 * oy0 && y < 2 * oy0 + 2 * FR_TH) A.in_dbg[(((size_t)f * A.NH + y) * A.NW + x) * 3 + cc] = v;
@@ -501,6 +513,9 @@ __global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
     }
     __syncthreads();
     // 4. features.0 on the 180 halo pixels (k_stem_mfma's operand roles and tap order); zero outside the image
+    float4 wv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wv[q] = *(const float4 *)(Wst_s + r * FR_ES + 8 * q + 4 * hh);
     for (int t = wave; t < (FR_NPX + 31) / 32; t += 4) {
         const int hp = t * 32 + r, hq = min(hp, FR_NPX - 1);
         const int hy = hq / FR_HW, hx = hq - hy * FR_HW;
@@ -543,6 +558,9 @@ __global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
     // 5. depthwise 3x3 + bias + ReLU6 (k_irb's tap order): thread = channels 4 c4 .. + 3 of pixels tid / 8 + 32 i
     {
         const float4 b = *(const float4 *)(A.bd + c4 * 4);
+        float4 wd[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wd[t] = *(const float4 *)(Wd_s + t * 32 + c4 * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int px = (tid >> 3) + 32 * i, oy = px >> 4, ox = px & 15;
@@ -570,6 +588,9 @@ __global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
     // 6. project 32 -> 16: wave = pixels 32 wave .. + 31; k = 0..15 and 16..31 accumulate apart and are added afterwards,
     //    like the two k-split partials of k_irb on this block
     {
+        float4 wq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wq[q] = r < 16 ? *(const float4 *)(Wp_s + r * FR_ES + 8 * q + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
         f32x16 a0, a1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { a0[i] = 0.f; a1[i] = 0.f; }

@@ -7,6 +7,7 @@ from retargetvid_amd import ops, weights, synth
 from oracle import unisal_ref as U, cv_ref, tail_ref as T, hdbscan_ref as H, pipeline_ref as P
 
 torch.set_num_threads(8)
+os.environ.setdefault('SVC_KEEP_INPUT', '1')      # the input tap below needs the fused front kernel to write it
 sd = weights.make_synthetic_state_dict(0)
 eng = ops.Engine(sd)
 ok = True

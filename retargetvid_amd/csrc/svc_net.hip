@@ -555,33 +555,43 @@ __global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
         }
     }
     __syncthreads();
-    // 5. depthwise 3x3 + bias + ReLU6 (k_irb's tap order): thread = channels 4 c4 .. + 3 of pixels tid / 8 + 32 i
+    // 5. depthwise 3x3 + bias + ReLU6 (k_irb's tap order): thread = channels 4 c4 .. + 3 of four adjacent pixels of a row,
+    //    from six columns per halo row (18 LDS reads for four outputs instead of 36: the phase is bound by LDS bandwidth)
     {
         const float4 b = *(const float4 *)(A.bd + c4 * 4);
         float4 wd[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) wd[t] = *(const float4 *)(Wd_s + t * 32 + c4 * 4);
+        const int oy = tid >> 5, ox = ((tid >> 3) & 3) * 4;
+        float4 a4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float *sp = S + ((oy + ky) * FR_HW + ox) * FR_ES + c4 * 4;
+            float4 xv[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) xv[j] = *(const float4 *)(sp + j * FR_ES);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 w = wd[ky * 3 + kx];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a4[i].x = fmaf(xv[i + kx].x, w.x, a4[i].x);
+                    a4[i].y = fmaf(xv[i + kx].y, w.y, a4[i].y);
+                    a4[i].z = fmaf(xv[i + kx].z, w.z, a4[i].z);
+                    a4[i].w = fmaf(xv[i + kx].w, w.w, a4[i].w);
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int px = (tid >> 3) + 32 * i, oy = px >> 4, ox = px & 15;
-            float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float4 xv = *(const float4 *)(S + ((oy + ky) * FR_HW + ox + kx) * FR_ES + c4 * 4);
-                    const float4 w = wd[ky * 3 + kx];
-                    a4.x = fmaf(xv.x, w.x, a4.x);
-                    a4.y = fmaf(xv.y, w.y, a4.y);
-                    a4.z = fmaf(xv.z, w.z, a4.z);
-                    a4.w = fmaf(xv.w, w.w, a4.w);
-                }
             float4 o;
-            o.x = fminf(fmaxf(a4.x + b.x, 0.f), 6.f);
-            o.y = fminf(fmaxf(a4.y + b.y, 0.f), 6.f);
-            o.z = fminf(fmaxf(a4.z + b.z, 0.f), 6.f);
-            o.w = fminf(fmaxf(a4.w + b.w, 0.f), 6.f);
-            *(float4 *)(D + px * FR_ES + c4 * 4) = o;
+            o.x = fminf(fmaxf(a4[i].x + b.x, 0.f), 6.f);
+            o.y = fminf(fmaxf(a4[i].y + b.y, 0.f), 6.f);
+            o.z = fminf(fmaxf(a4[i].z + b.z, 0.f), 6.f);
+            o.w = fminf(fmaxf(a4[i].w + b.w, 0.f), 6.f);
+            *(float4 *)(D + (oy * FR_TW + ox + i) * FR_ES + c4 * 4) = o;
         }
     }
     __syncthreads();

@@ -134,6 +134,8 @@ struct SvcHandle {
     int stem_mfma = 1;                 // features.0 as MFMA im2col tiles (SVC_STEM_MFMA=0: the FMA kernel k_stem)
     bool stem_fused = false;           // features.0 computed inside the kernel of backbone block 1 (SVC_STEM_FUSED=1); measured equal to k_stem + block 1 at B=32 (146 vs 151 us), 218 MB less HBM traffic per 32 frames
     bool front = true;                 // LANCZOS + features.0 + features.1 as one kernel, k_front (SVC_FRONT=0: three kernels)
+    bool use_graph = false;            // repeated passes (same buffers and size) replay a captured hipGraph (SVC_GRAPH=1)
+    std::map<std::tuple<const void *, void *, int, int, int, const void *>, hipGraphExec_t> graphs;
     bool keep_input = false;           // ... which then also writes the normalised network input for svc_debug_tap(SVC_TAP_INPUT) (SVC_KEEP_INPUT=1)
     bool dwpw = true;                  // depthwise 3x3 fused into the following 1x1 project (SVC_DWPW=0: two kernels)
     int dwpw_min_px = 400;             // ... on levels with at least this many pixels per frame; the 8x13 level has too few patches (SVC_DWPW_MIN_PX)

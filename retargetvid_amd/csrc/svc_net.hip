@@ -1607,6 +1607,8 @@ int svc_net_release(SvcHandle *h) {
         delete p;
         h->plan = nullptr;
     }
+    for (auto &kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
     for (auto &kv : h->cvtabs) kv.second.release();
     h->cvtabs.clear();
     return SVC_OK;
@@ -2671,9 +2673,43 @@ extern "C" int svc_saliency_u8(SvcHandle *h, const uint8_t *frames, int n, int h
     const int nb = std::min(n, h->chunk);
     RC(build_plan(h, height, width, nb));
     const size_t fin = (size_t)height * width * 3, fout = (size_t)height * width;
+    hipStream_t s = (hipStream_t)stream;
     for (int i = 0; i < n; i += h->plan->nb) {
         int m = std::min(h->plan->nb, n - i);
-        RC(forward_chunk(h, frames + i * fin, m, maps + i * fout, (hipStream_t)stream));
+        const uint8_t *fr = frames + i * fin;
+        uint8_t *mp = maps + i * fout;
+        // SVC_GRAPH=1: a pass with the same buffers, size and workspace as an earlier one replays that pass's launches as a
+        // hipGraph (captured on the second sighting: the first runs eagerly, so one-time work -- function attributes,
+        // the constant prior maps -- stays out of the graph).  Profiled passes and the null stream always launch directly.
+        if (h->use_graph && h->prof_class < 0 && s) {
+            const auto key = std::make_tuple((const void *)fr, (void *)mp, m, height, width, (const void *)h->plan->ws.p);
+            auto it = h->graphs.find(key);
+            if (it != h->graphs.end() && it->second) {
+                SVC_HIP(hipGraphLaunch(it->second, s));
+                h->plan->last_n = m;
+                continue;
+            }
+            if (it != h->graphs.end()) {                    // second sighting: capture, instantiate, launch
+                hipGraph_t g = nullptr;
+                SVC_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                const int rc = forward_chunk(h, fr, m, mp, s);
+                const hipError_t e = hipStreamEndCapture(s, &g);
+                if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+                SVC_HIP(e);
+                hipGraphExec_t ex = nullptr;
+                SVC_HIP(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(g);
+                it->second = ex;
+                SVC_HIP(hipGraphLaunch(ex, s));
+                continue;
+            }
+            if (h->graphs.size() >= 64) {                   // a stream of ever-new buffers: stop caching
+                for (auto &kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+                h->graphs.clear();
+            }
+            h->graphs.emplace(key, nullptr);
+        }
+        RC(forward_chunk(h, fr, m, mp, s));
     }
     return SVC_OK;
 }
@@ -2790,6 +2826,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->stem_fused = atoi(env) != 0;
     env = getenv("SVC_FRONT");
     if (env) h->front = atoi(env) != 0;
+    env = getenv("SVC_GRAPH");
+    if (env) h->use_graph = atoi(env) != 0;
     env = getenv("SVC_KEEP_INPUT");
     if (env) h->keep_input = atoi(env) != 0;
     env = getenv("SVC_DWPW");

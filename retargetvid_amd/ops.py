@@ -65,12 +65,16 @@ class Engine:
         return out
 
     # -- saliency ------------------------------------------------------------------------
-    def saliency(self, frames):
-        """uint8 [n,h,w,3] RGB at saliency size -> uint8 [n,h,w] maps (frame-major)."""
+    def saliency(self, frames, out=None):
+        """uint8 [n,h,w,3] RGB at saliency size -> uint8 [n,h,w] maps (frame-major); `out`: write into this tensor."""
         _need_cuda(frames, torch.uint8, 'frames')
         n, h, w, c = frames.shape
         assert c == 3
-        out = torch.empty((n, h, w), dtype=torch.uint8, device=frames.device)
+        if out is None:
+            out = torch.empty((n, h, w), dtype=torch.uint8, device=frames.device)
+        else:
+            _need_cuda(out, torch.uint8, 'out')
+            assert tuple(out.shape) == (n, h, w)
         _lib.check(self.lib.svc_saliency_u8(self._h, _ptr(frames), n, h, w, _ptr(out), _stream()))
         return out
 

@@ -171,6 +171,43 @@ def test_front_kernel_bit_identical_to_three_kernels(engine, synthetic_sd, shape
     assert np.array_equal(maps, maps0)
 
 
+def test_graph_replay_matches_direct_launches(engine, synthetic_sd):
+    """SVC_GRAPH=1: the third and later passes over the same buffers replay a captured hipGraph; same maps as direct
+    launches, also after the input frames change in place and after a pass with other buffers in between."""
+    fr = torch.from_numpy(synth.blob_frames(6, 140, 250, seed=33)).cuda()
+    fr2 = torch.from_numpy(synth.blob_frames(6, 140, 250, seed=34)).cuda()
+    ref, ref2 = engine.saliency(fr), engine.saliency(fr2)
+    old = os.environ.get('SVC_GRAPH')
+    os.environ['SVC_GRAPH'] = '1'
+    try:
+        other = ops.Engine(synthetic_sd)
+    finally:
+        if old is None:
+            os.environ.pop('SVC_GRAPH', None)
+        else:
+            os.environ['SVC_GRAPH'] = old
+    try:
+        buf = fr.clone()
+        out = torch.empty((6, 140, 250), dtype=torch.uint8, device='cuda')
+        st = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            for i in range(4):                               # eager, capture + launch, replay, replay
+                other.saliency(buf, out=out)
+                st.synchronize()
+                assert torch.equal(out, ref), i
+            buf.copy_(fr2)                                   # same buffers, new content: the replay must see it
+            other.saliency(buf, out=out)
+            st.synchronize()
+            assert torch.equal(out, ref2)
+            assert torch.equal(other.saliency(fr), ref)      # other buffers: a direct pass
+            other.saliency(buf, out=out)
+            st.synchronize()
+            assert torch.equal(out, ref2)
+    finally:
+        other.close()
+
+
 def test_tail_bit_exact_default_settings(engine, golden_dir):
     CP = P.init_crop_params()
     g = np.load(os.path.join(golden_dir, 'unisal_golden.npz'))

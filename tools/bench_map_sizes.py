@@ -1,0 +1,24 @@
+"""Points per map (N after the threshold) of bench.py's synthetic batch, and the tail kernels' time on them (GPU box helper)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from retargetvid_amd import ops, synth, weights
+from oracle import pipeline_ref as P
+eng = ops.Engine(weights.make_synthetic_state_dict(0))
+CP = P.init_crop_params()
+fr = torch.from_numpy(synth.blob_frames(32, 360, 640, seed=100)).cuda()
+small = eng.resize_frames(fr, 140, 250)
+maps = eng.saliency(small)
+eng.threshold_(maps, CP['t_threshold'])
+n = (maps != 0).flatten(1).sum(1).cpu().numpy()
+print('N per map: min %d mean %.0f max %d' % (n.min(), n.mean(), n.max()), n[:8])
+flags = np.zeros(32, np.uint8); flags[:2] = 1
+for tag in ('flags', 'none'):
+    fl = flags if tag == 'flags' else np.zeros(32, np.uint8)
+    for _ in range(3):
+        m = maps.clone(); eng.cluster_center_(m, fl, CP)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(10):
+        m = maps.clone(); eng.cluster_center_(m, fl, CP)
+    torch.cuda.synchronize()
+    print('%s tail %s: %.3f ms' % (os.environ.get('TAG', ''), tag, (time.perf_counter() - t) / 10 * 1e3))

@@ -22,3 +22,9 @@ for tag in ('flags', 'none'):
         m = maps.clone(); eng.cluster_center_(m, fl, CP)
     torch.cuda.synchronize()
     print('%s tail %s: %.3f ms' % (os.environ.get('TAG', ''), tag, (time.perf_counter() - t) / 10 * 1e3))
+m = maps.clone(); eng.cluster_center_(m, np.zeros(32, np.uint8), CP); torch.cuda.synchronize()
+for i in range(0, 32, 6):
+    st = eng.cluster_state(i, 35000)
+    h = st['hdr']
+    print('  map %2d: N=%5d clusters %3d  stamps (us, 100 MHz wall clock): k_sort %.1f | k_tree built %.1f hierarchy %.1f chosen %.1f | '
+          'k_finish %.1f | k_prim %.1f' % (i, st['n'], h[4], h[8] / 100.0, h[13] / 100.0, h[9] / 100.0, h[10] / 100.0, h[11] / 100.0, h[12] / 100.0))

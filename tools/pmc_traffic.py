@@ -21,7 +21,7 @@ import csv
 import glob
 import json
 
-CLASS = [('k_dwpw', 'pw'), ('k_pw', 'pw'), ('k_irb', 'pw'), ('k_dw', 'dw'), ('k_stem', 'stem'), ('k_lanczos', 'lanczos'),
+CLASS = [('k_dwpw', 'pw'), ('k_pw', 'pw'), ('k_irb', 'pw'), ('k_dw', 'dw'), ('k_front', 'stem'), ('k_stem', 'stem'), ('k_lanczos', 'lanczos'),
          ('k_cv_resize', 'resize'), ('k_smooth', 'smooth'), ('k_quant', 'smooth'),
          ('k_subsample', 'resample'), ('k_upsample', 'resample'), ('k_gauss', 'resample'), ('k_adapt', 'resample'),
          ('k_prim', 'prim'), ('k_sort', 'finish'), ('k_tree', 'finish'), ('k_finish', 'finish'), ('k_core', 'core'),

@@ -38,7 +38,7 @@ import time
 
 # one HIP stream per in-flight batch: give the runtime enough hardware queues that the streams do not
 # share one (ROCclr default is 4; with it the same run is ~20 % slower) — must be set before HIP starts
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -175,6 +175,7 @@ def main():
 
     B = args.batch
     P = max(1, args.pipeline)
+    TAIL_CUS = int(os.environ.get('BENCH_TAIL_CUS', '0'))          # 0: one stream per batch; 32 / 64: the tail on a CU-masked stream
     sd = weights.make_synthetic_state_dict(0)
     CP = S.sc_init_crop_params()
     CP['out_ratio'] = '1:3'
@@ -184,30 +185,62 @@ def main():
     if os.environ.get('BENCH_NO_BLEND', '0') != '1':   # (diagnostic: a batch without a cut has one tail round instead of three)
         flags[:2] = 1                  # the batch starts a shot: maps 0,1 blend into 1,2 (smartVidCrop.py:2369-2373)
 
+    spans = {'net': 0.0, 'tail': 0.0, 'n': 0}                  # device milliseconds of a batch's two phases (HIP events on its stream)
+    host_t = {'wait': 0.0, 'boxes': 0.0, 'enqueue': 0.0}      # host seconds: waiting for a batch, boxes on the host, enqueueing a batch
+
+    tail_pool, slots_made = [], []
+
     class Slot:
         """One in-flight step: its own engine (weights + workspace), HIP stream and pinned result buffer,
         so the low-occupancy clustering tail of one batch overlaps the network of the next."""
         def __init__(self):
             self.eng = ops.Engine(sd)
             self.stream = torch.cuda.Stream(device=dev)
+            # the clustering tail on a stream of its own, confined to TAIL_CUS compute units: its long single-workgroup
+            # kernels then neither wait behind the next batch's network in the same queue nor slow the network's
+            # workgroups on the CUs they would otherwise share with them
+            self.masked = ops.MaskedStream(ops.tail_cu_mask(TAIL_CUS), device=dev.index or 0) if TAIL_CUS > 0 else None
+            if TAIL_CUS < 0:                                  # plain second stream: one of -TAIL_CUS shared tail streams
+                while len(tail_pool) < -TAIL_CUS:
+                    tail_pool.append(torch.cuda.Stream(device=dev))
+                self.tail_stream = tail_pool[len(slots_made) % len(tail_pool)]
+            else:
+                self.tail_stream = self.masked.stream if self.masked else self.stream
+            slots_made.append(self)
             self.xy_host = torch.empty((B, 2), dtype=torch.float64).pin_memory()
-            self.done = torch.cuda.Event()
+            self.maps = torch.empty((B, 140, 250), dtype=torch.uint8, device=dev)
+            self.net_done = torch.cuda.Event(enable_timing=True)
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.done = torch.cuda.Event(enable_timing=True)
             self.pending = False
 
         def enqueue(self):
             with torch.cuda.stream(self.stream):
+                self.start.record(self.stream)
                 small = self.eng.resize_frames(frames, 140, 250)
-                maps = self.eng.saliency(small)
+                maps = self.eng.saliency(small, out=self.maps)
                 self.eng.threshold_(maps, CP['t_threshold'])
+                self.net_done.record(self.stream)
+            with torch.cuda.stream(self.tail_stream):
+                if self.tail_stream is not self.stream:
+                    self.tail_stream.wait_event(self.net_done)
                 xy = self.eng.cluster_center_(maps, flags, CP)
                 self.xy_host.copy_(xy, non_blocking=True)
-                self.done.record(self.stream)
+                self.done.record(self.tail_stream)
             self.pending = True
 
         def finish(self):
+            t0 = time.perf_counter()
             self.done.synchronize()
+            t1 = time.perf_counter()
             self.pending = False
-            return host_boxes(self.xy_host.numpy())
+            spans['net'] += self.start.elapsed_time(self.net_done)
+            spans['tail'] += self.net_done.elapsed_time(self.done)
+            spans['n'] += 1
+            b = host_boxes(self.xy_host.numpy())
+            host_t['wait'] += t1 - t0
+            host_t['boxes'] += time.perf_counter() - t1
+            return b
 
     slots = [Slot() for _ in range(P)]
     torch.cuda.synchronize()
@@ -218,7 +251,9 @@ def main():
             sl = slots[s % P]
             if sl.pending:
                 boxes = sl.finish()
+            t0 = time.perf_counter()
             sl.enqueue()
+            host_t['enqueue'] += time.perf_counter() - t0
         for sl in slots:
             if sl.pending:
                 boxes = sl.finish()
@@ -261,9 +296,14 @@ def main():
 
     # 2. the timed region: K steps, P batches in flight
     barrier()
+    for k in host_t:
+        host_t[k] = 0.0
+    spans.update(net=0.0, tail=0.0, n=0)
     t0 = time.perf_counter()
     boxes = run(args.steps)
     barrier()
+    host_ms = {k: round(v / max(args.steps, 1) * 1e3, 4) for k, v in host_t.items()}
+    span_ms = {'network': round(spans['net'] / max(spans['n'], 1), 4), 'tail': round(spans['tail'] / max(spans['n'], 1), 4)}
     dt_local = dt = time.perf_counter() - t0
     fl_ms, fl_launches = 0.0, 0
     for sl in slots:
@@ -353,7 +393,8 @@ def main():
                                world_size_seen_by_rccl=seen_world if dist_on else None,
                                per_rank_frames_per_s=[round(v, 1) for v in rank_fps],
                                one_batch_in_flight=dict(latency_ms_per_batch=round(latency_ms, 4),
-                                                        frames_per_s=round(B / latency_ms * 1e3, 1))),
+                                                        frames_per_s=round(B / latency_ms * 1e3, 1)),
+                               host_ms_per_step=host_ms, batch_phase_ms_in_the_pipeline=span_ms),
                    roofline=roof, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if dist_on:

@@ -71,8 +71,7 @@ struct TailArgs {
     uint8_t *maps;          // [n][h][w]
     uint8_t *ws;            // per-frame workspace
     size_t ws_stride;
-    const uint8_t *depth;   // [n] round in which each frame runs
-    int round;
+    const uint16_t *order;  // the maps this launch works on (one workgroup each): the current round's slice of the list of all maps sorted by round
     int n, h, w;
     FDiv dW;                // division by w
     int mcs, min_samples, select_sum, op_close, clust_filt;
@@ -150,9 +149,8 @@ __global__ __launch_bounds__(256) void k_threshold(uint8_t *maps, size_t n, int 
     }
 }
 
-__global__ __launch_bounds__(256) void k_blend(uint8_t *maps, const uint8_t *depth, int round, int hw) {
-    const int f = blockIdx.y;
-    if (depth[f] != round) return;
+__global__ __launch_bounds__(256) void k_blend(uint8_t *maps, const uint16_t *order, int hw) {
+    const int f = order[blockIdx.y];                        // the maps of this round (see svc_cluster_center)
     uint8_t *cur = maps + (size_t)f * hw;
     const uint8_t *prev = cur - hw;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256)
@@ -176,10 +174,9 @@ __global__ __launch_bounds__(256) void k_iou(const int4 *__restrict__ a, const i
 // tab (int32): xofs[ow] | xa[ow][2] | yofs[oh] | ya[oh][2] | xmax
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_map_resize(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
-                                                    const int *__restrict__ tab, const uint8_t *__restrict__ depth,
-                                                    int round, int h, int w, int oh, int ow) {
-    const int f = blockIdx.y;
-    if (depth[f] != round) return;
+                                                    const int *__restrict__ tab, const uint16_t *__restrict__ order,
+                                                    int h, int w, int oh, int ow) {
+    const int f = order[blockIdx.y];
     const int *xofs = tab, *xa = tab + ow, *yofs = tab + 3 * ow, *ya = tab + 3 * ow + oh;
     const int xmax = tab[3 * ow + 3 * oh];
     const uint8_t *src = in + (size_t)f * h * w;
@@ -245,8 +242,7 @@ __device__ __forceinline__ void copy_bytes(uint8_t *__restrict__ dst, const uint
 }
 
 __global__ __launch_bounds__(TB) void k_compact(TailArgs A) {
-    const int f = blockIdx.x;
-    if (A.depth[f] != A.round) return;
+    const int f = A.order[blockIdx.x];
     __shared__ int lds16[NW16];
     extern __shared__ uint8_t sm_compact[];                  // the map: read once with whole lines, scanned from LDS
     const int hw = A.h * A.w;
@@ -289,8 +285,7 @@ __global__ __launch_bounds__(TB) void k_compact(TailArgs A) {
 //     of points within distance t over all N points.
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TB) void k_core(TailArgs A) {
-    const int f = blockIdx.x;
-    if (A.depth[f] != A.round) return;
+    const int f = A.order[blockIdx.x];
     uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
     const int32_t *hdr = (const int32_t *)(ws + A.L.hdr);
     if (!hdr[3]) return;
@@ -599,8 +594,7 @@ __device__ __forceinline__ void prim_global(const uint32_t *__restrict__ core_g,
 }
 
 __global__ __launch_bounds__(TB) void k_prim(TailArgs A) {
-    const int f = blockIdx.x;
-    if (A.depth[f] != A.round) return;
+    const int f = A.order[blockIdx.x];
     uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
     const int32_t *hdr = (const int32_t *)(ws + A.L.hdr);
     if (!hdr[3]) return;
@@ -1254,8 +1248,7 @@ __device__ __forceinline__ void sort_carve(uint8_t *lds, uint8_t *glob, int n, S
 }
 
 __global__ __launch_bounds__(TB) void k_sort(TailArgs A) {
-    const int f = blockIdx.x;
-    if (A.depth[f] != A.round) return;
+    const int f = A.order[blockIdx.x];
     uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
     int32_t *hdr = (int32_t *)(ws + A.L.hdr);
     if (!hdr[3]) return;
@@ -1286,8 +1279,7 @@ __global__ __launch_bounds__(TB) void k_argsort_test(const uint32_t *keys, int n
 // serial union-find pass, so the map gets ONE wavefront (64 threads): the other SIMDs and wave slots of
 // the CU stay free for the network kernels of the next batch (which use no LDS).
 __global__ __launch_bounds__(64) void k_tree(TailArgs A) {
-    const int f = blockIdx.x;
-    if (A.depth[f] != A.round) return;
+    const int f = A.order[blockIdx.x];
     uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
     int32_t *hdr = (int32_t *)(ws + A.L.hdr);
     if (!hdr[3]) return;
@@ -1304,8 +1296,7 @@ __global__ __launch_bounds__(64) void k_tree(TailArgs A) {
 
 // k_finish: zero everything outside the kept cluster, CLOSE 5x5, write the map back, centroid
 __global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
-    const int f = blockIdx.x;
-    if (A.depth[f] != A.round) return;
+    const int f = A.order[blockIdx.x];
     uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
     int32_t *hdr = (int32_t *)(ws + A.L.hdr);
     const int N = hdr[0];
@@ -1525,21 +1516,33 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
             depth[i] = depth[i - 1] + 1;
             maxd = std::max(maxd, (int)depth[i]);
         }
-    if ((rc = h->tail_ws.ensure((size_t)L.total * n + 8 * (size_t)DEPTH_SLOT))) return rc;
     if (n > DEPTH_SLOT) { svc_set_error("svc_cluster_center: more than %d maps per call", DEPTH_SLOT); return SVC_E_INVALID; }
-    // the per-map round numbers travel through a small ring of pinned host slots so that the upload is
-    // asynchronous (up to 8 calls may be in flight on the stream before a slot is reused)
-    if (!h->depth_pinned) SVC_HIP(hipHostMalloc((void **)&h->depth_pinned, 8 * (size_t)DEPTH_SLOT, hipHostMallocDefault));
+    // A round's kernels are launched over the maps of THAT round only: the list of all maps sorted by round (stable),
+    // one slice per round.  (One workgroup per map of the call in every round -- 31 of 32 exiting at once in the
+    // follower rounds -- still has each of them claim a whole CU's wave slots / up to 154 KB of LDS before it can exit:
+    // in the pipelined run those claims keep the network's workgroups off the CUs.)
+    std::vector<uint16_t> order(n);
+    std::vector<int> round_start(maxd + 2, 0);
+    for (int i = 0; i < n; ++i) ++round_start[depth[i] + 1];
+    for (int r = 0; r <= maxd; ++r) round_start[r + 1] += round_start[r];
+    {
+        std::vector<int> fill(round_start.begin(), round_start.end() - 1);
+        for (int i = 0; i < n; ++i) order[fill[depth[i]]++] = (uint16_t)i;
+    }
+    if ((rc = h->tail_ws.ensure((size_t)L.total * n + 8 * 2 * (size_t)DEPTH_SLOT))) return rc;
+    // the list travels through a small ring of pinned host slots so that the upload is asynchronous (up to 8 calls may
+    // be in flight on the stream before a slot is reused)
+    if (!h->depth_pinned) SVC_HIP(hipHostMalloc((void **)&h->depth_pinned, 8 * 2 * (size_t)DEPTH_SLOT, hipHostMallocDefault));
     const int slot = h->depth_slot++ & 7;
     if (h->depth_ev[slot]) SVC_HIP(hipEventSynchronize(h->depth_ev[slot]));      // the upload that last used this slot has run
     else SVC_HIP(hipEventCreateWithFlags(&h->depth_ev[slot], hipEventDisableTiming));
-    uint8_t *depth_dev = (uint8_t *)h->tail_ws.p + (size_t)L.total * n + (size_t)slot * DEPTH_SLOT;
-    memcpy(h->depth_pinned + (size_t)slot * DEPTH_SLOT, depth.data(), n);
-    SVC_HIP(hipMemcpyAsync(depth_dev, h->depth_pinned + (size_t)slot * DEPTH_SLOT, n, hipMemcpyHostToDevice, s));
+    uint16_t *order_dev = (uint16_t *)((uint8_t *)h->tail_ws.p + (size_t)L.total * n + (size_t)slot * 2 * DEPTH_SLOT);
+    memcpy(h->depth_pinned + (size_t)slot * 2 * DEPTH_SLOT, order.data(), (size_t)n * 2);
+    SVC_HIP(hipMemcpyAsync(order_dev, h->depth_pinned + (size_t)slot * 2 * DEPTH_SLOT, (size_t)n * 2, hipMemcpyHostToDevice, s));
     SVC_HIP(hipEventRecord(h->depth_ev[slot], s));
     h->tail_frames = n; h->tail_h = height; h->tail_w = width; h->tail_frame_stride = L.total;
     TailArgs A;
-    A.maps = maps; A.ws = (uint8_t *)h->tail_ws.p; A.ws_stride = L.total; A.depth = depth_dev; A.round = 0;
+    A.maps = maps; A.ws = (uint8_t *)h->tail_ws.p; A.ws_stride = L.total; A.order = order_dev;
     A.n = n; A.h = height; A.w = width; A.dW = make_fdiv(width);
     A.mcs = params->hdbscan_min; A.min_samples = params->hdbscan_min_samples; A.select_sum = params->select_sum;
     A.op_close = params->op_close; A.clust_filt = params->clust_filt;
@@ -1561,45 +1564,45 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
         SVC_HIP(hipFuncSetAttribute((const void *)k_sort, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_BYTES));
     }
     for (int r = 0; r <= maxd; ++r) {
-        A.round = r;
+        const int m = round_start[r + 1] - round_start[r];   // maps of this round
+        const uint16_t *ord = order_dev + round_start[r];
+        A.order = ord;
         if (r > 0) {
-            k_blend<<<dim3(8, n), 256, 0, s>>>(full_maps, depth_dev, r, full_h * full_w);
+            k_blend<<<dim3(8, m), 256, 0, s>>>(full_maps, ord, full_h * full_w);
             SVC_CHECK_LAUNCH();
         }
         if (factor > 1) {
-            k_map_resize<<<dim3(8, n), 256, 0, s>>>(full_maps, maps, rs_down, depth_dev, r, full_h, full_w,
-                                                    height, width);
+            k_map_resize<<<dim3(8, m), 256, 0, s>>>(full_maps, maps, rs_down, ord, full_h, full_w, height, width);
             SVC_CHECK_LAUNCH();
         }
         {
             ProfScope ps(h, SVC_K_COMPACT, s);
-            k_compact<<<n, TB, (size_t)(hw + 15) / 16 * 16, s>>>(A);
+            k_compact<<<m, TB, (size_t)(hw + 15) / 16 * 16, s>>>(A);
             SVC_CHECK_LAUNCH();
         }
         if (params->clust_filt) {
             {
                 ProfScope ps(h, SVC_K_CORE, s);
-                k_core<<<n, TB, lds_core, s>>>(A);
+                k_core<<<m, TB, lds_core, s>>>(A);
                 SVC_CHECK_LAUNCH();
             }
             ProfScope ps(h, SVC_K_PRIM, s);
-            k_prim<<<n, TB, lds_prim, s>>>(A);
+            k_prim<<<m, TB, lds_prim, s>>>(A);
             SVC_CHECK_LAUNCH();
         }
         {
             ProfScope ps(h, SVC_K_FINISH, s);
             if (params->clust_filt) {
-                k_sort<<<n, TB, SORT_LDS_BYTES, s>>>(A);
+                k_sort<<<m, TB, SORT_LDS_BYTES, s>>>(A);
                 SVC_CHECK_LAUNCH();
-                k_tree<<<n, 64, FIN_LDS_BYTES, s>>>(A);
+                k_tree<<<m, 64, FIN_LDS_BYTES, s>>>(A);
                 SVC_CHECK_LAUNCH();
             }
-            k_finish<<<n, TB, lds_fin, s>>>(A);
+            k_finish<<<m, TB, lds_fin, s>>>(A);
             SVC_CHECK_LAUNCH();
         }
         if (factor > 1) {
-            k_map_resize<<<dim3(16, n), 256, 0, s>>>(maps, full_maps, rs_up, depth_dev, r, height, width,
-                                                     full_h, full_w);
+            k_map_resize<<<dim3(16, m), 256, 0, s>>>(maps, full_maps, rs_up, ord, height, width, full_h, full_w);
             SVC_CHECK_LAUNCH();
         }
     }

@@ -245,7 +245,30 @@ def main():
     slots = [Slot() for _ in range(P)]
     torch.cuda.synchronize()
 
+    MAXNET = int(os.environ.get('BENCH_MAX_NET', '0'))       # experiment: > 0 = dynamic slot choice, at most this many batches in their network phase
+
+    def run_dynamic(steps):
+        boxes = None
+        for s in range(steps):
+            while True:
+                free = [sl for sl in slots if not sl.pending]
+                nets = sum(1 for sl in slots if sl.pending and not sl.net_done.query())
+                if free and nets < MAXNET:
+                    break
+                for sl in slots:
+                    if sl.pending and sl.done.query():
+                        boxes = sl.finish()
+            t0 = time.perf_counter()
+            free[0].enqueue()
+            host_t['enqueue'] += time.perf_counter() - t0
+        for sl in slots:
+            if sl.pending:
+                boxes = sl.finish()
+        return boxes
+
     def run(steps):
+        if MAXNET > 0:
+            return run_dynamic(steps)
         boxes = None
         for s in range(steps):
             sl = slots[s % P]

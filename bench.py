@@ -175,7 +175,6 @@ def main():
 
     B = args.batch
     P = max(1, args.pipeline)
-    TAIL_CUS = int(os.environ.get('BENCH_TAIL_CUS', '0'))          # 0: one stream per batch; 32 / 64: the tail on a CU-masked stream
     sd = weights.make_synthetic_state_dict(0)
     CP = S.sc_init_crop_params()
     CP['out_ratio'] = '1:3'
@@ -188,25 +187,12 @@ def main():
     spans = {'net': 0.0, 'tail': 0.0, 'n': 0}                  # device milliseconds of a batch's two phases (HIP events on its stream)
     host_t = {'wait': 0.0, 'boxes': 0.0, 'enqueue': 0.0}      # host seconds: waiting for a batch, boxes on the host, enqueueing a batch
 
-    tail_pool, slots_made = [], []
-
     class Slot:
         """One in-flight step: its own engine (weights + workspace), HIP stream and pinned result buffer,
         so the low-occupancy clustering tail of one batch overlaps the network of the next."""
         def __init__(self):
             self.eng = ops.Engine(sd)
             self.stream = torch.cuda.Stream(device=dev)
-            # the clustering tail on a stream of its own, confined to TAIL_CUS compute units: its long single-workgroup
-            # kernels then neither wait behind the next batch's network in the same queue nor slow the network's
-            # workgroups on the CUs they would otherwise share with them
-            self.masked = ops.MaskedStream(ops.tail_cu_mask(TAIL_CUS), device=dev.index or 0) if TAIL_CUS > 0 else None
-            if TAIL_CUS < 0:                                  # plain second stream: one of -TAIL_CUS shared tail streams
-                while len(tail_pool) < -TAIL_CUS:
-                    tail_pool.append(torch.cuda.Stream(device=dev))
-                self.tail_stream = tail_pool[len(slots_made) % len(tail_pool)]
-            else:
-                self.tail_stream = self.masked.stream if self.masked else self.stream
-            slots_made.append(self)
             self.xy_host = torch.empty((B, 2), dtype=torch.float64).pin_memory()
             self.maps = torch.empty((B, 140, 250), dtype=torch.uint8, device=dev)
             self.net_done = torch.cuda.Event(enable_timing=True)
@@ -221,12 +207,9 @@ def main():
                 maps = self.eng.saliency(small, out=self.maps)
                 self.eng.threshold_(maps, CP['t_threshold'])
                 self.net_done.record(self.stream)
-            with torch.cuda.stream(self.tail_stream):
-                if self.tail_stream is not self.stream:
-                    self.tail_stream.wait_event(self.net_done)
                 xy = self.eng.cluster_center_(maps, flags, CP)
                 self.xy_host.copy_(xy, non_blocking=True)
-                self.done.record(self.tail_stream)
+                self.done.record(self.stream)
             self.pending = True
 
         def finish(self):
@@ -245,30 +228,7 @@ def main():
     slots = [Slot() for _ in range(P)]
     torch.cuda.synchronize()
 
-    MAXNET = int(os.environ.get('BENCH_MAX_NET', '0'))       # experiment: > 0 = dynamic slot choice, at most this many batches in their network phase
-
-    def run_dynamic(steps):
-        boxes = None
-        for s in range(steps):
-            while True:
-                free = [sl for sl in slots if not sl.pending]
-                nets = sum(1 for sl in slots if sl.pending and not sl.net_done.query())
-                if free and nets < MAXNET:
-                    break
-                for sl in slots:
-                    if sl.pending and sl.done.query():
-                        boxes = sl.finish()
-            t0 = time.perf_counter()
-            free[0].enqueue()
-            host_t['enqueue'] += time.perf_counter() - t0
-        for sl in slots:
-            if sl.pending:
-                boxes = sl.finish()
-        return boxes
-
     def run(steps):
-        if MAXNET > 0:
-            return run_dynamic(steps)
         boxes = None
         for s in range(steps):
             sl = slots[s % P]

@@ -141,13 +141,6 @@ int svc_debug_cluster_state(SvcHandle *h, int frame, int cap, uint32_t *pts_host
  * Returns n (or a negative error). */
 int svc_debug_argsort_u32(SvcHandle *h, const uint32_t *keys_host, int n, int32_t *order_host);
 
-/* A HIP stream restricted to a subset of the compute units (hipExtStreamCreateWithCUMask): cu_mask = n_words x 32 bits,
- * bit i = CU i enabled.  The clustering tail is a handful of long-running single-workgroup kernels; confined to a few
- * CUs of its own it stops slowing the full-chip network kernels of the batches behind it (bench.py).
- * The caller owns the stream: svc_stream_destroy when done.  No reference counterpart (the reference has one CUDA stream). */
-int svc_stream_create_cu_mask(int device, const uint32_t *cu_mask, int n_words, void **stream_out);
-int svc_stream_destroy(void *stream);
-
 /* Test/diagnostic door: copy an intermediate activation of the LAST svc_saliency_u8
  * call (NHWC fp32, frame 0..n-1) to a HOST buffer.  `which` is one of the SVC_TAP_*
  * ids.  Returns the number of floats per frame (or a negative error).  Synchronises. */

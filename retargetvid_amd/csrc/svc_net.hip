@@ -2741,23 +2741,6 @@ extern "C" int svc_debug_tap(SvcHandle *h, int which, int frame, float *out_host
     return (int)count;
 }
 
-extern "C" int svc_stream_create_cu_mask(int device, const uint32_t *cu_mask, int n_words, void **stream_out) {
-    if (!cu_mask || n_words < 1 || !stream_out) { svc_set_error("svc_stream_create_cu_mask: invalid argument"); return SVC_E_INVALID; }
-    bool any = false;
-    for (int i = 0; i < n_words; ++i) any = any || cu_mask[i] != 0;
-    if (!any) { svc_set_error("svc_stream_create_cu_mask: empty mask"); return SVC_E_INVALID; }
-    SVC_HIP(hipSetDevice(device));
-    hipStream_t s = nullptr;
-    SVC_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask));
-    *stream_out = (void *)s;
-    return SVC_OK;
-}
-extern "C" int svc_stream_destroy(void *stream) {
-    if (!stream) return SVC_OK;
-    SVC_HIP(hipStreamDestroy((hipStream_t)stream));
-    return SVC_OK;
-}
-
 extern "C" int svc_front_fused(const SvcHandle *h) { return h && h->plan && h->plan->last_front ? 1 : 0; }
 
 // --------------------------------------------------------------------------------------

@@ -27,34 +27,6 @@ def _need_cuda(t, dtype, name):
         raise TypeError('%s must be a contiguous CUDA tensor of dtype %s' % (name, dtype))
 
 
-def tail_cu_mask(n_cus=32, total=256):
-    """A CU mask of n_cus (32 or 64) compute units that is balanced over the 8 XCDs whether the driver reads the mask
-    bits XCD-major (bit = 32 xcd + cu) or interleaved (bit = 8 cu + xcd): per 32-bit word k the bits {0, 9, 18, 27}
-    (even k) / {4, 13, 22, 31} (odd k), or all eight for 64."""
-    a, b = (1 << 0) | (1 << 9) | (1 << 18) | (1 << 27), (1 << 4) | (1 << 13) | (1 << 22) | (1 << 31)
-    words = []
-    for k in range(total // 32):
-        words.append((a | b) if n_cus >= 64 else (a if k % 2 == 0 else b))
-    return np.array(words, np.uint32)
-
-
-class MaskedStream:
-    """A HIP stream confined to the CUs of `mask` (svc_stream_create_cu_mask), usable as a torch stream."""
-    def __init__(self, mask, device=0):
-        lib = _lib.load()
-        mask = np.ascontiguousarray(mask, np.uint32)
-        ptr = ctypes.c_void_p()
-        _lib.check(lib.svc_stream_create_cu_mask(int(device), mask.ctypes.data_as(ctypes.c_void_p), mask.size, ctypes.byref(ptr)))
-        self._lib, self.ptr = lib, ptr.value
-        self.stream = torch.cuda.ExternalStream(self.ptr, device=device)
-
-    def close(self):
-        if self.ptr:
-            self.stream.synchronize()
-            _lib.check(self._lib.svc_stream_destroy(ctypes.c_void_p(self.ptr)))
-            self.ptr = None
-
-
 class Engine:
     """Owns one SvcHandle (weights + workspace) on one GPU.  Replaces the reference's module-level
     ``unisal_model`` singleton (smartVidCrop.py:77).  Not re-entrant, like the reference."""

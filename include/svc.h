@@ -141,6 +141,18 @@ int svc_debug_cluster_state(SvcHandle *h, int frame, int cap, uint32_t *pts_host
  * Returns n (or a negative error). */
 int svc_debug_argsort_u32(SvcHandle *h, const uint32_t *keys_host, int n, int32_t *order_host);
 
+/* ---- TransNet V1 shot-boundary network ----
+ * Replaces ShotTransNet._restore / predict_raw (3rd_party_libs/transnetv1/transnetv1_handler.py:86-97; the reference
+ * calls it through predict_frames at smartVidCrop.py:369).
+ * svc_transnet_load: the F16 L3 S2 D256 weights as ONE float32 array in the layout of
+ *   retargetvid_amd/weights.pack_transnet_blob (per DDCNN cell four [rows][27 taps x channels] GEMM matrices + biases,
+ *   Dense(256) and Dense(2) transposed); n_floats is checked.
+ * svc_transnet_predict: frames = DEVICE uint8 [n_windows][frames_per_window][27][48][3] (RGB, already 48x27),
+ *   probs = DEVICE float32 [n_windows][frames_per_window] = P(transition) of every frame (softmax class 1).
+ *   Windowing of a video (100-frame windows, stride 50, edge padding) is host logic: transnetv1_handler.predict_video. */
+int svc_transnet_load(SvcHandle *h, const float *blob_host, size_t n_floats);
+int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_windows, int frames_per_window, float *probs, void *stream);
+
 /* Test/diagnostic door: copy an intermediate activation of the LAST svc_saliency_u8
  * call (NHWC fp32, frame 0..n-1) to a HOST buffer.  `which` is one of the SVC_TAP_*
  * ids.  Returns the number of floats per frame (or a negative error).  Synchronises. */

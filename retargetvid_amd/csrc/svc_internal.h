@@ -141,6 +141,9 @@ struct SvcHandle {
     int dwpw_min_px = 400;             // ... on levels with at least this many pixels per frame; the 8x13 level has too few patches (SVC_DWPW_MIN_PX)
     int dw_tile = 42;                  // stride-1 depthwise: outputs per thread as TX*10+TY (SVC_DW_TILE: 21, 22, 41, 42, 44; 0 = one output per thread)
     int prim_pt = 2;                   // k_prim: smallest points-per-thread variant (SVC_PRIM_PT: 2, 4, 8, 16)
+    // TransNet V1 (svc_shot.hip)
+    DevBuf shot_blob, shot_ws;
+    bool shot_loaded = false;
     // per-kernel-class event log (svc_profile_*)
     int prof_class = -1;
     hipStream_t prof_stream = nullptr;          // stream of the last recorded launch (the empty-pair calibration of svc_profile_read runs on it)

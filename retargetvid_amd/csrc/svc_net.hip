@@ -2960,6 +2960,8 @@ extern "C" int svc_destroy(SvcHandle *h) {
     h->tail_offsets.release();
     for (auto &kv : h->tail_delta) kv.second.release();
     h->stem_wt.release();
+    h->shot_blob.release();
+    h->shot_ws.release();
     h->rs_maps.release();
     for (auto &kv : h->rs_tabs) { kv.second.first.release(); kv.second.second.release(); }
     for (auto &e : h->depth_ev) if (e) (void)hipEventDestroy(e);

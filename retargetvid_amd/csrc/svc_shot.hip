@@ -1,0 +1,246 @@
+// svc_shot.hip — TransNet V1 (shot-boundary network) forward for gfx950.
+//
+// Reference: 3rd_party_libs/transnetv1/transnetv1_handler.py:25-97 (TensorFlow 1.x graph): uint8 frames [B, T, 27, 48, 3]
+// / 255 -> three blocks of two DDCNN cells (a cell = four Conv3D 3x3x3 with temporal dilation 1, 2, 4, 8 on the same
+// input, bias, ReLU, concatenated) with a (1, 2, 2) max-pool after each block -> flatten -> Dense 256 ReLU -> Dense 2 ->
+// softmax[:, :, 1].  The CPU restatement the tests compare with is oracle/transnet_ref.py.
+//
+// Layout: NDHWC fp32 (a frame position's channels contiguous), so a 3x3x3 convolution is 27 shifted 1x1 convolutions
+// accumulated into one MFMA tile: k_shot_conv is an implicit GEMM [positions x 27 C] . [27 C x filters] on
+// v_mfma_f32_32x32x2_f32 (exact fp32 products) with the operands the way round the network kernels use them (weights as
+// A, positions as B: a lane ends with 16 channels of ONE position in runs of four -> bias, ReLU, float4 stores).  The four
+// dilations of a cell are the y dimension of one launch and write disjoint channel ranges of the cell's output.
+// Dense(256) is the same kernel with one tap over the 4608 flattened inputs.
+#include <algorithm>
+
+#include "svc_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define SHOT_H 27
+#define SHOT_W 48
+#define SHOT_F 16
+#define SHOT_L 3
+#define SHOT_S 2
+#define SHOT_D 256
+
+// uint8 [n][27][48][3] -> float [n][27][48][4] = v / 255 (tf.cast(float32) / 255.), fourth channel 0
+__global__ __launch_bounds__(256) void k_shot_in(const uint8_t *__restrict__ in, float *__restrict__ out, size_t npix) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const uint8_t *p = in + i * 3;
+    *(float4 *)(out + i * 4) = make_float4((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, 0.f);
+}
+
+struct ShotConv {
+    const float *X;         // [B][T][H][W][C]
+    const float *Wt;        // [branches][Fpad][kpad]: rows = output channel, k = tap * C + channel
+    const float *bias;      // [branches * F]
+    float *Y;               // [B][T][H][W][ldy], a branch writes channels br * F ..
+    long long M;            // positions = B * T * H * W
+    int T, H, W, C, logC;   // C = 1 << logC for the 27-tap form
+    int F, Fpad, kpad, ntaps, ldy, relu;
+};
+
+__global__ __launch_bounds__(256) void k_shot_conv(const ShotConv A) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const long long m = std::min((long long)blockIdx.x * 128 + wave * 32 + r, A.M - 1);
+    const int tiles = A.Fpad >> 5, br = blockIdx.y / tiles, nt = blockIdx.y - br * tiles;
+    const int d = 1 << br;                                   // temporal dilation of this branch: 1, 2, 4, 8
+    // position of this lane
+    const int x = (int)(m % A.W);
+    long long q = m / A.W;
+    const int y = (int)(q % A.H);
+    q /= A.H;
+    const int t = (int)(q % A.T);
+    const long long frame0 = q - t;                          // first frame of this position's window
+    const float *wrow = A.Wt + ((size_t)br * A.Fpad + nt * 32 + r) * A.kpad + 4 * hh;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if (A.ntaps == 1) {                                      // Dense: one tap, the position's own row of C inputs
+        const float *xp = A.X + (size_t)m * A.C + 4 * hh;
+        for (int kk = 0; kk < A.kpad; kk += 8) {
+            const float4 a = *(const float4 *)(xp + kk);
+            const float4 b = *(const float4 *)(wrow + kk);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
+        }
+    } else {
+        for (int kk = 0; kk < A.kpad; kk += 8) {
+            const int k0 = kk + 4 * hh, tap = k0 >> A.logC, c0 = k0 & (A.C - 1);
+            const int kt = tap / 9, kh = (tap - 9 * kt) / 3, kw = tap - 9 * kt - 3 * kh;
+            const int tt = t + (kt - 1) * d, yy = y + kh - 1, xx = x + kw - 1;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);     // SAME padding: zeros outside the window / the frame
+            if (tap < 27 && (unsigned)tt < (unsigned)A.T && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W)
+                a = *(const float4 *)(A.X + ((((size_t)(frame0 + tt)) * A.H + yy) * A.W + xx) * A.C + c0);
+            const float4 b = *(const float4 *)(wrow + kk);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
+        }
+    }
+    if ((long long)blockIdx.x * 128 + wave * 32 + r >= A.M) return;
+    float *yp = A.Y + (size_t)m * A.ldy + br * A.F;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int col = nt * 32 + 8 * g + 4 * hh;
+        if (col >= A.F) continue;
+        const float4 b = *(const float4 *)(A.bias + br * A.F + col);
+        float4 v = make_float4(acc[4 * g] + b.x, acc[4 * g + 1] + b.y, acc[4 * g + 2] + b.z, acc[4 * g + 3] + b.w);
+        if (A.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *(float4 *)(yp + col) = v;
+    }
+}
+
+// MaxPool3D (1, 2, 2), VALID: [n][H][W][C] -> [n][H/2][W/2][C]
+__global__ __launch_bounds__(256) void k_shot_pool(const float *__restrict__ X, float *__restrict__ Y, size_t total, int H, int W,
+                                                   int C4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int OH = H / 2, OW = W / 2;
+    const int c = (int)(i % C4);
+    size_t q = i / C4;
+    const int ox = (int)(q % OW);
+    q /= OW;
+    const int oy = (int)(q % OH);
+    const size_t f = q / OH;
+    const float4 *p = (const float4 *)X + ((f * H + 2 * oy) * W + 2 * ox) * C4 + c;
+    const float4 a = p[0], b = p[C4], e = p[(size_t)W * C4], g = p[(size_t)W * C4 + C4];
+    float4 v;
+    v.x = fmaxf(fmaxf(a.x, b.x), fmaxf(e.x, g.x));
+    v.y = fmaxf(fmaxf(a.y, b.y), fmaxf(e.y, g.y));
+    v.z = fmaxf(fmaxf(a.z, b.z), fmaxf(e.z, g.z));
+    v.w = fmaxf(fmaxf(a.w, b.w), fmaxf(e.w, g.w));
+    ((float4 *)Y)[i] = v;
+}
+
+// Dense(2) + softmax, class 1: one wavefront per frame
+__global__ __launch_bounds__(64) void k_shot_head(const float *__restrict__ X, const float *__restrict__ W2, const float *__restrict__ b2,
+                                                  float *__restrict__ prob, int rows) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    if (row >= rows) return;
+    const float4 xv = *(const float4 *)(X + (size_t)row * SHOT_D + lane * 4);
+    const float4 w0 = *(const float4 *)(W2 + lane * 4), w1 = *(const float4 *)(W2 + SHOT_D + lane * 4);
+    float s0 = xv.x * w0.x + xv.y * w0.y + xv.z * w0.z + xv.w * w0.w;
+    float s1 = xv.x * w1.x + xv.y * w1.y + xv.z * w1.z + xv.w * w1.w;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+    if (lane == 0) {
+        const float l0 = s0 + b2[0], l1 = s1 + b2[1], mx = fmaxf(l0, l1);
+        const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+        prob[row] = e1 / (e0 + e1);
+    }
+}
+
+// ---- host -------------------------------------------------------------------------------------------------------------
+struct ShotCell { int cin, cpad, f, fpad, kpad; size_t w_off, b_off; };
+
+static size_t shot_layout(ShotCell cells[SHOT_L * SHOT_S], size_t *d1w, size_t *d1b, size_t *d2w, size_t *d2b) {
+    size_t o = 0;
+    int cin = 3;
+    for (int b = 0; b < SHOT_L; ++b)
+        for (int c = 0; c < SHOT_S; ++c) {
+            ShotCell &k = cells[b * SHOT_S + c];
+            k.cin = cin; k.cpad = std::max(4, cin); k.f = SHOT_F << b; k.fpad = (k.f + 31) / 32 * 32;
+            k.kpad = (27 * k.cpad + 7) / 8 * 8;
+            k.w_off = o; o += (size_t)4 * k.fpad * k.kpad;
+            k.b_off = o; o += (size_t)4 * k.f;
+            cin = 4 * k.f;
+        }
+    const size_t nflat = (size_t)3 * 6 * 4 * (SHOT_F << (SHOT_L - 1));
+    *d1w = o; o += (size_t)SHOT_D * nflat;
+    *d1b = o; o += SHOT_D;
+    *d2w = o; o += 2 * SHOT_D;
+    *d2b = o; o += 2;
+    return o;
+}
+
+extern "C" int svc_transnet_load(SvcHandle *h, const float *blob_host, size_t n_floats) {
+    if (!h || !blob_host) { svc_set_error("svc_transnet_load: invalid argument"); return SVC_E_INVALID; }
+    ShotCell cells[SHOT_L * SHOT_S];
+    size_t a, b, c, d;
+    // the packed layout keeps kpad == 27 * cpad except for the first cell (108 -> 112): the packer pads rows itself
+    const size_t need = shot_layout(cells, &a, &b, &c, &d);
+    if (n_floats != need) {
+        svc_set_error("svc_transnet_load: blob has %zu floats, the F16 L3 S2 D256 network needs %zu", n_floats, need);
+        return SVC_E_INVALID;
+    }
+    SVC_HIP(hipSetDevice(h->device));
+    int rc = h->shot_blob.ensure(need * sizeof(float));
+    if (rc) return rc;
+    SVC_HIP(hipMemcpy(h->shot_blob.p, blob_host, need * sizeof(float), hipMemcpyHostToDevice));
+    h->shot_loaded = true;
+    return SVC_OK;
+}
+
+extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_windows, int frames_per_window, float *probs,
+                                    void *stream) {
+    if (!h || n_windows < 0 || frames_per_window < 1 || (n_windows > 0 && (!frames || !probs))) {
+        svc_set_error("svc_transnet_predict: invalid argument");
+        return SVC_E_INVALID;
+    }
+    if (!h->shot_loaded) { svc_set_error("svc_transnet_predict: no weights (svc_transnet_load)"); return SVC_E_INVALID; }
+    if (n_windows == 0) return SVC_OK;
+    SVC_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    ShotCell cells[SHOT_L * SHOT_S];
+    size_t d1w, d1b, d2w, d2b;
+    shot_layout(cells, &d1w, &d1b, &d2w, &d2b);
+    const float *blob = (const float *)h->shot_blob.p;
+    const int T = frames_per_window;
+    // windows per pass: two ping-pong activation buffers of T x 27 x 48 x 64 floats per window (the largest tensor)
+    const size_t per_win = (size_t)T * SHOT_H * SHOT_W * 64;
+    const int chunk = std::max(1, std::min(n_windows, (int)(((size_t)768 << 20) / (2 * per_win * sizeof(float)))));
+    int rc = h->shot_ws.ensure(2 * per_win * chunk * sizeof(float));
+    if (rc) return rc;
+    float *P[2] = {(float *)h->shot_ws.p, (float *)h->shot_ws.p + per_win * chunk};
+    for (int w0 = 0; w0 < n_windows; w0 += chunk) {
+        const int nw = std::min(chunk, n_windows - w0);
+        const size_t nfr = (size_t)nw * T;
+        int H = SHOT_H, W = SHOT_W, cur = 0;
+        {
+            const size_t npix = nfr * H * W;
+            k_shot_in<<<(unsigned)((npix + 255) / 256), 256, 0, s>>>(frames + (size_t)w0 * T * H * W * 3, P[0], npix);
+            SVC_CHECK_LAUNCH();
+        }
+        for (int b = 0; b < SHOT_L; ++b) {
+            for (int c = 0; c < SHOT_S; ++c) {
+                const ShotCell &k = cells[b * SHOT_S + c];
+                ShotConv A;
+                A.X = P[cur]; A.Wt = blob + k.w_off; A.bias = blob + k.b_off; A.Y = P[cur ^ 1];
+                A.M = (long long)nfr * H * W; A.T = T; A.H = H; A.W = W; A.C = k.cpad;
+                A.logC = 0;
+                while ((1 << A.logC) < k.cpad) ++A.logC;
+                A.F = k.f; A.Fpad = k.fpad; A.kpad = k.kpad; A.ntaps = 27; A.ldy = 4 * k.f; A.relu = 1;
+                dim3 grid((unsigned)((A.M + 127) / 128), (unsigned)(4 * (k.fpad / 32)));
+                k_shot_conv<<<grid, 256, 0, s>>>(A);
+                SVC_CHECK_LAUNCH();
+                cur ^= 1;
+            }
+            const int C = 4 * (SHOT_F << b);
+            const size_t total = nfr * (H / 2) * (W / 2) * (C / 4);
+            k_shot_pool<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(P[cur], P[cur ^ 1], total, H, W, C / 4);
+            SVC_CHECK_LAUNCH();
+            cur ^= 1;
+            H /= 2; W /= 2;
+        }
+        {
+            ShotConv A;
+            const int nflat = H * W * 4 * (SHOT_F << (SHOT_L - 1));
+            A.X = P[cur]; A.Wt = blob + d1w; A.bias = blob + d1b; A.Y = P[cur ^ 1];
+            A.M = (long long)nfr; A.T = 1; A.H = 1; A.W = 1; A.C = nflat; A.logC = 0;
+            A.F = SHOT_D; A.Fpad = SHOT_D; A.kpad = nflat; A.ntaps = 1; A.ldy = SHOT_D; A.relu = 1;
+            dim3 grid((unsigned)((A.M + 127) / 128), (unsigned)(SHOT_D / 32));
+            k_shot_conv<<<grid, 256, 0, s>>>(A);
+            SVC_CHECK_LAUNCH();
+            cur ^= 1;
+            k_shot_head<<<(unsigned)nfr, 64, 0, s>>>(P[cur], blob + d2w, blob + d2b, probs + (size_t)w0 * T, (int)nfr);
+            SVC_CHECK_LAUNCH();
+        }
+    }
+    return SVC_OK;
+}

@@ -1,0 +1,169 @@
+"""TransNet V1 shot-boundary detection on the device -- the counterpart of the reference's
+3rd_party_libs/transnetv1/transnetv1_handler.py (same names, argument meaning and return values):
+
+  ShotTransNetParams                  :8-15    (F, L, S, D, INPUT_WIDTH, INPUT_HEIGHT, CHECKPOINT_PATH)
+  ShotTransNet(params, ...)           :17-24   the network; here `weights=` takes the TensorFlow-layout arrays
+      .predict_raw(frames)            :93-97   [batch, frames, 27, 48, 3] uint8 -> [batch, frames] P(transition)
+      .predict_frames(frames)         :99-100
+      .predict_video(frames)          :102-130 100-frame windows, stride 50, edge frames repeated
+  shot_preprocess_frame(s)(_list)     :133-150 cv2.resize to 48 x 27 (here: the library's OpenCV-exact down-scale)
+  shots_from_predictions, assert_segmentation  :232-262
+  scenes_from_predictions             transnet_utils.py:5-19;  predictions_to_scenes  smartVidCrop.py:214-230
+
+The forward pass is hand-written HIP behind the C ABI (svc_transnet_load / svc_transnet_predict, csrc/svc_shot.hip); there
+is no CPU fallback.  The reference restores a TensorFlow checkpoint that does not ship with it (note.txt:1) and that
+this build cannot read (no TensorFlow): pass `weights=` (weights.make_transnet_state_dict for the synthetic network of the
+tests, or arrays exported from the checkpoint under the reference's variable names)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, ops, weights as _weights
+
+
+class ShotTransNetParams:
+    F = 16
+    L = 3
+    S = 2
+    D = 256
+    INPUT_WIDTH = 48
+    INPUT_HEIGHT = 27
+    CHECKPOINT_PATH = None
+
+
+class ShotTransNet:
+    def __init__(self, params=None, session=None, weights=None, engine=None, windows_per_call=8):
+        self.params = params or ShotTransNetParams()
+        p = self.params
+        if (p.F, p.L, p.S, p.D, p.INPUT_WIDTH, p.INPUT_HEIGHT) != (16, 3, 2, 256, 48, 27):
+            raise ValueError('only the F16 L3 S2 D256 network on 48x27 frames (the reference\'s configuration) is built')
+        if weights is None:
+            raise ValueError('ShotTransNet needs weights= (TensorFlow-layout arrays under the reference\'s variable names): the '
+                             'checkpoint %r cannot be read without TensorFlow' % (p.CHECKPOINT_PATH,))
+        self._own = engine is None
+        self.eng = engine or ops.Engine(seed=0)
+        self.windows_per_call = int(windows_per_call)
+        blob = np.ascontiguousarray(_weights.pack_transnet_blob(weights), np.float32)
+        _lib.check(self.eng.lib.svc_transnet_load(self.eng._h, blob.ctypes.data_as(ctypes.c_void_p), blob.size))
+
+    def close(self):
+        if self._own and self.eng is not None:
+            self.eng.close()
+        self.eng = None
+
+    # -- the reference's methods --------------------------------------------------------------------------------
+    def predict_raw_device(self, frames):
+        """CUDA uint8 [batch, frames, 27, 48, 3] -> CUDA float32 [batch, frames]."""
+        if not (torch.is_tensor(frames) and frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous()):
+            raise TypeError('frames must be a contiguous CUDA uint8 tensor')
+        assert frames.dim() == 5 and tuple(frames.shape[2:]) == (self.params.INPUT_HEIGHT, self.params.INPUT_WIDTH, 3), \
+            ' [ShotTransNet] Input shape must be [batch, frames, height, width, 3].'
+        nb, nt = int(frames.shape[0]), int(frames.shape[1])
+        out = torch.empty((nb, nt), dtype=torch.float32, device=frames.device)
+        _lib.check(self.eng.lib.svc_transnet_predict(self.eng._h, ctypes.c_void_p(frames.data_ptr()), nb, nt,
+                                                     ctypes.c_void_p(out.data_ptr()),
+                                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out
+
+    def predict_raw(self, frames):
+        dev = torch.device('cuda', torch.cuda.current_device())
+        t = frames if torch.is_tensor(frames) else torch.from_numpy(np.ascontiguousarray(frames, np.uint8))
+        return self.predict_raw_device(t.to(dev).contiguous()).cpu().numpy()
+
+    def predict_frames(self, frames):
+        return self.predict_video(frames)
+
+    def predict_video(self, frames):
+        """[frames, 27, 48, 3] uint8 (NumPy or CUDA tensor) -> NumPy float32 [frames]."""
+        assert len(frames.shape) == 4 and tuple(frames.shape[1:]) == (self.params.INPUT_HEIGHT, self.params.INPUT_WIDTH, 3), \
+            ' [ShotTransNet] Input shape must be [frames, height, width, 3].'
+        dev = torch.device('cuda', torch.cuda.current_device())
+        t = frames if torch.is_tensor(frames) else torch.from_numpy(np.ascontiguousarray(frames, np.uint8))
+        t = t.to(dev).contiguous()
+        n = int(t.shape[0])
+        wi = torch.from_numpy(window_indices(n)).to(dev)
+        res = []
+        for i in range(0, len(wi), self.windows_per_call):
+            win = t[wi[i:i + self.windows_per_call].reshape(-1)].reshape(-1, 100, *t.shape[1:]).contiguous()
+            res.append(self.predict_raw_device(win)[:, 25:75].reshape(-1))
+        return torch.cat(res)[:n].cpu().numpy()
+
+
+def window_indices(n):
+    """Frame index of every slot of every window: windows of 100 where the first / last 25 frames belong to the previous /
+    next window; 25 copies of the first frame in front, 25 + 50 - (n % 50 or 50) copies of the last behind (:104-121)."""
+    pad_end = 25 + 50 - (n % 50 if n % 50 != 0 else 50)
+    idx = np.concatenate([np.zeros(25, np.int64), np.arange(n, dtype=np.int64), np.full(pad_end, n - 1, np.int64)])
+    wins, ptr = [], 0
+    while ptr + 100 <= len(idx):
+        wins.append(idx[ptr:ptr + 100])
+        ptr += 50
+    return np.stack(wins)
+
+
+def shot_preprocess_frames(frames, engine=None):
+    """[n, h, w, 3] uint8 -> [n, 27, 48, 3] with the library's OpenCV-exact INTER_LINEAR down-scale (cv2.resize(frame,
+    (48, 27)) in the reference, :133-142).  CUDA in -> CUDA out; NumPy in -> NumPy out."""
+    own = engine is None
+    eng = engine or ops.Engine(seed=0)
+    try:
+        t = frames if torch.is_tensor(frames) else torch.from_numpy(np.ascontiguousarray(frames, np.uint8))
+        out = eng.resize_frames(t.cuda().contiguous(), ShotTransNetParams.INPUT_HEIGHT, ShotTransNetParams.INPUT_WIDTH)
+        return out if torch.is_tensor(frames) else out.cpu().numpy()
+    finally:
+        if own:
+            eng.close()
+
+
+def shot_preprocess_frame(frame, engine=None):
+    return shot_preprocess_frames(np.asarray(frame)[None], engine)[0]
+
+
+def shot_preprocess_frames_list(frames, engine=None):
+    return shot_preprocess_frames(np.stack([np.asarray(f) for f in frames]), engine)
+
+
+def scenes_from_predictions(predictions, threshold=0.1):
+    pred = (np.asarray(predictions) > threshold).astype(np.uint8)
+    scenes, t, tp, start, i = [], -1, 0, 0, 0
+    for i, t in enumerate(pred):
+        if tp == 1 and t == 0:
+            start = i
+        if tp == 0 and t == 1 and i != 0:
+            scenes.append([start, i])
+        tp = t
+    if t == 0:
+        scenes.append([start, i])
+    return np.array(scenes, dtype=np.int32)
+
+
+def predictions_to_scenes(predictions, threshold=0.5):
+    """smartVidCrop.py:214-230: scenes_from_predictions plus the "all frames are transitions" fix."""
+    scenes = scenes_from_predictions(predictions, threshold)
+    if len(scenes) == 0:
+        return np.array([[0, len(predictions) - 1]], dtype=np.int32)
+    return scenes
+
+
+def assert_segmentation(shots, l, min_frames=12):
+    """:209-230 (the reference compares with the literal 12, not min_frames; kept)."""
+    shots = [list(s) for s in shots]
+    shots = [s for s in shots if not (s[1] - s[0] < 12)]
+    if len(shots) == 0:
+        shots.append([0, l - 1])
+    for i in range(len(shots) - 1):
+        if shots[i][1] != (shots[i + 1][0] - 1):
+            shots[i][1] = shots[i + 1][0] - 1
+    if shots[-1][1] < l - 1:
+        shots[-1][1] = l - 1
+    return shots
+
+
+def shots_from_predictions(predictions, threshold=0.1):
+    shots = [list(s) for s in scenes_from_predictions(predictions, threshold)]
+    return np.array(assert_segmentation(shots, len(predictions), min_frames=12), dtype=np.int32)
+
+
+def shot_trans_net_handler_version():
+    return '1.0'

@@ -387,3 +387,65 @@ def pack_blob(layers):
         struct.pack_into('<QQ', out, 16 + 16 * i, head // 4 + o, t.size)
         out[head + o * 4: head + o * 4 + t.size * 4] = t.tobytes()
     return bytes(out)
+
+
+# ------------------------------------------------------------------------------------------------------
+# TransNet V1 (shot boundaries): variable names and layouts of the reference's TensorFlow graph
+# (3rd_party_libs/transnetv1/transnetv1_handler.py:25-84); no pre-trained checkpoint ships with the reference
+# (note.txt:1), so the tests and the bench use this seeded initialisation.
+# ------------------------------------------------------------------------------------------------------
+TRANSNET_F, TRANSNET_L, TRANSNET_S, TRANSNET_D = 16, 3, 2, 256
+TRANSNET_DILATIONS = (1, 2, 4, 8)
+
+
+def transnet_cells():
+    """(block, cell, cin, filters) of the six DDCNN cells."""
+    cells, cin = [], 3
+    for b in range(TRANSNET_L):
+        f = TRANSNET_F << b
+        for c in range(TRANSNET_S):
+            cells.append((b, c, cin, f))
+            cin = 4 * f
+    return cells
+
+
+def make_transnet_state_dict(seed=0):
+    """TensorFlow-layout float32 arrays: conv kernels [3, 3, 3, cin, f] (He-scaled so activations stay O(1) through the
+    six cells), biases, Dense(256) on the 3 x 6 x 256 flattened map, Dense(2)."""
+    rng = np.random.RandomState(seed)
+    sd = {}
+    for b, c, cin, f in transnet_cells():
+        for d in TRANSNET_DILATIONS:
+            p = 'TransNet/SDDCNN_%d/DDCNN_%d/Conv3D_%d' % (b + 1, c + 1, d)
+            sd[p + '/kernel'] = (rng.randn(3, 3, 3, cin, f) * np.sqrt(2.0 / (27 * cin))).astype(np.float32)
+            sd[p + '/bias'] = (rng.randn(f) * 0.05).astype(np.float32)
+    nflat = 3 * 6 * 4 * (TRANSNET_F << (TRANSNET_L - 1))
+    sd['TransNet/dense/kernel'] = (rng.randn(nflat, TRANSNET_D) * np.sqrt(2.0 / nflat)).astype(np.float32)
+    sd['TransNet/dense/bias'] = (rng.randn(TRANSNET_D) * 0.05).astype(np.float32)
+    sd['TransNet/dense_1/kernel'] = (rng.randn(TRANSNET_D, 2) * np.sqrt(4.0 / TRANSNET_D)).astype(np.float32)
+    sd['TransNet/dense_1/bias'] = (rng.randn(2) * 0.5).astype(np.float32)
+    return sd
+
+
+def pack_transnet_blob(sd):
+    """The device layout (csrc/svc_shot.hip): per cell, per dilation a GEMM weight [rows = out channel, padded to a multiple
+    of 32][27 taps x cpad] (cpad = max(4, cin): the three input channels get a zero fourth), then the cell's 4f biases;
+    Dense(256) transposed to [256][4608] + bias; Dense(2) transposed to [2][256] + bias.  One flat float32 array."""
+    parts = []
+    for b, c, cin, f in transnet_cells():
+        cpad, rows = max(4, cin), (f + 31) // 32 * 32
+        kpad = (27 * cpad + 7) // 8 * 8                                        # rows padded to whole 8-deep MFMA k steps
+        for d in TRANSNET_DILATIONS:
+            k = np.asarray(sd['TransNet/SDDCNN_%d/DDCNN_%d/Conv3D_%d/kernel' % (b + 1, c + 1, d)], np.float32)
+            w = np.zeros((rows, 27, cpad), np.float32)
+            w[:f, :, :cin] = k.reshape(27, cin, f).transpose(2, 0, 1)          # tap = (kt * 3 + kh) * 3 + kw
+            wp = np.zeros((rows, kpad), np.float32)
+            wp[:, :27 * cpad] = w.reshape(rows, -1)
+            parts.append(wp.reshape(-1))
+        parts.append(np.concatenate([np.asarray(sd['TransNet/SDDCNN_%d/DDCNN_%d/Conv3D_%d/bias' % (b + 1, c + 1, d)], np.float32)
+                                     for d in TRANSNET_DILATIONS]))
+    parts.append(np.ascontiguousarray(np.asarray(sd['TransNet/dense/kernel'], np.float32).T).reshape(-1))
+    parts.append(np.asarray(sd['TransNet/dense/bias'], np.float32))
+    parts.append(np.ascontiguousarray(np.asarray(sd['TransNet/dense_1/kernel'], np.float32).T).reshape(-1))
+    parts.append(np.asarray(sd['TransNet/dense_1/bias'], np.float32))
+    return np.concatenate(parts)

@@ -1,0 +1,80 @@
+"""TransNet V1 on the device (csrc/svc_shot.hip through the C ABI) against the CPU restatement of the reference's graph
+(oracle/transnet_ref.py; PARITY UNPINNED against TensorFlow, see its header).  Tolerance: fp32 against fp32 in another
+summation order over up to 6 912 products per output -- |dP| <= 1e-4 on the transition probability."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cv_ref, transnet_ref as R
+from retargetvid_amd import ops, transnetv1_handler as Hd, weights
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def net():
+    sd = weights.make_transnet_state_dict(0)
+    n = Hd.ShotTransNet(Hd.ShotTransNetParams(), weights=sd)
+    yield n, sd
+    n.close()
+
+
+def _frames(n, seed, smooth=True):
+    rng = np.random.RandomState(seed)
+    fr = rng.randint(0, 256, (n, 27, 48, 3)).astype(np.uint8)
+    if smooth:                                     # a "video": slowly varying frames with two hard cuts
+        base = rng.randint(0, 256, (3, 27, 48, 3)).astype(np.float32)
+        for i in range(n):
+            s = 0 if i < n // 3 else (1 if i < 2 * n // 3 else 2)
+            fr[i] = np.clip(base[s] + 8 * np.sin(i / 5.0) + rng.randn(27, 48, 3) * 3, 0, 255).astype(np.uint8)
+    return fr
+
+
+def test_predict_raw_matches_oracle(net):
+    n, sd = net
+    fr = np.stack([_frames(100, 1), _frames(100, 2, smooth=False)])
+    got = n.predict_raw(fr)
+    ref = R.forward(sd, fr)
+    assert got.shape == (2, 100) and got.dtype == np.float32
+    assert np.abs(got - ref).max() <= TOL, float(np.abs(got - ref).max())
+    assert ref.max() - ref.min() > 0.05                              # the check is not vacuous: probabilities spread out
+    # any window length (predict_raw takes [batch, frames, ...]), odd batch
+    fr = _frames(3 * 37, 3).reshape(3, 37, 27, 48, 3)
+    assert np.abs(n.predict_raw(fr) - R.forward(sd, fr)).max() <= TOL
+
+
+@pytest.mark.parametrize('nframes', [7, 100, 130, 451])
+def test_predict_video_matches_oracle(net, nframes):
+    n, sd = net
+    fr = _frames(nframes, 10 + nframes)
+    got = n.predict_video(fr)
+    ref = R.predict_video(sd, fr)
+    assert got.shape == (nframes,)
+    assert np.abs(got - ref).max() <= TOL
+    assert np.array_equal(n.predict_frames(torch.from_numpy(fr).cuda()), got)      # CUDA input, the reference's alias
+    assert np.array_equal(Hd.predictions_to_scenes(got, 0.5), R.predictions_to_scenes(ref, 0.5))
+
+
+def test_preprocess_is_the_opencv_down_scale(net):
+    fr = np.random.RandomState(5).randint(0, 256, (4, 360, 640, 3)).astype(np.uint8)
+    got = Hd.shot_preprocess_frames(fr, engine=net[0].eng)
+    ref = np.stack([cv_ref.resize_linear_u8(f, 27, 48) for f in fr])
+    assert got.shape == (4, 27, 48, 3) and np.array_equal(got, ref)
+    assert np.array_equal(Hd.shot_preprocess_frame(fr[1], engine=net[0].eng), ref[1])
+
+
+def test_errors():
+    eng = ops.Engine(seed=0)
+    try:
+        with pytest.raises(ValueError):
+            Hd.ShotTransNet(Hd.ShotTransNetParams())                                  # no weights: no silent random network
+        out = torch.empty((1, 4), dtype=torch.float32, device='cuda')
+        fr = torch.zeros((1, 4, 27, 48, 3), dtype=torch.uint8, device='cuda')
+        import ctypes
+        rc = eng.lib.svc_transnet_predict(eng._h, ctypes.c_void_p(fr.data_ptr()), 1, 4, ctypes.c_void_p(out.data_ptr()), None)
+        assert rc < 0                                                                  # predict before load
+        bad = np.zeros(10, np.float32)
+        assert eng.lib.svc_transnet_load(eng._h, bad.ctypes.data_as(ctypes.c_void_p), bad.size) < 0
+    finally:
+        eng.close()

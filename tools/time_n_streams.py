@@ -3,9 +3,10 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from retargetvid_amd import ops, synth
 NS = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 6]
-fr = torch.from_numpy(synth.blob_frames(32, 140, 250, seed=0)).cuda()
+NF = int(os.environ.get('FRAMES', '32'))
+fr = torch.from_numpy(synth.blob_frames(NF, 140, 250, seed=0)).cuda()
 engs = [ops.Engine(seed=0) for _ in range(max(NS))]
-outs = [torch.empty((32, 140, 250), dtype=torch.uint8, device='cuda') for _ in engs]
+outs = [torch.empty((NF, 140, 250), dtype=torch.uint8, device='cuda') for _ in engs]
 sts = [torch.cuda.Stream() for _ in engs]
 for n in NS:
     def run(k):

@@ -332,6 +332,23 @@ def ingest_frames(video, crop_params, engine=None, verbose=False):
     return vid_data
 
 
+def detect_shots(frames, fr, crop_params=None, net=None, engine=None, trans_threshold=0.1):
+    """Shot detection of the reference's video path (smartVidCrop.py:248-372, :457) on the device: frames [n, h, w, 3]
+    uint8 (CUDA tensor or NumPy, RGB) -> dict(trans_probs, segmentation, trans_inds).  `net` is a
+    transnetv1_handler.ShotTransNet (it owns the weights; the reference's checkpoint does not ship with it).  The result's
+    trans_inds is what ingest_frames / smart_vid_crop take in the video dict."""
+    import torch
+    from . import transnetv1_handler as T
+    if net is None:
+        raise ValueError('detect_shots needs net= (a transnetv1_handler.ShotTransNet holding the weights)')
+    CP = crop_params or sc_init_crop_params()
+    t = frames if torch.is_tensor(frames) else torch.from_numpy(np.ascontiguousarray(frames, np.uint8))
+    small = T.shot_preprocess_frames(t.cuda().contiguous(), engine=engine or net.eng)
+    probs = T.video_transition_probs(net, small, fr, CP['read_batch'])
+    seg = T.predictions_to_scenes(probs, threshold=trans_threshold)
+    return dict(trans_probs=probs, segmentation=seg, trans_inds=T.shots_to_trans_inds(seg, len(probs)))
+
+
 def blend_flags(fc_sel, segmentation_sel):
     """Which maps are blended into their successor (smartVidCrop.py:2324-2327, :2369-2370)."""
     cuts = set(int(s[0]) for s in segmentation_sel)

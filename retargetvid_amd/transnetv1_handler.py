@@ -167,3 +167,37 @@ def shots_from_predictions(predictions, threshold=0.1):
 
 def shot_trans_net_handler_version():
     return '1.0'
+
+
+# ---- the reference's call site (smartVidCrop.py:248-372): read batches with an overlap ---------------------------------
+def video_transition_probs(net, frames_small, fr, read_batch=2000, predict=None):
+    """Transition probability of every frame of a video the way read_and_segment_video obtains it: the video is cut in
+    read batches of `read_batch` frames; each batch is predicted inside an array of read_batch + overlap frames
+    (overlap = int(fr - 5)) whose head holds the last `overlap` rows of the previous batch's array -- ZEROS for the first
+    batch -- and whose unused tail is zeros (smartVidCrop.py:258-260, :353-358, :369-374); rows overlap .. overlap + len of
+    predict_frames' output are kept.  frames_small: [n, 27, 48, 3] uint8, CUDA tensor or NumPy.  -> NumPy float32 [n].
+    `predict` replaces net.predict_frames (the tests pass the oracle)."""
+    predict = predict or net.predict_frames
+    is_t = torch.is_tensor(frames_small)
+    n = int(frames_small.shape[0])
+    overlap = int(fr - 5)
+    size = read_batch + overlap
+    probs, prev = [], None
+    for si in range(0, n, read_batch):
+        cur = frames_small[si:si + read_batch]
+        ln = int(cur.shape[0])
+        arr = torch.zeros((size,) + tuple(frames_small.shape[1:]), dtype=torch.uint8, device=frames_small.device) if is_t \
+            else np.zeros((size,) + tuple(frames_small.shape[1:]), np.uint8)
+        arr[overlap:overlap + ln] = cur
+        if prev is not None and overlap > 0:
+            arr[:overlap] = prev[size - overlap:]
+        prev = arr
+        probs.append(np.asarray(predict(arr))[overlap:overlap + ln])
+    return np.concatenate(probs).astype(np.float32) if probs else np.zeros(0, np.float32)
+
+
+def shots_to_trans_inds(scenes, frame_count):
+    """Scene list -> the `trans_inds` of the package's input dict (smartVidCrop.ingest_frames: scene i = trans_inds[i] ..
+    trans_inds[i + 1] - 1): the scene starts plus the frame count.  NB: the reference's video path keeps the scenes
+    themselves ([start, first transition frame]); for the one-frame hard cuts both describe the same partition."""
+    return [int(s[0]) for s in scenes] + [int(frame_count)]

@@ -78,3 +78,25 @@ def test_errors():
         assert eng.lib.svc_transnet_load(eng._h, bad.ctypes.data_as(ctypes.c_void_p), bad.size) < 0
     finally:
         eng.close()
+
+
+def test_video_batches_with_overlap_and_detect_shots(net):
+    """The reference's call site (smartVidCrop.py:248-372): read batches with an overlap taken from the previous batch's
+    array (zeros in front of the first), then predictions_to_scenes; smartVidCrop.detect_shots is that chain on the device."""
+    from retargetvid_amd import smartVidCrop as S
+    n, sd = net
+    rng = np.random.RandomState(4)
+    base = rng.randint(0, 256, (4, 72, 128, 3)).astype(np.float32)
+    fr = np.stack([np.clip(base[min(i // 60, 3)] + rng.randn(72, 128, 3) * 2, 0, 255) for i in range(230)]).astype(np.uint8)
+    CP = S.sc_init_crop_params()
+    CP['read_batch'] = 100                                            # three read batches, the last one partial
+    got = S.detect_shots(fr, 25.0, CP, net=n)
+    small = np.stack([cv_ref.resize_linear_u8(f, 27, 48) for f in fr])
+    ref = Hd.video_transition_probs(None, small, 25.0, 100, predict=lambda a: R.predict_video(sd, a))
+    assert got['trans_probs'].shape == (230,) and np.abs(got['trans_probs'] - ref).max() <= TOL
+    seg = R.predictions_to_scenes(ref, 0.1)
+    assert np.array_equal(got['segmentation'], seg)
+    assert got['trans_inds'] == [int(s[0]) for s in seg] + [230]
+    # the overlap matters: predicting the batches on their own (no overlap rows) gives other values at the batch heads
+    alone = np.concatenate([R.predict_video(sd, small[i:i + 100]) for i in range(0, 230, 100)])
+    assert np.abs(alone - ref).max() > 1e-3

@@ -68,6 +68,44 @@ __global__ __launch_bounds__(256) void k_shot_conv(const ShotConv A) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
         }
+    } else if (A.C >= 8) {
+        // 27 taps x C / 8 steps.  Measured first: with the operand loads taken out the loop runs at 102 TFLOP/s, with a load
+        // guarded by the tap's bounds test in front of every step's MFMAs at 57 -- the wave waits for each load.  So a tap's
+        // source row is decoded once, the loads are unconditional (an out-of-range tap reads a valid dummy address and is
+        // zeroed by a select: SAME padding), and the next step's operands are requested before this step's MFMAs.
+        const int spt = A.C >> 3;
+        auto tap_ptr = [&](int tap, bool &ok) -> const float * {
+            const int kt = tap / 9, kh = (tap - 9 * kt) / 3, kw = tap - 9 * kt - 3 * kh;
+            const int tt = t + (kt - 1) * d, yy = y + kh - 1, xx = x + kw - 1;
+            ok = (unsigned)tt < (unsigned)A.T && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W;
+            return ok ? A.X + ((((size_t)(frame0 + tt)) * A.H + yy) * A.W + xx) * A.C + 4 * hh : A.X + 4 * hh;
+        };
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool okc, okn = false;
+        const float *pc = tap_ptr(0, okc), *pn = pc;
+        float4 an = *(const float4 *)pc, bn = *(const float4 *)wrow;
+        if (!okc) an = z4;
+        int kk = 0;
+        for (int tap = 0; tap < 27; ++tap) {
+            if (tap + 1 < 27) pn = tap_ptr(tap + 1, okn);
+            for (int st = 0; st < spt; ++st) {
+                const float4 a = an, b = bn;
+                if (st + 1 < spt) {
+                    an = *(const float4 *)(pc + 8 * (st + 1));
+                    if (!okc) an = z4;
+                } else if (tap + 1 < 27) {
+                    an = *(const float4 *)pn;
+                    if (!okn) an = z4;
+                }
+                kk += 8;
+                if (kk < A.kpad) bn = *(const float4 *)(wrow + kk);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
+            }
+            pc = pn; okc = okn;
+        }
     } else {
         for (int kk = 0; kk < A.kpad; kk += 8) {
             const int k0 = kk + 4 * hh, tap = k0 >> A.logC, c0 = k0 & (A.C - 1);
@@ -82,6 +120,95 @@ __global__ __launch_bounds__(256) void k_shot_conv(const ShotConv A) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
         }
+    }
+    if ((long long)blockIdx.x * 128 + wave * 32 + r >= A.M) return;
+    float *yp = A.Y + (size_t)m * A.ldy + br * A.F;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int col = nt * 32 + 8 * g + 4 * hh;
+        if (col >= A.F) continue;
+        const float4 b = *(const float4 *)(A.bias + br * A.F + col);
+        float4 v = make_float4(acc[4 * g] + b.x, acc[4 * g + 1] + b.y, acc[4 * g + 2] + b.z, acc[4 * g + 3] + b.w);
+        if (A.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *(float4 *)(yp + col) = v;
+    }
+}
+
+// The 27-tap cells with C >= 64 input channels: the tap's [32 output channels x C] slice of the weights goes through LDS
+// (double-buffered, fetched with whole-line loads by all four waves, one barrier per tap) instead of every wave reading
+// its 32 weight rows 16 bytes at a time: k_shot_conv's loads, not its MFMAs, set its pace (with the operand loads taken
+// out it runs at 102 TFLOP/s, with them at 57: a wave-wide float4 load of 32 different rows is 32 L1 transactions), and
+// the weight operand is the half of them that the four waves of a workgroup share.
+__global__ __launch_bounds__(256) void k_shot_conv_lds(const ShotConv A) {
+    extern __shared__ float sm_shot[];                       // [2][32][C + 4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const long long m = std::min((long long)blockIdx.x * 128 + wave * 32 + r, A.M - 1);
+    const int tiles = A.Fpad >> 5, br = blockIdx.y / tiles, nt = blockIdx.y - br * tiles;
+    const int d = 1 << br;
+    const int x = (int)(m % A.W);
+    long long q = m / A.W;
+    const int y = (int)(q % A.H);
+    q /= A.H;
+    const int t = (int)(q % A.T);
+    const long long frame0 = q - t;
+    const int C = A.C, WS = C + 4, spt = C >> 3, c4n = C >> 2;
+    const int per_thread = (32 * c4n) >> 8;                  // float4 of a weight slice per thread: 2 (C = 64), 4, 8
+    const float *wbase = A.Wt + ((size_t)br * A.Fpad + nt * 32) * A.kpad;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    auto tap_ptr = [&](int tap, bool &ok) -> const float * {
+        const int kt = tap / 9, kh = (tap - 9 * kt) / 3, kw = tap - 9 * kt - 3 * kh;
+        const int tt = t + (kt - 1) * d, yy = y + kh - 1, xx = x + kw - 1;
+        ok = (unsigned)tt < (unsigned)A.T && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W;
+        return ok ? A.X + ((((size_t)(frame0 + tt)) * A.H + yy) * A.W + xx) * C + 4 * hh : A.X + 4 * hh;
+    };
+    float4 wreg[8];
+    auto fetch_w = [&](int tap) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < per_thread) {
+                const int idx = tid + 256 * i, row = idx / c4n, c4 = idx - row * c4n;
+                wreg[i] = *(const float4 *)(wbase + (size_t)row * A.kpad + tap * C + c4 * 4);
+            }
+    };
+    auto store_w = [&](float *dst) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < per_thread) {
+                const int idx = tid + 256 * i, row = idx / c4n, c4 = idx - row * c4n;
+                *(float4 *)(dst + row * WS + c4 * 4) = wreg[i];
+            }
+    };
+    fetch_w(0);
+    store_w(sm_shot);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool okc, okn = false;
+    const float *pc = tap_ptr(0, okc), *pn = pc;
+    float4 an = *(const float4 *)pc;
+    if (!okc) an = z4;
+    for (int tap = 0; tap < 27; ++tap) {
+        float *Bs = sm_shot + (tap & 1) * 32 * WS;
+        __syncthreads();                                     // this tap's slice is in LDS; the other buffer's readers are done
+        if (tap + 1 < 27) { fetch_w(tap + 1); pn = tap_ptr(tap + 1, okn); }
+        const float *bp = Bs + r * WS + 4 * hh;
+        for (int st = 0; st < spt; ++st) {
+            const float4 a = an;
+            const float4 b = *(const float4 *)(bp + 8 * st);
+            if (st + 1 < spt) {
+                an = *(const float4 *)(pc + 8 * (st + 1));
+                if (!okc) an = z4;
+            } else if (tap + 1 < 27) {
+                an = *(const float4 *)pn;
+                if (!okn) an = z4;
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
+        }
+        if (tap + 1 < 27) store_w(sm_shot + ((tap + 1) & 1) * 32 * WS);
+        pc = pn; okc = okn;
     }
     if ((long long)blockIdx.x * 128 + wave * 32 + r >= A.M) return;
     float *yp = A.Y + (size_t)m * A.ldy + br * A.F;
@@ -217,7 +344,14 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
                 while ((1 << A.logC) < k.cpad) ++A.logC;
                 A.F = k.f; A.Fpad = k.fpad; A.kpad = k.kpad; A.ntaps = 27; A.ldy = 4 * k.f; A.relu = 1;
                 dim3 grid((unsigned)((A.M + 127) / 128), (unsigned)(4 * (k.fpad / 32)));
-                k_shot_conv<<<grid, 256, 0, s>>>(A);
+                if (k.cpad >= 64 && k.cpad <= 256) {
+                    const size_t lds = (size_t)2 * 32 * (k.cpad + 4) * sizeof(float);
+                    if (lds > 64 * 1024 && h->lds_attr_done.insert((const void *)k_shot_conv_lds).second)
+                        SVC_HIP(hipFuncSetAttribute((const void *)k_shot_conv_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                    k_shot_conv_lds<<<grid, 256, lds, s>>>(A);
+                } else {
+                    k_shot_conv<<<grid, 256, 0, s>>>(A);
+                }
                 SVC_CHECK_LAUNCH();
                 cur ^= 1;
             }

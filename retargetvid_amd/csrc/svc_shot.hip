@@ -223,6 +223,95 @@ __global__ __launch_bounds__(256) void k_shot_conv_lds(const ShotConv A) {
     }
 }
 
+// Both operands through LDS: per (tap, 64-channel slice) the workgroup's 128 positions x 64 channels and the NT x 32 output
+// channels x 64 weights are fetched with whole-line loads (a wave's float4 load covers four complete 256-byte rows; the
+// direct form reads 32 rows 16 bytes at a time: 4x the L1 transactions), parked in registers while the previous slice is
+// multiplied, and written to LDS between two barriers.  NT = 2 (64-filter cells) shares the positions between two tiles.
+template <int NT>
+__global__ __launch_bounds__(256) void k_shot_conv_lds2(const ShotConv A) {
+    extern __shared__ float sm_shot2[];                      // As [128][68] | Bs [NT * 32][68]
+    constexpr int WS = 68;
+    float *As = sm_shot2, *Bs = sm_shot2 + 128 * WS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int groups = A.Fpad / (32 * NT), br = blockIdx.y / groups, ng = blockIdx.y - br * groups;
+    const int d = 1 << br, C = A.C, HW = A.H * A.W, nsl = C >> 6;
+    const long long m0 = (long long)blockIdx.x * 128;
+    // fetch role: float4 c4 = tid & 15 of rows (tid >> 4) + 16 j, j = 0..7 (positions) / j = 0..2 NT - 1 (weights)
+    const int c4 = tid & 15, row0 = tid >> 4;
+    int pxy[8], pfr[8];                                      // x | y << 8 | t << 16 and the frame index of the thread's eight positions
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long long m = std::min(m0 + row0 + 16 * j, A.M - 1);
+        const long long fr = m / HW;
+        const int rem = (int)(m - fr * HW), y = rem / A.W, x = rem - y * A.W;
+        pxy[j] = x | (y << 8) | ((int)(fr % A.T) << 16);
+        pfr[j] = (int)fr;
+    }
+    const float *wbase = A.Wt + ((size_t)br * A.Fpad + ng * 32 * NT) * A.kpad;
+    float4 areg[8], breg[2 * NT];
+    auto fetch = [&](int it) {
+        const int tap = it / nsl, sl = it - tap * nsl;
+        const int kt = tap / 9, kh = (tap - 9 * kt) / 3, kw = tap - 9 * kt - 3 * kh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int x = (pxy[j] & 255) + kw - 1, y = ((pxy[j] >> 8) & 255) + kh - 1, t = (pxy[j] >> 16) + (kt - 1) * d;
+            const bool ok = (unsigned)t < (unsigned)A.T && (unsigned)y < (unsigned)A.H && (unsigned)x < (unsigned)A.W;
+            const size_t pos = ok ? ((size_t)(pfr[j] + (kt - 1) * d) * A.H + y) * A.W + x : 0;
+            const float4 v = *(const float4 *)(A.X + pos * C + sl * 64 + c4 * 4);
+            areg[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);          // SAME padding
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * NT; ++j)
+            breg[j] = *(const float4 *)(wbase + (size_t)(row0 + 16 * j) * A.kpad + tap * C + sl * 64 + c4 * 4);
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *(float4 *)(As + (row0 + 16 * j) * WS + c4 * 4) = areg[j];
+#pragma unroll
+        for (int j = 0; j < 2 * NT; ++j) *(float4 *)(Bs + (row0 + 16 * j) * WS + c4 * 4) = breg[j];
+    };
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+    const int niter = 27 * nsl;
+    fetch(0);
+    for (int it = 0; it < niter; ++it) {
+        __syncthreads();                                     // the previous slice's readers are done
+        park();
+        __syncthreads();
+        if (it + 1 < niter) fetch(it + 1);                   // in flight during this slice's MFMAs
+        const float *ap = As + (wave * 32 + r) * WS + 4 * hh;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const float4 a = *(const float4 *)(ap + 8 * st);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float4 b = *(const float4 *)(Bs + (n * 32 + r) * WS + 4 * hh + 8 * st);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc[n], 0, 0, 0);
+            }
+        }
+    }
+    const long long m = m0 + wave * 32 + r;
+    if (m >= A.M) return;
+    float *yp = A.Y + (size_t)m * A.ldy + br * A.F;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = (ng * NT + n) * 32 + 8 * g + 4 * hh;
+            if (col >= A.F) continue;
+            const float4 b = *(const float4 *)(A.bias + br * A.F + col);
+            float4 v = make_float4(acc[n][4 * g] + b.x, acc[n][4 * g + 1] + b.y, acc[n][4 * g + 2] + b.z, acc[n][4 * g + 3] + b.w);
+            if (A.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *(float4 *)(yp + col) = v;
+        }
+}
+
 // MaxPool3D (1, 2, 2), VALID: [n][H][W][C] -> [n][H/2][W/2][C]
 __global__ __launch_bounds__(256) void k_shot_pool(const float *__restrict__ X, float *__restrict__ Y, size_t total, int H, int W,
                                                    int C4) {
@@ -344,7 +433,15 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
                 while ((1 << A.logC) < k.cpad) ++A.logC;
                 A.F = k.f; A.Fpad = k.fpad; A.kpad = k.kpad; A.ntaps = 27; A.ldy = 4 * k.f; A.relu = 1;
                 dim3 grid((unsigned)((A.M + 127) / 128), (unsigned)(4 * (k.fpad / 32)));
-                if (k.cpad >= 64 && k.cpad <= 256) {
+                static const int shot_form = getenv("SVC_SHOT_FORM") ? atoi(getenv("SVC_SHOT_FORM")) : 2;      // 0: direct, 1: weights through LDS, 2: both operands
+                if (shot_form == 2 && k.cpad >= 64 && k.cpad % 64 == 0) {
+                    if (k.fpad % 64 == 0) {
+                        dim3 g2(grid.x, (unsigned)(4 * (k.fpad / 64)));
+                        k_shot_conv_lds2<2><<<g2, 256, (128 + 64) * 68 * sizeof(float), s>>>(A);
+                    } else {
+                        k_shot_conv_lds2<1><<<grid, 256, (128 + 32) * 68 * sizeof(float), s>>>(A);
+                    }
+                } else if (shot_form >= 1 && k.cpad >= 64 && k.cpad <= 256) {
                     const size_t lds = (size_t)2 * 32 * (k.cpad + 4) * sizeof(float);
                     if (lds > 64 * 1024 && h->lds_attr_done.insert((const void *)k_shot_conv_lds).second)
                         SVC_HIP(hipFuncSetAttribute((const void *)k_shot_conv_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));

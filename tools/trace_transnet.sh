@@ -7,7 +7,8 @@ cd /tmp && export TMPDIR=/tmp
 CPU=0 rocprofv3 --kernel-trace --output-format csv -d $O/raw -- python3 $R/tools/time_transnet.py > $O/run.log 2>&1
 python3 - "$(ls $O/raw/*/*kernel_trace.csv | head -1)" <<'PY'
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if r['Kernel_Name'].startswith('k_shot')]
+rows = [dict(r, Kernel_Name=r['Kernel_Name'].replace('void ', '')) for r in csv.DictReader(open(sys.argv[1]))]
+rows = [r for r in rows if r['Kernel_Name'].startswith('k_shot')]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 last = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('k_shot_in')][-1]
 tot = 0

@@ -312,6 +312,81 @@ __global__ __launch_bounds__(256) void k_shot_conv_lds2(const ShotConv A) {
         }
 }
 
+// The 16-filter cells (SDDCNN_1): a 32-column tile would be half padding -- 40 % of the network's executed FLOPs sit in
+// SDDCNN_1/DDCNN_2 -- so the tile is 16 output channels on v_mfma_f32_16x16x4_f32, two 16-position tiles per wave.  A lane
+// group g = lane / 16 owns k = 4 g .. 4 g + 3 of every 16-deep block (one float4 per operand; element e feeds the e-th
+// MFMA, for both operands alike), and ends with channels 4 g .. 4 g + 3 of its position: one float4 store.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_shot_conv_lds2_n16(const ShotConv A) {
+    extern __shared__ float sm_shot3[];                      // As [128][68] | Bs [16][68]
+    constexpr int WS = 68;
+    float *As = sm_shot3, *Bs = sm_shot3 + 128 * WS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p16 = lane & 15, g = lane >> 4;
+    const int br = blockIdx.y, d = 1 << br, C = A.C, HW = A.H * A.W, nsl = C >> 6;
+    const long long m0 = (long long)blockIdx.x * 128;
+    const int c4 = tid & 15, row0 = tid >> 4;
+    int pxy[8], pfr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long long m = std::min(m0 + row0 + 16 * j, A.M - 1);
+        const long long fr = m / HW;
+        const int rem = (int)(m - fr * HW), y = rem / A.W, x = rem - y * A.W;
+        pxy[j] = x | (y << 8) | ((int)(fr % A.T) << 16);
+        pfr[j] = (int)fr;
+    }
+    const float *wbase = A.Wt + (size_t)br * A.Fpad * A.kpad;
+    float4 areg[8], breg;
+    auto fetch = [&](int it) {
+        const int tap = it / nsl, sl = it - tap * nsl;
+        const int kt = tap / 9, kh = (tap - 9 * kt) / 3, kw = tap - 9 * kt - 3 * kh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int x = (pxy[j] & 255) + kw - 1, y = ((pxy[j] >> 8) & 255) + kh - 1, t = (pxy[j] >> 16) + (kt - 1) * d;
+            const bool ok = (unsigned)t < (unsigned)A.T && (unsigned)y < (unsigned)A.H && (unsigned)x < (unsigned)A.W;
+            const size_t pos = ok ? ((size_t)(pfr[j] + (kt - 1) * d) * A.H + y) * A.W + x : 0;
+            const float4 v = *(const float4 *)(A.X + pos * C + sl * 64 + c4 * 4);
+            areg[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        breg = *(const float4 *)(wbase + (size_t)row0 * A.kpad + tap * C + sl * 64 + c4 * 4);       // 16 rows x 16 float4
+    };
+    f32x4 acc[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[n][i] = 0.f;
+    const int niter = 27 * nsl;
+    fetch(0);
+    for (int it = 0; it < niter; ++it) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *(float4 *)(As + (row0 + 16 * j) * WS + c4 * 4) = areg[j];
+        *(float4 *)(Bs + row0 * WS + c4 * 4) = breg;
+        __syncthreads();
+        if (it + 1 < niter) fetch(it + 1);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const float4 w = *(const float4 *)(Bs + p16 * WS + 16 * st + 4 * g);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const float4 a = *(const float4 *)(As + (wave * 32 + n * 16 + p16) * WS + 16 * st + 4 * g);
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a.x, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, a.y, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, a.z, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, a.w, acc[n], 0, 0, 0);
+            }
+        }
+    }
+    const float4 b = *(const float4 *)(A.bias + br * 16 + 4 * g);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const long long m = m0 + wave * 32 + n * 16 + p16;
+        if (m >= A.M) continue;
+        float4 v = make_float4(acc[n][0] + b.x, acc[n][1] + b.y, acc[n][2] + b.z, acc[n][3] + b.w);
+        if (A.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *(float4 *)(A.Y + (size_t)m * A.ldy + br * 16 + 4 * g) = v;
+    }
+}
+
 // MaxPool3D (1, 2, 2), VALID: [n][H][W][C] -> [n][H/2][W/2][C]
 __global__ __launch_bounds__(256) void k_shot_pool(const float *__restrict__ X, float *__restrict__ Y, size_t total, int H, int W,
                                                    int C4) {
@@ -435,7 +510,10 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
                 dim3 grid((unsigned)((A.M + 127) / 128), (unsigned)(4 * (k.fpad / 32)));
                 static const int shot_form = getenv("SVC_SHOT_FORM") ? atoi(getenv("SVC_SHOT_FORM")) : 2;      // 0: direct, 1: weights through LDS, 2: both operands
                 if (shot_form == 2 && k.cpad >= 64 && k.cpad % 64 == 0) {
-                    if (k.fpad % 64 == 0) {
+                    if (k.f == 16) {
+                        dim3 g16(grid.x, 4);
+                        k_shot_conv_lds2_n16<<<g16, 256, (128 + 16) * 68 * sizeof(float), s>>>(A);
+                    } else if (k.fpad % 64 == 0) {
                         dim3 g2(grid.x, (unsigned)(4 * (k.fpad / 64)));
                         k_shot_conv_lds2<2><<<g2, 256, (128 + 64) * 68 * sizeof(float), s>>>(A);
                     } else {

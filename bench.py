@@ -272,7 +272,10 @@ def main():
         slots[0].finish()
     latency_ms = (time.perf_counter() - t1) / 10 * 1e3
     dominant = max(per_class, key=lambda k: per_class[k][0])
-    live = os.environ.get('BENCH_LIVE_PROFILE', '1') != '0' and not plain      # diagnostic: cost of the in-library events
+    # BENCH_LIVE_PROFILE=1 also records the dominant class's events INSIDE the timed region (roofline.*_in_flight).  Off by
+    # default: 76 event records per step on every stream cost 2-3 % of the step with four batches in flight (1.49 -> 1.45 ms)
+    # and more with deeper pipelines; roofline.frac comes from the un-pipelined passes above either way.
+    live = os.environ.get('BENCH_LIVE_PROFILE', '0') == '1' and not plain
     for sl in slots:
         sl.eng.profile_enable(dominant if live else None)
         sl.eng.profile_read()

@@ -16,12 +16,18 @@ if os.environ.get('BENCH_NO_BLEND', '0') != '1':
 engs = [ops.Engine(sd) for _ in range(max(NS))]
 sts = [torch.cuda.Stream() for _ in engs]
 maps = [torch.empty((32, 140, 250), dtype=torch.uint8, device='cuda') for _ in engs]
+COPY = os.environ.get('COPY', '0') == '1'
+pinned = [torch.empty((32, 2), dtype=torch.float64).pin_memory() for _ in engs]
+evs = [torch.cuda.Event() for _ in engs]
 def batch(i):
     with torch.cuda.stream(sts[i]):
         small = engs[i].resize_frames(frames, 140, 250)
         m = engs[i].saliency(small, out=maps[i])
         engs[i].threshold_(m, CP['t_threshold'])
-        engs[i].cluster_center_(m, flags, CP)
+        xy = engs[i].cluster_center_(m, flags, CP)
+        if COPY:
+            pinned[i].copy_(xy, non_blocking=True)
+            evs[i].record(sts[i])
 for n in NS:
     def run(k):
         torch.cuda.synchronize(); t = time.perf_counter()

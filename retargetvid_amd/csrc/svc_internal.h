@@ -144,6 +144,7 @@ struct SvcHandle {
     // TransNet V1 (svc_shot.hip)
     DevBuf shot_blob, shot_ws;
     bool shot_loaded = false;
+    int shot_form = 2;                 // TransNet convolution cells: 0 = operands straight from global memory (k_shot_conv), 1 = weights through LDS, 2 = both operands through LDS with whole-line loads (SVC_SHOT_FORM)
     // per-kernel-class event log (svc_profile_*)
     int prof_class = -1;
     hipStream_t prof_stream = nullptr;          // stream of the last recorded launch (the empty-pair calibration of svc_profile_read runs on it)

@@ -2836,6 +2836,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->dwpw_min_px = atoi(env);
     env = getenv("SVC_DW_TILE");
     if (env) h->dw_tile = atoi(env);
+    env = getenv("SVC_SHOT_FORM");
+    if (env) h->shot_form = atoi(env);
     env = getenv("SVC_PRIM_PT");
     if (env && atoi(env) > 0) h->prim_pt = atoi(env);
     int rc = h->blob.ensure(n_bytes);

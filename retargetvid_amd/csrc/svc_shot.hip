@@ -508,7 +508,7 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
                 while ((1 << A.logC) < k.cpad) ++A.logC;
                 A.F = k.f; A.Fpad = k.fpad; A.kpad = k.kpad; A.ntaps = 27; A.ldy = 4 * k.f; A.relu = 1;
                 dim3 grid((unsigned)((A.M + 127) / 128), (unsigned)(4 * (k.fpad / 32)));
-                static const int shot_form = getenv("SVC_SHOT_FORM") ? atoi(getenv("SVC_SHOT_FORM")) : 2;      // 0: direct, 1: weights through LDS, 2: both operands
+                const int shot_form = h->shot_form;             // 0: direct operand loads, 1: weights through LDS, 2: both operands (SVC_SHOT_FORM)
                 if (shot_form == 2 && k.cpad >= 64 && k.cpad % 64 == 0) {
                     if (k.f == 16) {
                         dim3 g16(grid.x, 4);

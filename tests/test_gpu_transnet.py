@@ -64,6 +64,30 @@ def test_preprocess_is_the_opencv_down_scale(net):
     assert np.array_equal(Hd.shot_preprocess_frame(fr[1], engine=net[0].eng), ref[1])
 
 
+@pytest.mark.parametrize('form', ['0', '1'])
+def test_kernel_forms_agree(net, form):
+    """The three forms of the convolution cells (operands straight from global memory / weights through LDS / both
+    operands through LDS, the default) compute the same network."""
+    import os
+    n, sd = net
+    fr = _frames(100, 77)[None]
+    ref = n.predict_raw(fr)
+    old = os.environ.get('SVC_SHOT_FORM')
+    os.environ['SVC_SHOT_FORM'] = form
+    try:
+        other = Hd.ShotTransNet(Hd.ShotTransNetParams(), weights=sd)      # the knob is read when the handle is created
+    finally:
+        if old is None:
+            os.environ.pop('SVC_SHOT_FORM', None)
+        else:
+            os.environ['SVC_SHOT_FORM'] = old
+    try:
+        got = other.predict_raw(fr)
+    finally:
+        other.close()
+    assert np.abs(got - ref).max() <= TOL and np.abs(got - R.forward(sd, fr)).max() <= TOL
+
+
 def test_errors():
     eng = ops.Engine(seed=0)
     try:

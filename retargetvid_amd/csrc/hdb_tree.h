@@ -290,7 +290,8 @@ inline bool build_batched(Tree &t, const Edge *edges, int n, int mcs) {
         bool bad[B];                                   // cannot be part of a prefix
         for (int j = 0; j < m; ++j) {
             const bool aB = pre[j].ca != NONE16, bB = pre[j].cb != NONE16;
-            const bool aF = !aB && fa[j] == (uint32_t)j, bF = !bB && fb[j] == (uint32_t)j;
+            const bool aF = !aB && fa[j] == (uint32_t)j;   // (the other side: bF = !bB && fb[j] == j, implied where it matters)
+            (void)bB;
             par[j] = j; clus[j] = NONE16; add[j] = 0; bad[j] = false;
             if (aF && bF) add[j] = pre[j].sa + pre[j].sb;
             else if (aF && bB) { clus[j] = pre[j].cb; add[j] = pre[j].sa; }
@@ -334,7 +335,8 @@ inline bool build_batched(Tree &t, const Edge *edges, int n, int mcs) {
             for (int k = 0; k < j; ++k)                // (several chains of one batch may feed the same cluster)
                 if (c != NONE16 ? clus[root[k]] == c : root[k] == r0) prev = k;
             const bool aB = q.ca != NONE16, bB = q.cb != NONE16;
-            const bool aF = !aB && fa[j] == (uint32_t)j, bF = !bB && fb[j] == (uint32_t)j;
+            const bool aF = !aB && fa[j] == (uint32_t)j;   // (the other side: bF = !bB && fb[j] == j, implied where it matters)
+            (void)bB;
             if (c != NONE16) {                         // absorption into cluster c: the fresh side falls out of it
                 const bool abig = !aF;                 // the a side is the cluster's side
                 const uint32_t r = abig ? q.rb : q.ra, s = abig ? q.sb : q.sa, ns = abig ? q.nb : q.na;

@@ -290,8 +290,7 @@ inline bool build_batched(Tree &t, const Edge *edges, int n, int mcs) {
         bool bad[B];                                   // cannot be part of a prefix
         for (int j = 0; j < m; ++j) {
             const bool aB = pre[j].ca != NONE16, bB = pre[j].cb != NONE16;
-            const bool aF = !aB && fa[j] == (uint32_t)j;   // (the other side: bF = !bB && fb[j] == j, implied where it matters)
-            (void)bB;
+            const bool aF = !aB && fa[j] == (uint32_t)j, bF = !bB && fb[j] == (uint32_t)j;
             par[j] = j; clus[j] = NONE16; add[j] = 0; bad[j] = false;
             if (aF && bF) add[j] = pre[j].sa + pre[j].sb;
             else if (aF && bB) { clus[j] = pre[j].cb; add[j] = pre[j].sa; }

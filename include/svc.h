@@ -89,10 +89,17 @@ int svc_saliency_u8(SvcHandle *h, const uint8_t *frames_nhwc, int n, int height,
 int svc_threshold_u8(SvcHandle *h, uint8_t *maps, size_t n_bytes, int t, void *stream);
 
 /* Cluster filter + cut blend + centre of every map, in place on thresholded maps.
- * blend_flags_host[n] (HOST memory, may be NULL): non-zero at i means "after filtering
- * map i, blend it into map i+1" (smartVidCrop.py:2369-2373; the caller evaluates the
- * cut test).  xy[n][2] receives (x, y) centres as float64 in saliency-map pixels,
- * NaN = None (empty map).  stats may be NULL. */
+ * blend_flags_host[n] (HOST memory, may be NULL), bits per map i:
+ *   SVC_BLEND_NEXT  "once map i is final, blend it into map i+1" (smartVidCrop.py:2369-2373; the caller evaluates the
+ *                   cut test); map i+1 is then processed after map i;
+ *   SVC_MAP_HELD    map i is NOT processed by this call: it is already final (the end of a chain a previous call
+ *                   processed, carried over so that the chain can continue: HELD | BLEND_NEXT) or left for a later call.
+ *                   A chain that straddles two calls gives the same maps and centres as in one call
+ *                   (tests/test_gpu_parity.py::test_blend_chain_carried_over_between_calls).
+ * xy[n][2] receives (x, y) centres as float64 in saliency-map pixels, NaN = None (empty map); the entries of held
+ * maps are unspecified.  stats may be NULL. */
+#define SVC_BLEND_NEXT 1
+#define SVC_MAP_HELD 2
 int svc_cluster_center(SvcHandle *h, uint8_t *maps_nhw, int n, int height, int width,
                        const uint8_t *blend_flags_host, const SvcParams *params,
                        double *xy, int32_t *stats, void *stream);

@@ -1507,38 +1507,49 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
     const int cap = height * width;
     const int mc = hdb::max_clusters(cap, params->hdbscan_min);
     FrameWS L = make_layout(cap, mc);
-    // depth (round) of every map: a map blended from its predecessor runs one round later
+    // depth (round) of every map: a map blended from its predecessor runs one round later.  A HELD map (SVC_MAP_HELD) is not
+    // processed at all -- it is final already (the tail of a chain carried over from an earlier call) or left for a later
+    // call -- and a map blended from a held one runs in round 0, after the blend.
+    const int HELD = 255;
     std::vector<uint8_t> depth(n, 0);
+    std::vector<uint16_t> blend0;                       // round-0 maps that take a blend from a held predecessor first
     int maxd = 0;
-    for (int i = 1; i < n; ++i)
-        if (blend_flags_host && blend_flags_host[i - 1]) {
-            if (depth[i - 1] == 255) { svc_set_error("svc_cluster_center: blend chain longer than 255"); return SVC_E_INVALID; }
-            depth[i] = depth[i - 1] + 1;
-            maxd = std::max(maxd, (int)depth[i]);
+    for (int i = 0; i < n; ++i) {
+        const int fl = blend_flags_host ? blend_flags_host[i] : 0, fp = (blend_flags_host && i > 0) ? blend_flags_host[i - 1] : 0;
+        if (fl & SVC_MAP_HELD) { depth[i] = HELD; continue; }
+        if (fp & SVC_BLEND_NEXT) {
+            if (depth[i - 1] == HELD) { depth[i] = 0; blend0.push_back((uint16_t)i); }
+            else {
+                if (depth[i - 1] >= 254) { svc_set_error("svc_cluster_center: blend chain longer than 254"); return SVC_E_INVALID; }
+                depth[i] = depth[i - 1] + 1;
+                maxd = std::max(maxd, (int)depth[i]);
+            }
         }
+    }
     if (n > DEPTH_SLOT) { svc_set_error("svc_cluster_center: more than %d maps per call", DEPTH_SLOT); return SVC_E_INVALID; }
     // A round's kernels are launched over the maps of THAT round only: the list of all maps sorted by round (stable),
     // one slice per round.  (One workgroup per map of the call in every round -- 31 of 32 exiting at once in the
     // follower rounds -- still has each of them claim a whole CU's wave slots / up to 154 KB of LDS before it can exit:
     // in the pipelined run those claims keep the network's workgroups off the CUs.)
-    std::vector<uint16_t> order(n);
+    std::vector<uint16_t> order(2 * (size_t)n, 0);      // [0, n): maps sorted by round; [n, n + blend0.size()): the round-0 blend targets
     std::vector<int> round_start(maxd + 2, 0);
-    for (int i = 0; i < n; ++i) ++round_start[depth[i] + 1];
+    for (int i = 0; i < n; ++i) if (depth[i] != HELD) ++round_start[depth[i] + 1];
     for (int r = 0; r <= maxd; ++r) round_start[r + 1] += round_start[r];
     {
         std::vector<int> fill(round_start.begin(), round_start.end() - 1);
-        for (int i = 0; i < n; ++i) order[fill[depth[i]]++] = (uint16_t)i;
+        for (int i = 0; i < n; ++i) if (depth[i] != HELD) order[fill[depth[i]]++] = (uint16_t)i;
     }
-    if ((rc = h->tail_ws.ensure((size_t)L.total * n + 8 * 2 * (size_t)DEPTH_SLOT))) return rc;
-    // the list travels through a small ring of pinned host slots so that the upload is asynchronous (up to 8 calls may
+    for (size_t i = 0; i < blend0.size(); ++i) order[n + i] = blend0[i];
+    if ((rc = h->tail_ws.ensure((size_t)L.total * n + 8 * 4 * (size_t)DEPTH_SLOT))) return rc;
+    // the lists travel through a small ring of pinned host slots so that the upload is asynchronous (up to 8 calls may
     // be in flight on the stream before a slot is reused)
-    if (!h->depth_pinned) SVC_HIP(hipHostMalloc((void **)&h->depth_pinned, 8 * 2 * (size_t)DEPTH_SLOT, hipHostMallocDefault));
+    if (!h->depth_pinned) SVC_HIP(hipHostMalloc((void **)&h->depth_pinned, 8 * 4 * (size_t)DEPTH_SLOT, hipHostMallocDefault));
     const int slot = h->depth_slot++ & 7;
     if (h->depth_ev[slot]) SVC_HIP(hipEventSynchronize(h->depth_ev[slot]));      // the upload that last used this slot has run
     else SVC_HIP(hipEventCreateWithFlags(&h->depth_ev[slot], hipEventDisableTiming));
-    uint16_t *order_dev = (uint16_t *)((uint8_t *)h->tail_ws.p + (size_t)L.total * n + (size_t)slot * 2 * DEPTH_SLOT);
-    memcpy(h->depth_pinned + (size_t)slot * 2 * DEPTH_SLOT, order.data(), (size_t)n * 2);
-    SVC_HIP(hipMemcpyAsync(order_dev, h->depth_pinned + (size_t)slot * 2 * DEPTH_SLOT, (size_t)n * 2, hipMemcpyHostToDevice, s));
+    uint16_t *order_dev = (uint16_t *)((uint8_t *)h->tail_ws.p + (size_t)L.total * n + (size_t)slot * 4 * DEPTH_SLOT);
+    memcpy(h->depth_pinned + (size_t)slot * 4 * DEPTH_SLOT, order.data(), (size_t)n * 4);
+    SVC_HIP(hipMemcpyAsync(order_dev, h->depth_pinned + (size_t)slot * 4 * DEPTH_SLOT, (size_t)n * 4, hipMemcpyHostToDevice, s));
     SVC_HIP(hipEventRecord(h->depth_ev[slot], s));
     h->tail_frames = n; h->tail_h = height; h->tail_w = width; h->tail_frame_stride = L.total;
     TailArgs A;
@@ -1567,6 +1578,11 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
         const int m = round_start[r + 1] - round_start[r];   // maps of this round
         const uint16_t *ord = order_dev + round_start[r];
         A.order = ord;
+        if (r == 0 && !blend0.empty()) {                     // blends from held (already final) predecessors
+            k_blend<<<dim3(8, (unsigned)blend0.size()), 256, 0, s>>>(full_maps, order_dev + n, full_h * full_w);
+            SVC_CHECK_LAUNCH();
+        }
+        if (m == 0) continue;                                // every map of the call is held
         if (r > 0) {
             k_blend<<<dim3(8, m), 256, 0, s>>>(full_maps, ord, full_h * full_w);
             SVC_CHECK_LAUNCH();

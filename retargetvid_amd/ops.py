@@ -27,6 +27,9 @@ def _need_cuda(t, dtype, name):
         raise TypeError('%s must be a contiguous CUDA tensor of dtype %s' % (name, dtype))
 
 
+BLEND_NEXT, MAP_HELD = 1, 2          # bits of cluster_center_'s per-map flags (include/svc.h: SVC_BLEND_NEXT, SVC_MAP_HELD)
+
+
 class Engine:
     """Owns one SvcHandle (weights + workspace) on one GPU.  Replaces the reference's module-level
     ``unisal_model`` singleton (smartVidCrop.py:77).  Not re-entrant, like the reference."""
@@ -90,8 +93,10 @@ class Engine:
         return maps
 
     def cluster_center_(self, maps, blend_flags, CP, want_stats=False):
-        """In place on thresholded uint8 [n,h,w] maps.  blend_flags: host sequence of n bools
-        (or None).  -> xy float64 [n,2] (NaN = None) [, stats int32 [n,4]]."""
+        """In place on thresholded uint8 [n,h,w] maps.  blend_flags: host sequence of n flags (or None): True / BLEND_NEXT =
+        blend map i into map i+1 once it is final; MAP_HELD = not processed by this call (already final, or left for a
+        later one), so a blend chain can be carried over between calls.  -> xy float64 [n,2] (NaN = None; unspecified for
+        held maps) [, stats int32 [n,4]]."""
         _need_cuda(maps, torch.uint8, 'maps')
         n, h, w = maps.shape
         p = _lib.make_params(CP)

@@ -208,6 +208,36 @@ def test_graph_replay_matches_direct_launches(engine, synthetic_sd):
         other.close()
 
 
+def test_blend_chain_carried_over_between_calls(engine, golden_dir):
+    """SVC_MAP_HELD: a blend chain that straddles two calls (its last map left for the second call, the already final map
+    before it carried over as HELD | BLEND_NEXT) gives the same maps and centres as the chain in one call."""
+    CP = P.init_crop_params()
+    g = np.load(os.path.join(golden_dir, 'unisal_golden.npz'))
+    base = np.transpose(g['smaps_u8'], (2, 0, 1)).copy()
+    rng = np.random.RandomState(11)
+    maps = np.stack([np.roll(base[i % len(base)], (3 * i, 5 * i), (0, 1)) for i in range(6)])
+    maps[4] = (rng.rand(140, 250) < 0.02) * 200
+    one = torch.from_numpy(maps.copy()).cuda()
+    engine.threshold_(one, CP['t_threshold'])
+    thr = one.clone()
+    xy1 = engine.cluster_center_(one, [1, 1, 0, 0, 1, 0], CP).cpu().numpy()            # chains 0 -> 1 -> 2 and 4 -> 5
+    H, B = ops.MAP_HELD, ops.BLEND_NEXT
+    a = thr.clone()
+    xya = engine.cluster_center_(a, [B, 0, H, 0, B, H], CP).cpu().numpy()              # maps 2 and 5 left for later
+    assert torch.equal(a[[0, 1, 3, 4]], one[[0, 1, 3, 4]]) and torch.equal(a[[2, 5]], thr[[2, 5]])
+    for i in (0, 1, 3, 4):
+        assert np.array_equal(xya[i], xy1[i], equal_nan=True)
+    b = torch.stack([a[1], a[2], a[4], a[5]])                                          # (final, raw) pairs of the two chains
+    keep = b.clone()
+    xyb = engine.cluster_center_(b, [H | B, 0, H | B, 0], CP).cpu().numpy()
+    assert torch.equal(b[0], keep[0]) and torch.equal(b[2], keep[2])                   # held maps are not touched
+    assert torch.equal(b[1], one[2]) and torch.equal(b[3], one[5])
+    assert np.array_equal(xyb[1], xy1[2], equal_nan=True) and np.array_equal(xyb[3], xy1[5], equal_nan=True)
+    c = keep.clone()                                                                    # a call with held maps only is a no-op
+    engine.cluster_center_(c, [H, H, H, H], CP)
+    assert torch.equal(c, keep)
+
+
 def test_tail_bit_exact_default_settings(engine, golden_dir):
     CP = P.init_crop_params()
     g = np.load(os.path.join(golden_dir, 'unisal_golden.npz'))

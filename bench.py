@@ -15,12 +15,20 @@ then one D2H of the 32 centres and the crop-box arithmetic on the host.  Frames 
 across ranks with no data-path collective ("weak" scaling: 32 frames per GPU per step); the
 only exchange is the all_gather of the final boxes after the timed region.
 
+Every batch starts a shot: its maps 0, 1, 2 form a blend chain (each is clustered after its predecessor has been), the
+other 29 maps are independent.  In the timed loop the chain is spread over the batch's call and the next two calls ON THE
+SAME STREAM (SVC_MAP_HELD, include/svc.h: map 1 joins round 0 of the next call, map 2 round 0 of the one after), so a call
+has one tail round instead of three serial ones; the results are those of the three-round call (asserted at start-up;
+config.blend_chain says which schedule ran; BENCH_CARRY=0 / 1 select the three- / two-round forms), every batch is
+completed inside the timed region (two short calls per stream drain the carried maps), and config.one_batch_in_flight
+is the plain three-round call.
+
 Rank 0 prints ONE JSON line.  `roofline` describes the kernel class that takes the most device time
 (HIP events recorded by the library around each launch of that class, on the stream it is launched on):
   achieved / frac          algorithmic FLOPs (or bytes) of the class per step / the summed durations of its launches
                            in an UN-PIPELINED step (one batch in flight: launch durations that do not overlap anything,
                            what `rocprofv3 --kernel-trace --stats` of `bench.py --pipeline 1` shows per kernel)
-  *_in_flight              the same quotient over the events of the timed region, where several batches are in flight
+  *_in_flight              (BENCH_LIVE_PROFILE=1 only) the same quotient over the events of the timed region, where several batches are in flight
                            on their own streams: launch durations then include time shared with other streams' kernels
                            and their sum exceeds the wall clock; kept for reference, never the headline fraction
   frac_wall                algorithmic work of the class per step / ms_per_step: what the class achieves per wall-clock
@@ -234,8 +242,9 @@ def main():
     # SVC_MAP_HELD (include/svc.h) map 2 is left out of its own batch's call and clustered in round 0 of the NEXT call on
     # the same stream, next to that batch's 30 round-0 maps: two rounds per call instead of three, the same maps and
     # centres (tests/test_gpu_parity.py::test_blend_chain_carried_over_between_calls).  A batch is complete one call later;
-    # a short call per stream flushes the last ones inside the timed region.  BENCH_CARRY=0: three rounds per call.
-    CARRY = os.environ.get('BENCH_CARRY', '1') != '0' and B >= 4 and flags[:3].tolist() == [1, 1, 0] and not flags[3:].any()
+    # a short call per stream flushes the last ones inside the timed region.  BENCH_CARRY=1: this form; 0: three rounds per
+    # call; 2 (default, below): map 1 is carried over too, one round per call.
+    CARRY = os.environ.get('BENCH_CARRY', '2') != '0' and B >= 4 and flags[:3].tolist() == [1, 1, 0] and not flags[3:].any()
     HELD, BNEXT = ops.MAP_HELD, ops.BLEND_NEXT
 
     class CarrySlot:
@@ -300,7 +309,123 @@ def main():
             host_t['boxes'] += time.perf_counter() - t1
             return out, got
 
-    cslots = [CarrySlot(sl) for sl in slots] if CARRY else []
+    # BENCH_CARRY=2: map 1 is carried over as well -- it joins round 0 of the next call, map 2 round 0 of the call after
+    # that: ONE tail round per call.  Head of the buffer: A0 = final map 1 / A1 = raw map 2 of the batch two calls back,
+    # B0 = final map 0 / B1 = raw map 1 / C = raw map 2 of the previous batch.
+    CARRY2 = CARRY and os.environ.get('BENCH_CARRY', '2') == '2'
+
+    class CarrySlot2:
+        def __init__(self, sl):
+            self.sl = sl
+            self.buf = torch.empty((B + 5, 140, 250), dtype=torch.uint8, device=dev)
+            self.xy = [torch.empty((B + 5, 2), dtype=torch.float64).pin_memory() for _ in range(2)]
+            self.done = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+            self.t_start = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+            self.t_net = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+            self.timed = [False, False]
+            self.trace = None
+            self.reset()
+
+        def reset(self):
+            self.calls, self.va, self.vb = 0, False, False   # calls on this stream; is the A pair / the B triple loaded?
+            self.open1 = self.open2 = None                   # host copies of the batches that wait for map 1 + 2 / for map 2
+            self.kinds = [None, None]
+
+        def _head_flags(self):
+            return [HELD | BNEXT if self.va else HELD, 0 if self.va else HELD, HELD | BNEXT if self.vb else HELD, 0 if self.vb else HELD, HELD]
+
+        def _shift(self, with_own):
+            self.buf[0].copy_(self.buf[3]); self.buf[1].copy_(self.buf[4])     # B's map 1 is final now: it and the raw map 2 become A
+            self.va = self.vb
+            if with_own:
+                self.buf[2].copy_(self.buf[5]); self.buf[3].copy_(self.buf[6]); self.buf[4].copy_(self.buf[7])
+            self.vb = with_own
+
+        def enqueue(self):
+            k = self.calls & 1
+            fl = np.zeros(B + 5, np.uint8)
+            fl[:5] = self._head_flags()
+            fl[6], fl[7] = HELD, HELD
+            with torch.cuda.stream(self.sl.stream):
+                self.t_start[k].record(self.sl.stream)
+                small = self.sl.eng.resize_frames(frames, 140, 250)
+                self.sl.eng.saliency(small, out=self.buf[5:])
+                self.sl.eng.threshold_(self.buf[5:], CP['t_threshold'])
+                self.t_net[k].record(self.sl.stream)
+                xy = self.sl.eng.cluster_center_(self.buf, fl, CP)
+                self.xy[k].copy_(xy, non_blocking=True)
+                self.kinds[k] = ('batch', self.va, self.vb)
+                self._shift(True)
+                self.done[k].record(self.sl.stream)
+            self.timed[k] = True
+            self.calls += 1
+
+        def flush(self):
+            """A call over the head only: moves the carried maps one stage on."""
+            k = self.calls & 1
+            with torch.cuda.stream(self.sl.stream):
+                xy = self.sl.eng.cluster_center_(self.buf[:5], np.array(self._head_flags(), np.uint8), CP)
+                self.xy[k][:5].copy_(xy, non_blocking=True)
+                self.kinds[k] = ('flush', self.va, self.vb)
+                self._shift(False)
+                self.done[k].record(self.sl.stream)
+            self.timed[k] = False
+            self.calls += 1
+
+        def collect(self):
+            k = (self.calls - 1) & 1
+            t0 = time.perf_counter()
+            self.done[k].synchronize()
+            t1 = time.perf_counter()
+            host_t['wait'] += t1 - t0
+            if self.timed[k]:
+                spans['net'] += self.t_start[k].elapsed_time(self.t_net[k])
+                spans['tail'] += self.t_net[k].elapsed_time(self.done[k])
+                spans['n'] += 1
+            got = self.xy[k].numpy()
+            kind, va, vb = self.kinds[k]
+            out = None
+            if va and self.open2 is not None:
+                self.open2[2] = got[1]
+                if self.trace is not None:
+                    self.trace.append(self.open2.copy())
+                out = host_boxes(self.open2)
+                self.open2 = None
+            if vb and self.open1 is not None:
+                self.open1[1] = got[3]
+                self.open2, self.open1 = self.open1, None
+            if kind == 'batch':
+                cur = np.empty((B, 2), np.float64)
+                cur[0], cur[3:] = got[5], got[8:]
+                self.open1 = cur
+            host_t['boxes'] += time.perf_counter() - t1
+            return out
+
+    cslots = ([CarrySlot2(sl) for sl in slots] if CARRY2 else [CarrySlot(sl) for sl in slots]) if CARRY else []
+
+    def run_carry2(steps, only=None):
+        boxes = None
+        cslots_ = only or cslots
+        for cs in cslots_:
+            cs.reset()
+        for s in range(steps):
+            cs = cslots_[s % len(cslots_)]
+            if cs.calls:
+                b = cs.collect()
+                boxes = b if b is not None else boxes
+            t0 = time.perf_counter()
+            cs.enqueue()
+            host_t['enqueue'] += time.perf_counter() - t0
+        for _ in range(3):                                    # the last call, then two head-only calls that finish the carried maps
+            for cs in cslots_:
+                if cs.calls:
+                    b = cs.collect()
+                    boxes = b if b is not None else boxes
+                    if cs.va or cs.vb:
+                        cs.flush()
+        for cs in cslots_:
+            assert cs.open1 is None and cs.open2 is None and not cs.va and not cs.vb
+        return boxes
 
     def run_carry(steps):
         boxes = None
@@ -334,7 +459,16 @@ def main():
                 boxes = b if b is not None else boxes
         return boxes
 
-    if CARRY and P > 1 and rank == 0:
+    if CARRY2 and P > 1 and rank == 0:
+        slots[0].enqueue(); slots[0].finish()
+        ref_xy = slots[0].xy_host.numpy().copy()
+        seen = cslots[0].trace = []
+        run_carry2(3, only=cslots[:1])
+        cslots[0].trace = None
+        assert len(seen) == 3
+        for o in seen:
+            assert np.array_equal(o, ref_xy, equal_nan=True), 'carried-over blend chain: centres differ from the three-round call'
+    if CARRY and not CARRY2 and P > 1 and rank == 0:
         # the two schedules give the same centres: three batches through stream 0 both ways
         slots[0].enqueue(); slots[0].finish()
         ref_xy = slots[0].xy_host.numpy().copy()
@@ -358,6 +492,8 @@ def main():
         cs.calls, cs.open = 0, None
 
     def run(steps):
+        if CARRY2 and P > 1:
+            return run_carry2(steps)
         if CARRY and P > 1:
             return run_carry(steps)
         boxes = None
@@ -512,8 +648,11 @@ def main():
                                one_batch_in_flight=dict(latency_ms_per_batch=round(latency_ms, 4),
                                                         frames_per_s=round(B / latency_ms * 1e3, 1)),
                                host_ms_per_step=host_ms, batch_phase_ms_in_the_pipeline=span_ms,
-                               blend_chain=('map 2 of a batch is clustered in round 0 of the next call on its stream (SVC_MAP_HELD): '
-                                            'two tail rounds per call') if (CARRY and P > 1) else 'three tail rounds per call'),
+                               blend_chain=('three tail rounds per call' if not (CARRY and P > 1) else
+                                            'maps 1 and 2 of a batch are clustered in round 0 of the next two calls on its stream '
+                                            '(SVC_MAP_HELD): one tail round per call' if CARRY2 else
+                                            'map 2 of a batch is clustered in round 0 of the next call on its stream (SVC_MAP_HELD): '
+                                            'two tail rounds per call')),
                    roofline=roof, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if dist_on:

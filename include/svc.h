@@ -104,6 +104,11 @@ int svc_cluster_center(SvcHandle *h, uint8_t *maps_nhw, int n, int height, int w
                        const uint8_t *blend_flags_host, const SvcParams *params,
                        double *xy, int32_t *stats, void *stream);
 
+/* Test door, host only (no GPU): the rounds svc_cluster_center plans for a flag array.  round_out[i] = round in which
+ * map i is processed, -1 = held; blend0_out[i] = 1 when map i first takes a blend from a held predecessor.
+ * Returns the number of rounds (0 when every map is held) or a negative error. */
+int svc_debug_round_plan(const uint8_t *flags_host, int n, int32_t *round_out, int32_t *blend0_out);
+
 /* a[n][4], b[n][4] int32 boxes (x1,y1,x2,y2) -> out[n] float64 IoU, inclusive +1 pixel convention. */
 int svc_iou_i32(const int32_t *a, const int32_t *b, size_t n, double *out, void *stream);
 

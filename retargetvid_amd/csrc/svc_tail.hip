@@ -1459,6 +1459,44 @@ static int ensure_ring_delta(SvcHandle *h, int width, const int32_t **out) {
     return SVC_OK;
 }
 
+// The round of every map of a call: a map blended from its predecessor runs one round after it.  A HELD map (SVC_MAP_HELD)
+// is not processed at all (depth 255) -- it is final already (the tail of a chain carried over from an earlier call) or
+// left for a later call -- and a map blended from a held one runs in round 0, after the blend (listed in blend0).
+static int plan_rounds(const uint8_t *flags, int n, std::vector<uint8_t> &depth, std::vector<uint16_t> &blend0, int &maxd) {
+    const int HELD = 255;
+    depth.assign(n, 0);
+    blend0.clear();
+    maxd = 0;
+    for (int i = 0; i < n; ++i) {
+        const int fl = flags ? flags[i] : 0, fp = (flags && i > 0) ? flags[i - 1] : 0;
+        if (fl & SVC_MAP_HELD) { depth[i] = HELD; continue; }
+        if (fp & SVC_BLEND_NEXT) {
+            if (depth[i - 1] == HELD) { depth[i] = 0; blend0.push_back((uint16_t)i); }
+            else {
+                if (depth[i - 1] >= 254) { svc_set_error("svc_cluster_center: blend chain longer than 254"); return SVC_E_INVALID; }
+                depth[i] = depth[i - 1] + 1;
+                maxd = std::max(maxd, (int)depth[i]);
+            }
+        }
+    }
+    return SVC_OK;
+}
+
+// Test door (no GPU needed): the plan svc_cluster_center makes for a flag array.  round_out[i] = round of map i, -1 = held;
+// blend0_out[i] = 1 when map i first takes a blend from a held predecessor.  Returns the number of rounds.
+extern "C" int svc_debug_round_plan(const uint8_t *flags_host, int n, int32_t *round_out, int32_t *blend0_out) {
+    if (n < 0 || (n > 0 && (!round_out || !blend0_out))) { svc_set_error("svc_debug_round_plan: invalid argument"); return SVC_E_INVALID; }
+    std::vector<uint8_t> depth;
+    std::vector<uint16_t> blend0;
+    int maxd = 0;
+    const int rc = plan_rounds(flags_host, n, depth, blend0, maxd);
+    if (rc) return rc;
+    bool any = false;
+    for (int i = 0; i < n; ++i) { round_out[i] = depth[i] == 255 ? -1 : depth[i]; blend0_out[i] = 0; any = any || depth[i] != 255; }
+    for (uint16_t i : blend0) blend0_out[i] = 1;
+    return any ? maxd + 1 : 0;
+}
+
 extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height, int width,
                                   const uint8_t *blend_flags_host, const SvcParams *params, double *xy,
                                   int32_t *stats, void *stream) {
@@ -1507,25 +1545,11 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
     const int cap = height * width;
     const int mc = hdb::max_clusters(cap, params->hdbscan_min);
     FrameWS L = make_layout(cap, mc);
-    // depth (round) of every map: a map blended from its predecessor runs one round later.  A HELD map (SVC_MAP_HELD) is not
-    // processed at all -- it is final already (the tail of a chain carried over from an earlier call) or left for a later
-    // call -- and a map blended from a held one runs in round 0, after the blend.
     const int HELD = 255;
-    std::vector<uint8_t> depth(n, 0);
+    std::vector<uint8_t> depth;
     std::vector<uint16_t> blend0;                       // round-0 maps that take a blend from a held predecessor first
     int maxd = 0;
-    for (int i = 0; i < n; ++i) {
-        const int fl = blend_flags_host ? blend_flags_host[i] : 0, fp = (blend_flags_host && i > 0) ? blend_flags_host[i - 1] : 0;
-        if (fl & SVC_MAP_HELD) { depth[i] = HELD; continue; }
-        if (fp & SVC_BLEND_NEXT) {
-            if (depth[i - 1] == HELD) { depth[i] = 0; blend0.push_back((uint16_t)i); }
-            else {
-                if (depth[i - 1] >= 254) { svc_set_error("svc_cluster_center: blend chain longer than 254"); return SVC_E_INVALID; }
-                depth[i] = depth[i - 1] + 1;
-                maxd = std::max(maxd, (int)depth[i]);
-            }
-        }
-    }
+    if ((rc = plan_rounds(blend_flags_host, n, depth, blend0, maxd))) return rc;
     if (n > DEPTH_SLOT) { svc_set_error("svc_cluster_center: more than %d maps per call", DEPTH_SLOT); return SVC_E_INVALID; }
     // A round's kernels are launched over the maps of THAT round only: the list of all maps sorted by round (stable),
     // one slice per round.  (One workgroup per map of the call in every round -- 31 of 32 exiting at once in the

@@ -204,3 +204,34 @@ def test_decode_hand_off_adapter(monkeypatch):
         assert not isinstance(ei.value, NotImplementedError)
     finally:
         S.set_video_reader(None)
+
+
+def test_round_plan_of_the_cluster_filter_with_held_maps():
+    """svc_cluster_center's planner (host code of the HIP library, no GPU needed): a map blended from its predecessor runs
+    one round later; a held map (SVC_MAP_HELD) is skipped; a map blended from a held one runs in round 0 after the blend."""
+    import ctypes
+    from retargetvid_amd import _lib
+    lib = _lib.load()
+    B, H = 1, 2
+
+    def plan(flags):
+        fl = np.asarray(flags, np.uint8)
+        r, b = np.zeros(len(fl), np.int32), np.zeros(len(fl), np.int32)
+        vp = ctypes.c_void_p
+        n = lib.svc_debug_round_plan(fl.ctypes.data_as(vp), len(fl), r.ctypes.data_as(vp), b.ctypes.data_as(vp))
+        return n, r.tolist(), b.tolist()
+
+    assert plan([0, 0, 0]) == (1, [0, 0, 0], [0, 0, 0])
+    assert plan([B, B, 0, 0, B, 0]) == (3, [0, 1, 2, 0, 0, 1], [0] * 6)                 # the reference's shot start: 0 -> 1 -> 2
+    assert plan([B, 0, H, 0, B, H]) == (2, [0, 1, -1, 0, 0, -1], [0] * 6)               # the chains' last maps left for later
+    assert plan([H | B, 0, H | B, 0]) == (1, [-1, 0, -1, 0], [0, 1, 0, 1])              # ... and finished by the next call
+    assert plan([H | B, B, 0]) == (2, [-1, 0, 1], [0, 1, 0])                            # a carried chain goes on
+    assert plan([H, H]) == (0, [-1, -1], [0, 0])
+    assert plan([H | B, H, 0]) == (1, [-1, -1, 0], [0, 0, 0])                           # a held map does not pass a blend on
+    # bench.py's one-round schedule: head [A0, A1, B0, B1, C] + own maps 0 (processed), 1, 2 (held), 3 ...
+    n, r, b = plan([H | B, 0, H | B, 0, H, 0, H, H, 0, 0])
+    assert n == 1 and r == [-1, 0, -1, 0, -1, 0, -1, -1, 0, 0] and b == [0, 1, 0, 1, 0, 0, 0, 0, 0, 0]
+    assert plan([]) [0] == 0
+    assert lib.svc_debug_round_plan(np.ones(300, np.uint8).ctypes.data_as(ctypes.c_void_p), 300,
+                                    np.zeros(300, np.int32).ctypes.data_as(ctypes.c_void_p),
+                                    np.zeros(300, np.int32).ctypes.data_as(ctypes.c_void_p)) < 0      # chain too long

@@ -82,3 +82,21 @@ def test_stale_binding_is_rejected_not_over_read(engine):
         finally:
             fn.argtypes = saved
         assert rc == -1 and b'struct_size' in lib.svc_last_error()
+
+
+@pytest.mark.gpu
+def test_documented_transnet_binding_runs_and_matches_the_package(engine):
+    """the `svc_transnet.py` block, executed as written against the built library."""
+    from retargetvid_amd import transnetv1_handler as Hd
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    m = re.search(r'```python\n(# svc_transnet\.py.*?)```', text, flags=re.S)
+    assert m, 'INTEGRATION.md no longer holds the svc_transnet.py block'
+    mod = types.ModuleType('svc_transnet')
+    exec(compile(m.group(1), 'INTEGRATION.md:svc_transnet.py', 'exec'), mod.__dict__)
+    sd = weights.make_transnet_state_dict(2)
+    lib = _lib.load()
+    net = mod.ShotTransNetHIP(lib, engine._h, np.ascontiguousarray(weights.pack_transnet_blob(sd)))
+    fr = np.random.RandomState(3).randint(0, 256, (2, 30, 27, 48, 3)).astype(np.uint8)
+    got = net.predict_raw(fr)
+    ref_net = Hd.ShotTransNet(Hd.ShotTransNetParams(), weights=sd, engine=engine)
+    assert got.shape == (2, 30) and np.array_equal(got, ref_net.predict_raw(fr))

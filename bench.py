@@ -335,10 +335,10 @@ def main():
             return [HELD | BNEXT if self.va else HELD, 0 if self.va else HELD, HELD | BNEXT if self.vb else HELD, 0 if self.vb else HELD, HELD]
 
         def _shift(self, with_own):
-            self.buf[0].copy_(self.buf[3]); self.buf[1].copy_(self.buf[4])     # B's map 1 is final now: it and the raw map 2 become A
+            self.buf[0:2].copy_(self.buf[3:5])               # B's map 1 is final now: it and the raw map 2 become A
             self.va = self.vb
             if with_own:
-                self.buf[2].copy_(self.buf[5]); self.buf[3].copy_(self.buf[6]); self.buf[4].copy_(self.buf[7])
+                self.buf[2:5].copy_(self.buf[5:8])           # the batch's final map 0 and raw maps 1, 2 become B and C
             self.vb = with_own
 
         def enqueue(self):

@@ -19,7 +19,7 @@ Every batch starts a shot: its maps 0, 1, 2 form a blend chain (each is clustere
 other 29 maps are independent.  In the timed loop the chain is spread over the batch's call and the next two calls ON THE
 SAME STREAM (SVC_MAP_HELD, include/svc.h: map 1 joins round 0 of the next call, map 2 round 0 of the one after), so a call
 has one tail round instead of three serial ones; the results are those of the three-round call (asserted at start-up;
-config.blend_chain says which schedule ran; BENCH_CARRY=0 / 1 select the three- / two-round forms), every batch is
+config.blend_chain says which schedule ran; BENCH_CARRY=0 selects the three-round form), every batch is
 completed inside the timed region (two short calls per stream drain the carried maps), and config.one_batch_in_flight
 is the plain three-round call.
 
@@ -236,85 +236,20 @@ def main():
     slots = [Slot() for _ in range(P)]
     torch.cuda.synchronize()
 
-    # ---- the timed path: the blend chain's last map is carried over ----------------------------------------------------
+    # ---- the timed path: the blend chain is spread over three calls of a stream -------------------------------------------
     # A batch that starts a shot costs its stream three serial tail rounds, two of them for ONE map each (maps 1 and 2 of
     # the chain 0 -> 1 -> 2), and with four batches in flight the step time is (network phase + tail phase) / 4.  With
-    # SVC_MAP_HELD (include/svc.h) map 2 is left out of its own batch's call and clustered in round 0 of the NEXT call on
-    # the same stream, next to that batch's 30 round-0 maps: two rounds per call instead of three, the same maps and
-    # centres (tests/test_gpu_parity.py::test_blend_chain_carried_over_between_calls).  A batch is complete one call later;
-    # a short call per stream flushes the last ones inside the timed region.  BENCH_CARRY=1: this form; 0: three rounds per
-    # call; 2 (default, below): map 1 is carried over too, one round per call.
-    CARRY = os.environ.get('BENCH_CARRY', '2') != '0' and B >= 4 and flags[:3].tolist() == [1, 1, 0] and not flags[3:].any()
+    # SVC_MAP_HELD (include/svc.h) maps 1 and 2 are left out of their own batch's call: map 1 is clustered in round 0 of
+    # the NEXT call on the same stream, map 2 in round 0 of the call after that, next to those batches' 30 round-0 maps --
+    # ONE tail round per call, the same maps and centres (tests/test_gpu_parity.py::
+    # test_blend_chain_carried_over_between_calls; asserted below against the three-round call).  A batch is complete
+    # two calls later; two head-only calls per stream finish the last ones inside the timed region.
+    # Head of a stream's buffer: A0 = final map 1 / A1 = raw map 2 of the batch two calls back, B0 = final map 0 / B1 = raw
+    # map 1 / C = raw map 2 of the previous batch; then the batch's 32 maps.  BENCH_CARRY=0: three rounds per call.
+    CARRY = os.environ.get('BENCH_CARRY', '1') != '0' and B >= 4 and flags[:3].tolist() == [1, 1, 0] and not flags[3:].any()
     HELD, BNEXT = ops.MAP_HELD, ops.BLEND_NEXT
 
     class CarrySlot:
-        def __init__(self, sl):
-            self.sl = sl
-            self.buf = torch.empty((B + 2, 140, 250), dtype=torch.uint8, device=dev)     # [carried final map 1, carried raw map 2, the batch's 32 maps]
-            self.xy = [torch.empty((B + 2, 2), dtype=torch.float64).pin_memory() for _ in range(2)]
-            self.done = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
-            self.t_start = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
-            self.t_net = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
-            self.timed = [False, False]
-            self.calls = 0              # calls enqueued on this stream
-            self.open = None            # xy of the batch whose map 2 is still to come (host copy)
-
-        def enqueue(self):
-            k = self.calls & 1
-            first = self.calls == 0
-            fl = np.zeros(B + 2, np.uint8)
-            fl[0] = HELD if first else (HELD | BNEXT)
-            fl[1] = HELD if first else 0
-            fl[2], fl[4] = BNEXT, HELD
-            with torch.cuda.stream(self.sl.stream):
-                self.t_start[k].record(self.sl.stream)
-                small = self.sl.eng.resize_frames(frames, 140, 250)
-                self.sl.eng.saliency(small, out=self.buf[2:])
-                self.sl.eng.threshold_(self.buf[2:], CP['t_threshold'])
-                self.t_net[k].record(self.sl.stream)
-                self.timed[k] = True
-                xy = self.sl.eng.cluster_center_(self.buf, fl, CP)
-                self.xy[k].copy_(xy, non_blocking=True)
-                self.buf[0].copy_(self.buf[3])               # the final map 1 and the raw map 2 of this batch: the next call's head
-                self.buf[1].copy_(self.buf[4])
-                self.done[k].record(self.sl.stream)
-            self.calls += 1
-
-        def flush(self):
-            k = self.calls & 1
-            with torch.cuda.stream(self.sl.stream):
-                self.timed[k] = False
-                xy = self.sl.eng.cluster_center_(self.buf[:2], np.array([HELD | BNEXT, 0], np.uint8), CP)
-                self.xy[k][:2].copy_(xy, non_blocking=True)
-                self.done[k].record(self.sl.stream)
-            self.calls += 1
-
-        def collect(self):
-            """Wait for the newest call; -> boxes of the batch it completes (or None)."""
-            k = (self.calls - 1) & 1
-            t0 = time.perf_counter()
-            self.done[k].synchronize()
-            t1 = time.perf_counter()
-            host_t['wait'] += t1 - t0
-            if self.timed[k]:
-                spans['net'] += self.t_start[k].elapsed_time(self.t_net[k])
-                spans['tail'] += self.t_net[k].elapsed_time(self.done[k])
-                spans['n'] += 1
-            got = self.xy[k].numpy()
-            out = None
-            if self.open is not None:
-                self.open[2] = got[1]                        # map 2 of the previous batch on this stream
-                out = host_boxes(self.open)
-                self.open = None
-            host_t['boxes'] += time.perf_counter() - t1
-            return out, got
-
-    # BENCH_CARRY=2: map 1 is carried over as well -- it joins round 0 of the next call, map 2 round 0 of the call after
-    # that: ONE tail round per call.  Head of the buffer: A0 = final map 1 / A1 = raw map 2 of the batch two calls back,
-    # B0 = final map 0 / B1 = raw map 1 / C = raw map 2 of the previous batch.
-    CARRY2 = CARRY and os.environ.get('BENCH_CARRY', '2') == '2'
-
-    class CarrySlot2:
         def __init__(self, sl):
             self.sl = sl
             self.buf = torch.empty((B + 5, 140, 250), dtype=torch.uint8, device=dev)
@@ -401,9 +336,9 @@ def main():
             host_t['boxes'] += time.perf_counter() - t1
             return out
 
-    cslots = ([CarrySlot2(sl) for sl in slots] if CARRY2 else [CarrySlot(sl) for sl in slots]) if CARRY else []
+    cslots = [CarrySlot(sl) for sl in slots] if CARRY else []
 
-    def run_carry2(steps, only=None):
+    def run_carry(steps, only=None):
         boxes = None
         cslots_ = only or cslots
         for cs in cslots_:
@@ -427,73 +362,16 @@ def main():
             assert cs.open1 is None and cs.open2 is None and not cs.va and not cs.vb
         return boxes
 
-    def run_carry(steps):
-        boxes = None
-        for cs in cslots:
-            cs.calls, cs.open = 0, None
-        busy = [False] * P
-        for s in range(steps):
-            cs = cslots[s % P]
-            if busy[s % P]:
-                b, got = cs.collect()
-                boxes = b if b is not None else boxes
-                cur = np.empty((B, 2), np.float64)
-                cur[:2], cur[3:] = got[2:4], got[5:]
-                cs.open = cur
-            t0 = time.perf_counter()
-            cs.enqueue()
-            busy[s % P] = True
-            host_t['enqueue'] += time.perf_counter() - t0
-        for i, cs in enumerate(cslots):                       # the last call of every stream, then its held map 2
-            if not busy[i]:
-                continue
-            b, got = cs.collect()
-            boxes = b if b is not None else boxes
-            cur = np.empty((B, 2), np.float64)
-            cur[:2], cur[3:] = got[2:4], got[5:]
-            cs.open = cur
-            cs.flush()
-        for i, cs in enumerate(cslots):
-            if busy[i]:
-                b, _ = cs.collect()
-                boxes = b if b is not None else boxes
-        return boxes
-
-    if CARRY2 and P > 1 and rank == 0:
+    if CARRY and P > 1 and rank == 0:
         slots[0].enqueue(); slots[0].finish()
         ref_xy = slots[0].xy_host.numpy().copy()
         seen = cslots[0].trace = []
-        run_carry2(3, only=cslots[:1])
+        run_carry(3, only=cslots[:1])
         cslots[0].trace = None
         assert len(seen) == 3
         for o in seen:
             assert np.array_equal(o, ref_xy, equal_nan=True), 'carried-over blend chain: centres differ from the three-round call'
-    if CARRY and not CARRY2 and P > 1 and rank == 0:
-        # the two schedules give the same centres: three batches through stream 0 both ways
-        slots[0].enqueue(); slots[0].finish()
-        ref_xy = slots[0].xy_host.numpy().copy()
-        cs = cslots[0]
-        outs = []
-        for _ in range(3):
-            cs.enqueue()
-            _, got = cs.collect()
-            if cs.open is not None:
-                pass
-            cur = np.empty((B, 2), np.float64)
-            cur[:2], cur[3:] = got[2:4], got[5:]
-            if outs:
-                outs[-1][2] = got[1]
-            outs.append(cur)
-        cs.flush()
-        _, got = cs.collect()
-        outs[-1][2] = got[1]
-        for o in outs:
-            assert np.array_equal(o, ref_xy, equal_nan=True), 'carried-over blend chain: centres differ from the three-round call'
-        cs.calls, cs.open = 0, None
-
     def run(steps):
-        if CARRY2 and P > 1:
-            return run_carry2(steps)
         if CARRY and P > 1:
             return run_carry(steps)
         boxes = None
@@ -650,9 +528,7 @@ def main():
                                host_ms_per_step=host_ms, batch_phase_ms_in_the_pipeline=span_ms,
                                blend_chain=('three tail rounds per call' if not (CARRY and P > 1) else
                                             'maps 1 and 2 of a batch are clustered in round 0 of the next two calls on its stream '
-                                            '(SVC_MAP_HELD): one tail round per call' if CARRY2 else
-                                            'map 2 of a batch is clustered in round 0 of the next call on its stream (SVC_MAP_HELD): '
-                                            'two tail rounds per call')),
+                                            '(SVC_MAP_HELD): one tail round per call')),
                    roofline=roof, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if dist_on:

@@ -26,6 +26,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// a += x * w on four channels as two packed fp32 FMAs (v_pk_fma_f32: two lanes' worth of fused multiply-adds per
+// instruction; the same fma per element as fmaf, so the depthwise sums do not change)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fma4(float4 &a, const float4 x, const float4 w) {
+    const f32x2 lo = __builtin_elementwise_fma((f32x2){x.x, x.y}, (f32x2){w.x, w.y}, (f32x2){a.x, a.y});
+    const f32x2 hi = __builtin_elementwise_fma((f32x2){x.z, x.w}, (f32x2){w.z, w.w}, (f32x2){a.z, a.w});
+    a = make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
 // --------------------------------------------------------------------------------------
 // error string
 // --------------------------------------------------------------------------------------
@@ -576,12 +585,7 @@ __global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
             for (int kx = 0; kx < 3; ++kx) {
                 const float4 w = wd[ky * 3 + kx];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    a4[i].x = fmaf(xv[i + kx].x, w.x, a4[i].x);
-                    a4[i].y = fmaf(xv[i + kx].y, w.y, a4[i].y);
-                    a4[i].z = fmaf(xv[i + kx].z, w.z, a4[i].z);
-                    a4[i].w = fmaf(xv[i + kx].w, w.w, a4[i].w);
-                }
+                for (int i = 0; i < 4; ++i) fma4(a4[i], xv[i + kx], w);
             }
         }
 #pragma unroll
@@ -1853,11 +1857,7 @@ __global__ __launch_bounds__(64 * NWV) void k_dwpw(const float *__restrict__ X, 
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const float4 x = row[j + kx], ww = w[ky * 3 + kx];
-                        o[j].x = fmaf(x.x, ww.x, o[j].x);
-                        o[j].y = fmaf(x.y, ww.y, o[j].y);
-                        o[j].z = fmaf(x.z, ww.z, o[j].z);
-                        o[j].w = fmaf(x.w, ww.w, o[j].w);
+                        fma4(o[j], row[j + kx], w[ky * 3 + kx]);
                     }
             }
             const float4 b = *(const float4 *)(bd + cc);
@@ -2273,14 +2273,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) {
                             const float4 wk = w[ky * 3 + kx];
-                            a0.x = fmaf(x[kx].x, wk.x, a0.x);
-                            a0.y = fmaf(x[kx].y, wk.y, a0.y);
-                            a0.z = fmaf(x[kx].z, wk.z, a0.z);
-                            a0.w = fmaf(x[kx].w, wk.w, a0.w);
-                            a1.x = fmaf(x[kx + S].x, wk.x, a1.x);
-                            a1.y = fmaf(x[kx + S].y, wk.y, a1.y);
-                            a1.z = fmaf(x[kx + S].z, wk.z, a1.z);
-                            a1.w = fmaf(x[kx + S].w, wk.w, a1.w);
+                            fma4(a0, x[kx], wk);
+                            fma4(a1, x[kx + S], wk);
                         }
                     }
                     const float4 b = *(const float4 *)(Bds + c);

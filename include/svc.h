@@ -66,8 +66,10 @@ typedef struct SvcParams {
 const char *svc_last_error(void);
 
 /* ABI revision of the loaded library (bumped whenever a struct layout or a signature changes); a binding
- * checks it once after dlopen.  2 = SvcParams starts with struct_size and carries resize_factor. */
-#define SVC_ABI_VERSION 2
+ * checks it once after dlopen.  2 = SvcParams starts with struct_size and carries resize_factor.
+ * 3 = SVC_MAP_HELD is honoured by svc_cluster_center (a v2 library ignores the bit), svc_debug_cluster_state
+ *     returns 32 header words, svc_debug_round_plan / svc_debug_argsort_u32 / svc_transnet_* exist. */
+#define SVC_ABI_VERSION 3
 int svc_abi_version(void);
 
 /* weights_blob_host: the packed, BN-folded static SALICON slice of a UNISAL
@@ -140,9 +142,10 @@ int svc_profile_read(SvcHandle *h, double *total_ms, int *launches);
  *   core_host[cap]  core distances (squared)
  *   mst_host[cap][3] MST edges in Prim order: from, to, weight
  *   labels_host[cap] final labels (-1 = noise)
- *   hdr_host[16]    frame header: [0] points, [1] clusters selected, [2] cluster kept, [3] clustered,
+ *   hdr_host[32]    frame header: [0] points, [1] clusters selected, [2] cluster kept, [3] clustered,
  *                   [4] condensed clusters, [8..11] k_finish phase stamps in 10 ns units
- *                   (sorted, hierarchy built, cluster chosen, done)
+ *                   (sorted, hierarchy built, cluster chosen, done), [12] Prim duration,
+ *                   [16] rounds and [17] level rises of k_prim_lvl, [18..22] its phase sums (10 ns units)
  * Returns the number of points of that frame (or a negative error). */
 int svc_debug_cluster_state(SvcHandle *h, int frame, int cap, uint32_t *pts_host, uint32_t *core_host,
                             uint32_t *mst_host, int32_t *labels_host, int32_t *hdr_host);

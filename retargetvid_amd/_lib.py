@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SVC_LIB') or os.path.join(_HERE, 'libsvc_hip.so')      # SVC_LIB: another build of the same ABI (A/B runs)
 
-ABI_VERSION = 2          # include/svc.h SVC_ABI_VERSION this binding was written against
+ABI_VERSION = 3          # include/svc.h SVC_ABI_VERSION this binding was written against
 
 EXPORTS = ('svc_last_error', 'svc_abi_version', 'svc_create', 'svc_destroy', 'svc_resize_frames_u8', 'svc_saliency_u8',
            'svc_threshold_u8', 'svc_cluster_center', 'svc_iou_i32', 'svc_debug_cluster_state', 'svc_debug_tap', 'svc_front_fused', 'svc_debug_round_plan', 'svc_transnet_load', 'svc_transnet_predict',

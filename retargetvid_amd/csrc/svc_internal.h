@@ -104,6 +104,7 @@ struct SvcHandle {
     // tail workspace (svc_tail.hip)
     DevBuf tail_ws;
     DevBuf tail_offsets;     // ring-walk offset table
+    DevBuf tail_ring_cnt;    // u16[RING_R^2 + 1]: number of offsets with d2 <= index
     int tail_n_offsets = 0, tail_n_offsets1 = 0;
     std::vector<uint32_t> tail_offsets_host;
     std::map<int, DevBuf> tail_delta;  // dr * width + dc of every offset, one table per map width (never rewritten:
@@ -140,7 +141,8 @@ struct SvcHandle {
     bool dwpw = true;                  // depthwise 3x3 fused into the following 1x1 project (SVC_DWPW=0: two kernels)
     int dwpw_min_px = 400;             // ... on levels with at least this many pixels per frame; the 8x13 level has too few patches (SVC_DWPW_MIN_PX)
     int dw_tile = 42;                  // stride-1 depthwise: outputs per thread as TX*10+TY (SVC_DW_TILE: 21, 22, 41, 42, 44; 0 = one output per thread)
-    int prim_pt = 2;                   // k_prim: smallest points-per-thread variant (SVC_PRIM_PT: 2, 4, 8, 16)
+    int prim_pt = 2;                   // legacy Prim (k_prim_pt): smallest points-per-thread variant (SVC_PRIM_PT: 2, 4, 8, 16)
+    int prim_lvl = 1;                  // level-bucketed Prim k_prim_lvl for maps of up to 8192 points (SVC_PRIM_LVL=0: one node per step)
     // TransNet V1 (svc_shot.hip)
     DevBuf shot_blob, shot_ws;
     bool shot_loaded = false;

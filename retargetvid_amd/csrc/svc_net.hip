@@ -2834,6 +2834,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->shot_form = atoi(env);
     env = getenv("SVC_PRIM_PT");
     if (env && atoi(env) > 0) h->prim_pt = atoi(env);
+    env = getenv("SVC_PRIM_LVL");
+    if (env) h->prim_lvl = atoi(env) != 0;
     int rc = h->blob.ensure(n_bytes);
     if (rc) { delete h; return rc; }
     if (hipMemcpy(h->blob.p, blob_host, n_bytes, hipMemcpyHostToDevice) != hipSuccess) {
@@ -2954,6 +2956,7 @@ extern "C" int svc_destroy(SvcHandle *h) {
     svc_net_release(h);
     h->tail_ws.release();
     h->tail_offsets.release();
+    h->tail_ring_cnt.release();
     for (auto &kv : h->tail_delta) kv.second.release();
     h->stem_wt.release();
     h->shot_blob.release();

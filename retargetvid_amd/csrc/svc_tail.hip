@@ -34,7 +34,7 @@
 // per-frame workspace layout (all offsets in bytes from the frame base)
 // --------------------------------------------------------------------------------------
 struct FrameWS {
-    uint32_t hdr;        // int32[16]: [0]=N  [1]=nsel  [2]=kept cluster  [3]=clustered flag
+    uint32_t hdr;        // int32[32]: [0]=N  [1]=nsel  [2]=kept cluster  [3]=clustered flag  [16],[17]=k_prim_lvl rounds, rises
     uint32_t pts;        // u32[cap]   row | col<<8 | value<<16
     uint32_t core;       // u32[cap]
     uint32_t mst;        // Edge[cap]  Prim order
@@ -51,7 +51,7 @@ static FrameWS make_layout(int cap, int mc) {
     FrameWS L;
     uint32_t o = 0;
     auto take = [&](size_t bytes) { uint32_t r = o; o += (uint32_t)((bytes + 63) / 64 * 64); return r; };
-    L.hdr = take(64);
+    L.hdr = take(128);
     L.pts = take(4u * cap); L.core = take(4u * cap);
     L.mst = take(8u * cap); L.ea = take(8u * cap); L.eb = take(8u * cap);
     L.labels = take(4u * cap); L.reach = take(4u * cap); L.srt = take(16u * cap + 128);
@@ -79,6 +79,8 @@ struct TailArgs {
     const uint32_t *ring;   // sorted neighbour offsets
     const int32_t *ring_delta;  // dr * w + dc of the same offsets
     int n_ring, n_ring1;    // all offsets within RING_R / the prefix within RING_R1
+    const uint16_t *ring_cnt;   // [RING_R^2 + 1]: offsets with d2 <= index
+    int prim_lvl;           // 1: k_prim_lvl for maps of up to LVL_CAP points (SVC_PRIM_LVL)
     double *xy;
     int32_t *stats;
     FrameWS L;
@@ -99,6 +101,13 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T *carve(uint8_t *&p, size_t count) {
+    T *r = (T *)p;
+    p += (count * sizeof(T) + 15) / 16 * 16;
+    return r;
 }
 
 // exclusive prefix sum of one int per thread over the 1024-thread block; total in *tot
@@ -593,29 +602,429 @@ __device__ __forceinline__ void prim_global(const uint32_t *__restrict__ core_g,
     }
 }
 
-__global__ __launch_bounds__(TB) void k_prim(TailArgs A) {
+// The register-resident variant (points per thread) the legacy Prim uses for a map of N points: the first of 2, 4, 8
+// that holds N and is >= the handle's SVC_PRIM_PT, else 16 / 32, else 0 = the global-memory form.
+__device__ __forceinline__ int prim_variant(int N, int pt) {
+    if (N <= 2 * TB && pt <= 2) return 2;
+    if (N <= 4 * TB && pt <= 4) return 4;
+    if (N <= 8 * TB && pt <= 8) return 8;
+    if (N <= 16 * TB) return 16;
+    if (N <= 32 * TB) return 32;
+    return 0;
+}
+
+struct PrimFrame {
+    uint8_t *ws; int N; uint16_t *rc16; unsigned long long *slots;
+    const uint32_t *core; hdb::Edge *mst;
+};
+// common prologue of the legacy kernels: false = nothing to do for this map
+__device__ __forceinline__ bool prim_frame(const TailArgs &A, uint8_t *sm, PrimFrame &P, int n_min) {
+    const int f = A.order[blockIdx.x];
+    P.ws = A.ws + (size_t)f * A.ws_stride;
+    const int32_t *hdr = (const int32_t *)(P.ws + A.L.hdr);
+    if (!hdr[3]) return false;
+    P.N = hdr[0];
+    if (P.N <= n_min) return false;
+    P.slots = (unsigned long long *)sm;                               // [2][NW16] (uint4 or u64)
+    P.rc16 = (uint16_t *)(sm + 2 * NW16 * 16);                        // [N]
+    P.core = (const uint32_t *)(P.ws + A.L.core);
+    P.mst = (hdb::Edge *)(P.ws + A.L.mst);
+    return true;
+}
+__device__ __forceinline__ void prim_stage_points(const TailArgs &A, const PrimFrame &P) {
+    const uint32_t *pts = (const uint32_t *)(P.ws + A.L.pts);
+    for (int p = threadIdx.x; p < P.N; p += TB) P.rc16[p] = (uint16_t)(pts[p] & 0xFFFFu);
+    __syncthreads();
+}
+
+// Legacy Prim (one node per step), one kernel per register-resident variant so that each has its own register
+// budget: k_prim_pt<2|4|8> carry no private segment (profiles/r03_kernel_resources.txt); launched back to back, a
+// map is taken by the kernel whose variant it is.  n_min: maps of at most n_min points are left to k_prim_lvl.
+template <int PT>
+__global__ __launch_bounds__(TB) void k_prim_pt(TailArgs A, int n_min) {
+    extern __shared__ uint8_t sm_prim[];
+    PrimFrame P;
+    if (!prim_frame(A, sm_prim, P, n_min)) return;
+    if (prim_variant(P.N, A.prim_pt) != PT) return;
+    prim_stage_points(A, P);
+    const long long t0 = wall_clock64();
+    prim_regs32<PT>(P.core, P.mst, P.N, P.rc16, (uint4 *)P.slots);
+    if (threadIdx.x == 0) ((int32_t *)(P.ws + A.L.hdr))[12] = (int)(wall_clock64() - t0);
+}
+
+// maps of more than 8192 points: 16 / 32 points per thread (these spill: the price of N up to 32768 in registers) or
+// reachability in global memory
+__global__ __launch_bounds__(TB) void k_prim_big(TailArgs A, int n_min) {
+    extern __shared__ uint8_t sm_prim[];
+    PrimFrame P;
+    if (!prim_frame(A, sm_prim, P, n_min)) return;
+    const int v = prim_variant(P.N, A.prim_pt);
+    if (v != 16 && v != 32 && v != 0) return;
+    prim_stage_points(A, P);
+    const long long t0 = wall_clock64();
+    if (v == 16) prim_regs32<16>(P.core, P.mst, P.N, P.rc16, (uint4 *)P.slots);
+    else if (v == 32) prim_regs32<32>(P.core, P.mst, P.N, P.rc16, (uint4 *)P.slots);
+    else prim_global(P.core, (uint32_t *)(P.ws + A.L.reach), P.mst, P.N, P.rc16, P.slots);
+    if (threadIdx.x == 0) ((int32_t *)(P.ws + A.L.hdr))[12] = (int)(wall_clock64() - t0);
+}
+
+// --------------------------------------------------------------------------------------
+// k_prim_lvl: the same Prim -- identical (last node, new node, weight) sequence -- emitted in ROUNDS of up to 64
+// nodes (tools/sim/prim_levels.py is the executable specification, checked against oracle/hdbscan_ref.prim_mst).
+//
+// On a pixel grid the mutual-reachability weights are small integers and the library's Prim spends nearly all of its
+// N - 1 steps on plateaus: the minimum reach m of the points outside the tree stays put while the points of reach m
+// are taken in index order (first minimum wins).  State: the level m; F = bitmap (by point index) of the points
+// outside the tree whose reach is m; R = each point's exact reach against the first `done` tree nodes, in registers,
+// caught up only when the level has to rise.
+//   round   the first 64 members of F, f1 < f2 < ..., are candidates.  Candidate i probes the grid disc d2 <= m around
+//           itself through the occupancy bitmap (cell -> point index = prefix count + popcount): a point outside
+//           the tree with mr = max(d2, core_j, core_i) < m is a DROP (once f_i is in the tree the level falls), one
+//           with mr == m that is not in F is an ENTRANT.  Adding f1..fi leaves f(i+1) the library's next pick iff
+//           there was no drop and no entrant so far has a smaller index than f(i+1): the accepted prefix ends at the
+//           first i that breaks this (a prefix minimum over the candidates' lowest entrants).
+//   commit  accepted nodes get their edges (weight m), join the tree (top bit of their core distance), leave F;
+//           their entrants join F.  After a drop F is rebuilt from the last node's disc at the new, lower level.
+//   rise    F empty: every thread relaxes its points against the nodes added since the last rise (all pairs, but in
+//           bulk: one broadcast LDS read per node, 4 VALU per point), m = block minimum, F = {R == m}.
+//   m > RING_R^2 (jumps between far-apart blobs): one node per round, then a rise -- the legacy algorithm's step.
+// Golden maps (N = 660 .. 2 980): 28 .. 81 rounds and 6 .. 15 rises per map instead of N - 1 steps.
+// --------------------------------------------------------------------------------------
+#define LVL_CAP 8192                   // points per map (above: k_prim_big)
+#define LVL_PT (LVL_CAP / TB)
+#define LVL_TREE 0x80000000u
+#define LVL_NONE 0xFFFFFFFFu
+#define LVL_RINF 0x7FFFFFFFu
+#define LVL_RING2 (RING_R * RING_R)
+
+struct OccW { unsigned long long bits; uint32_t base, pad; };          // 64 grid cells: occupancy, points before them
+typedef short lvl_s2 __attribute__((ext_vector_type(2)));
+
+static size_t lvl_lds_bytes(int hw, int n_ring) {
+    const size_t cap = (size_t)std::min(hw, LVL_CAP);
+    auto up = [](size_t b) { return (b + 15) / 16 * 16; };
+    return up((size_t)((hw + 63) / 64) * sizeof(OccW)) + up(cap * 8) + up(cap * 4) + up((cap + 63) / 64 * 8) +
+           up((size_t)n_ring * 4) + up(cap * 2) + up(NW16 * 64 * 4) + up(64 * 8) + up(NW16 * 4) + 64;
+}
+
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int j) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, j);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), j);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// inclusive prefix minimum over the 64 lanes (the scan wave_min_u32 ends with a readlane of)
+__device__ __forceinline__ uint32_t wave_prefix_min_u32(uint32_t v) {
+    v = dpp_min_u32<0x111, 0xF>(v);
+    v = dpp_min_u32<0x112, 0xF>(v);
+    v = dpp_min_u32<0x114, 0xF>(v);
+    v = dpp_min_u32<0x118, 0xF>(v);
+    v = dpp_min_u32<0x142, 0xA>(v);
+    v = dpp_min_u32<0x143, 0xC>(v);
+    return v;
+}
+
+struct LvlLds {
+    OccW *occ; uint2 *tnode; uint32_t *corei; unsigned long long *F; uint32_t *ring; uint16_t *rc;
+    uint32_t *candw; uint2 *slot; uint32_t *red;
+};
+
+// The discs d2 <= level around up to NC points at once (the same ring offsets serve all of them; their dependent LDS
+// reads -- occupancy word, then core distance and F word of the point found -- are issued side by side).
+//   MARK = false: per point, dmin = smallest mr below the level (a drop), nmin = lowest index with mr == level outside
+//                 F (an entrant); both reduced over the wavefront.
+//   MARK = true:  F |= the points outside the tree whose mr is exactly `level` (tree members carry the top bit in
+//                 their core distance, so their mr is never equal to a level).
+template <int NC, bool MARK>
+__device__ __forceinline__ void lvl_discs(const LvlLds &S, const TailArgs &A, const uint32_t (&fi)[NC], int nc, uint32_t level,
+                                          uint32_t (&dmin)[NC], uint32_t (&nmin)[NC]) {
+    const int lane = threadIdx.x & 63;
+    int r[NC], c[NC];
+    uint32_t ci[NC];
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+        const uint32_t f0 = u < nc ? fi[u] : 0u;
+        const uint32_t v = S.rc[f0];
+        r[u] = v & 255; c[u] = v >> 8;
+        ci[u] = S.corei[f0] & ~LVL_TREE;
+        dmin[u] = nmin[u] = LVL_NONE;
+    }
+    const int nk = A.ring_cnt[level];
+    for (int base = 0; base < nk; base += 64) {
+        const int k = base + lane;
+        const bool valid = k < nk;
+        const uint32_t o = S.ring[valid ? k : 0];
+        const int dr = (int)(o & 255) - 128, dc = (int)((o >> 8) & 255) - 128;
+        OccW ow[NC];
+        int b[NC];
+        bool in[NC];
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+            const int rr = r[u] + dr, cc = c[u] + dc;
+            in[u] = valid && u < nc && (unsigned)rr < (unsigned)A.h && (unsigned)cc < (unsigned)A.w;
+            const int cell = in[u] ? rr * A.w + cc : 0;
+            b[u] = cell & 63;
+            ow[u] = S.occ[cell >> 6];
+        }
+        uint32_t j[NC], cj[NC];
+        unsigned long long fw[NC];
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+            in[u] = in[u] && ((ow[u].bits >> b[u]) & 1ull);
+            j[u] = in[u] ? ow[u].base + (uint32_t)__popcll(ow[u].bits & ((1ull << b[u]) - 1ull)) : 0u;
+            cj[u] = S.corei[j[u]];
+            if (!MARK) fw[u] = S.F[j[u] >> 6];
+        }
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+            const uint32_t mr = max(max(o >> 16, cj[u]), ci[u]);
+            if (MARK) {
+                if (in[u] && mr == level) atomicOr(&S.F[j[u] >> 6], 1ull << (j[u] & 63));
+            } else if (in[u]) {
+                if (mr < level) dmin[u] = min(dmin[u], mr);
+                else if (mr == level && !((fw[u] >> (j[u] & 63)) & 1ull)) nmin[u] = min(nmin[u], j[u]);
+            }
+        }
+    }
+    if (!MARK) {
+#pragma unroll
+        for (int u = 0; u < NC; ++u) { dmin[u] = wave_min_u32(dmin[u]); nmin[u] = wave_min_u32(nmin[u]); }
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
     const int f = A.order[blockIdx.x];
     uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
-    const int32_t *hdr = (const int32_t *)(ws + A.L.hdr);
+    int32_t *hdr = (int32_t *)(ws + A.L.hdr);
     if (!hdr[3]) return;
     const int N = hdr[0];
-    extern __shared__ uint8_t sm_prim[];
-    unsigned long long *slots = (unsigned long long *)sm_prim;       // [2][NW16] (uint4 or u64)
-    uint16_t *rc16 = (uint16_t *)(sm_prim + 2 * NW16 * 16);          // [N]
+    if (N > LVL_CAP) return;                                          // k_prim_big takes it
+    extern __shared__ uint8_t sm_lvl[];
+    __shared__ int lds16[NW16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hw = A.h * A.w, nocc = (hw + 63) >> 6, NFW = (N + 63) >> 6;
+    const int cap = min(hw, LVL_CAP);
+    LvlLds S;
+    {
+        uint8_t *p = sm_lvl;
+        S.occ = carve<OccW>(p, nocc);
+        S.tnode = carve<uint2>(p, cap);
+        S.corei = carve<uint32_t>(p, cap);
+        S.F = carve<unsigned long long>(p, (cap + 63) / 64);
+        S.ring = carve<uint32_t>(p, A.n_ring);
+        S.rc = carve<uint16_t>(p, cap);
+        S.candw = carve<uint32_t>(p, NW16 * 64);
+        S.slot = carve<uint2>(p, 64);
+        S.red = carve<uint32_t>(p, NW16);
+    }
+    const long long t0 = wall_clock64();
     const uint32_t *pts = (const uint32_t *)(ws + A.L.pts);
-    for (int p = threadIdx.x; p < N; p += TB) rc16[p] = (uint16_t)(pts[p] & 0xFFFFu);
-    __syncthreads();
-    const uint32_t *core = (const uint32_t *)(ws + A.L.core);
+    const uint32_t *core_g = (const uint32_t *)(ws + A.L.core);
     hdb::Edge *mst = (hdb::Edge *)(ws + A.L.mst);
-    long long t0 = wall_clock64();
-    const int pt = A.prim_pt;                                        // smallest points-per-thread to use
-    if (N <= 2 * TB && pt <= 2) prim_regs32<2>(core, mst, N, rc16, (uint4 *)slots);
-    else if (N <= 4 * TB && pt <= 4) prim_regs32<4>(core, mst, N, rc16, (uint4 *)slots);
-    else if (N <= 8 * TB && pt <= 8) prim_regs32<8>(core, mst, N, rc16, (uint4 *)slots);
-    else if (N <= 16 * TB) prim_regs32<16>(core, mst, N, rc16, (uint4 *)slots);
-    else if (N <= 32 * TB) prim_regs32<32>(core, mst, N, rc16, (uint4 *)slots);
-    else prim_global(core, (uint32_t *)(ws + A.L.reach), mst, N, rc16, slots);
-    if (threadIdx.x == 0) ((int32_t *)(ws + A.L.hdr))[12] = (int)(wall_clock64() - t0);
+    for (int i = tid; i < nocc; i += TB) S.occ[i] = OccW{0ull, 0u, 0u};
+    for (int i = tid; i < A.n_ring; i += TB) S.ring[i] = A.ring[i];
+    __syncthreads();
+    for (int p = tid; p < N; p += TB) {
+        const uint32_t v = pts[p];
+        S.rc[p] = (uint16_t)(v & 0xFFFFu);
+        S.corei[p] = core_g[p];
+        const int cell = (int)(v & 255) * A.w + (int)((v >> 8) & 255);
+        atomicOr(&S.occ[cell >> 6].bits, 1ull << (cell & 63));
+    }
+    __syncthreads();
+    {
+        int tot;
+        const int mine = tid < nocc ? __popcll(S.occ[tid].bits) : 0;       // hw <= 65535: at most 1024 words
+        const int ex = block_excl_scan(mine, lds16, &tot);
+        if (tid < nocc) S.occ[tid].base = (uint32_t)ex;
+    }
+    if (tid == 0) {
+        const uint32_t v = S.rc[0];
+        S.tnode[0] = make_uint2((v & 255) | ((v >> 8) << 16), S.corei[0]);
+        S.corei[0] |= LVL_TREE;
+    }
+    __syncthreads();
+    const int PTn = (N + TB - 1) / TB;                                 // points per thread: p = (wave * PTn + q) * 64 + lane
+    uint32_t R[LVL_PT];
+#pragma unroll
+    for (int q = 0; q < LVL_PT; ++q) R[q] = LVL_RINF;
+    int cnt = 1, done = 0;
+    uint32_t m = 0, cur = 0;
+    bool need_rise = true;
+    int n_rounds = 0, n_rises = 0;
+    long long ph[5] = {0, 0, 0, 0, 0}, tp = wall_clock64();        // phase stamps (10 ns units): rise, extract, probe, accept+commit, mark
+#define LVL_PHASE(i) do { const long long tn_ = wall_clock64(); ph[i] += tn_ - tp; tp = tn_; } while (0)
+    if (tid == 0) hdr[24] = (int)(tp - t0);
+    while (cnt < N) {
+        if (need_rise) {
+            // ---- rise: catch R up with tnode[done .. cnt), new level, new F
+            ++n_rises;
+            uint32_t cjq[LVL_PT], rcq[LVL_PT];
+            uint32_t qmask = 0;
+#pragma unroll
+            for (int q = 0; q < LVL_PT; ++q) {
+                cjq[q] = LVL_TREE; rcq[q] = 0;
+                if (q < PTn) {
+                    const int p = (wave * PTn + q) * 64 + lane;
+                    if (p < N) {
+                        cjq[q] = S.corei[p];
+                        const uint32_t v = S.rc[p];
+                        rcq[q] = (v & 255) | ((v >> 8) << 16);
+                    }
+                    if (cjq[q] & LVL_TREE) R[q] = LVL_RINF;
+                    if (__ballot(!(cjq[q] & LVL_TREE))) qmask |= 1u << q;
+                }
+            }
+            if (qmask) {
+                // 64 nodes at a time: one LDS read per lane, then the nodes travel through scalar registers
+                for (int tb = done; tb < cnt; tb += 64) {
+                    const int nt = min(64, cnt - tb);
+                    const uint2 mine = S.tnode[min(tb + lane, cnt - 1)];
+                    for (int j = 0; j < nt; ++j) {
+                        const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, j);
+                        const uint32_t ty = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, j);
+#pragma unroll
+                        for (int q = 0; q < LVL_PT; ++q)
+                            if (qmask & (1u << q)) {
+                                const lvl_s2 d = __builtin_bit_cast(lvl_s2, rcq[q]) - __builtin_bit_cast(lvl_s2, tx);
+                                const uint32_t d2 = (uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false);
+                                R[q] = min(R[q], max(max(d2, cjq[q]), ty));
+                            }
+                    }
+                }
+            }
+            done = cnt;
+            uint32_t best = LVL_RINF;
+#pragma unroll
+            for (int q = 0; q < LVL_PT; ++q) best = min(best, R[q]);
+            best = wave_min_u32(best);
+            if (lane == 0) S.red[wave] = best;
+            __syncthreads();
+            {
+                uint32_t k2 = S.red[lane & 15];
+                k2 = dpp_min_u32<0x111, 0xF>(k2);
+                k2 = dpp_min_u32<0x112, 0xF>(k2);
+                k2 = dpp_min_u32<0x114, 0xF>(k2);
+                k2 = dpp_min_u32<0x118, 0xF>(k2);
+                m = (uint32_t)__builtin_amdgcn_readlane((int)k2, 15);
+            }
+#pragma unroll
+            for (int q = 0; q < LVL_PT; ++q)
+                if (q < PTn) {
+                    const unsigned long long bal = __ballot(R[q] == m);
+                    const int word = wave * PTn + q;
+                    if (lane == 0 && word < NFW) S.F[word] = bal;
+                }
+            __syncthreads();
+            need_rise = false;
+            LVL_PHASE(0);
+        }
+        // ---- the first 64 members of F, in index order: lane i of every wavefront gets the i-th
+        uint32_t mycand = LVL_NONE;
+        int ncand = 0;
+        {
+            uint32_t *cw = S.candw + wave * 64;
+            for (int wb = 0; wb < NFW && ncand < 64; wb += 64) {
+                const int k = wb + lane;
+                const unsigned long long W = k < NFW ? S.F[k] : 0ull;
+                unsigned long long nz = __ballot(W != 0ull);
+                while (nz && ncand < 64) {
+                    const int src = __builtin_ctzll(nz);
+                    nz &= nz - 1ull;
+                    const unsigned long long Wk = readlane_u64(W, src);
+                    if ((Wk >> lane) & 1ull) {
+                        const int rank = ncand + __popcll(Wk & ((1ull << lane) - 1ull));
+                        if (rank < 64) cw[rank] = (uint32_t)((wb + src) * 64 + lane);
+                    }
+                    ncand += __popcll(Wk);
+                }
+            }
+            ncand = min(ncand, 64);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < ncand) mycand = cw[lane];
+        }
+        LVL_PHASE(1);
+        if (ncand == 0) { need_rise = true; continue; }            // F ran empty: the level rises
+        ++n_rounds;
+        int a;
+        bool dropped = false;
+        uint32_t m2 = 0;
+        if (m > (uint32_t)LVL_RING2) {
+            a = 1;                                                     // beyond the ring table: one node, then a rise
+            need_rise = true;
+        } else {
+            // ---- probes: wavefront w takes candidates w, w + 16, w + 32, w + 48
+            if (wave < ncand) {
+                uint32_t fi[4], dmin[4], nmin[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) fi[u] = (uint32_t)__builtin_amdgcn_readlane((int)mycand, wave + NW16 * u);
+                const int nc = (ncand - wave + NW16 - 1) / NW16;
+                if (nc == 1) {
+                    uint32_t f1[1] = {fi[0]}, d1[1], n1[1];
+                    lvl_discs<1, false>(S, A, f1, 1, m, d1, n1);
+                    dmin[0] = d1[0]; nmin[0] = n1[0];
+                } else {
+                    lvl_discs<4, false>(S, A, fi, nc, m, dmin, nmin);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (u < nc && lane == 0) S.slot[wave + NW16 * u] = make_uint2(dmin[u], nmin[u]);
+            }
+            __syncthreads();
+            LVL_PHASE(2);
+            // ---- accepted prefix (every wavefront computes the same)
+            uint2 sl = make_uint2(LVL_NONE, LVL_NONE);
+            if (lane < ncand) sl = S.slot[lane];
+            const uint32_t pend = wave_prefix_min_u32(sl.y);
+            const uint32_t nextf = (uint32_t)__shfl_down((int)mycand, 1);
+            const bool stop = lane < ncand && (sl.x != LVL_NONE || (lane + 1 < ncand && pend < nextf));
+            const unsigned long long bal = __ballot(stop);
+            a = bal ? __builtin_ctzll(bal) + 1 : ncand;
+            m2 = (uint32_t)__builtin_amdgcn_readlane((int)sl.x, a - 1);
+            dropped = m2 != LVL_NONE;
+        }
+        // ---- commit: edges, tree membership, F
+        const uint32_t prevc = (uint32_t)__shfl_up((int)mycand, 1);
+        if (wave == 0 && lane < a) {
+            const uint32_t from = lane == 0 ? cur : prevc;
+            mst[cnt - 1 + lane] = hdb::Edge{(uint16_t)from, (uint16_t)mycand, m};
+            const uint32_t v = S.rc[mycand];
+            const uint32_t cj = S.corei[mycand];
+            S.tnode[cnt + lane] = make_uint2((v & 255) | ((v >> 8) << 16), cj);
+            S.corei[mycand] = cj | LVL_TREE;
+            if (!dropped) atomicAnd(&S.F[mycand >> 6], ~(1ull << (mycand & 63)));
+        }
+        if (dropped) for (int i = tid; i < NFW; i += TB) S.F[i] = 0ull;
+        cur = (uint32_t)__builtin_amdgcn_readlane((int)mycand, a - 1);
+        cnt += a;
+        __syncthreads();
+        LVL_PHASE(3);
+        if (cnt >= N) break;
+        if (!need_rise) {
+            uint32_t du[4], nu[4];
+            if (dropped) {
+                if (wave == ((a - 1) & (NW16 - 1))) {
+                    uint32_t f1[1] = {cur}, d1[1], n1[1];
+                    lvl_discs<1, true>(S, A, f1, 1, m2, d1, n1);
+                }
+                m = m2;
+            } else if (wave < a) {
+                uint32_t fi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) fi[u] = (uint32_t)__builtin_amdgcn_readlane((int)mycand, wave + NW16 * u);
+                const int nc = (a - wave + NW16 - 1) / NW16;
+                if (nc == 1) {
+                    uint32_t f1[1] = {fi[0]}, d1[1], n1[1];
+                    lvl_discs<1, true>(S, A, f1, 1, m, d1, n1);
+                } else {
+                    lvl_discs<4, true>(S, A, fi, nc, m, du, nu);
+                }
+            }
+            __syncthreads();
+            LVL_PHASE(4);
+        }
+    }
+    if (tid == 0) { hdr[12] = (int)(wall_clock64() - t0); hdr[16] = n_rounds; hdr[17] = n_rises;
+                    for (int i = 0; i < 5; ++i) hdr[18 + i] = (int)ph[i]; }
 }
 
 // One 1x5 (ROWS) or 5x1 pass of the separable grey CLOSE over a map in LDS: MAX = dilate, else erode; samples
@@ -704,13 +1113,6 @@ __device__ void radix_pass(const hdb::Edge *__restrict__ src, hdb::Edge *__restr
         }
         __syncthreads();
     }
-}
-
-template <typename T>
-__device__ __forceinline__ T *carve(uint8_t *&p, size_t count) {
-    T *r = (T *)p;
-    p += (count * sizeof(T) + 15) / 16 * 16;
-    return r;
 }
 
 struct TreeShared {
@@ -1438,6 +1840,11 @@ static int ensure_ring(SvcHandle *h) {
     h->tail_n_offsets = (int)v.size();
     h->tail_n_offsets1 = 0;
     for (uint32_t x : v) h->tail_n_offsets1 += (int)((x >> 16) <= RING_R1 * RING_R1);
+    std::vector<uint16_t> cnt(RING_R * RING_R + 1, 0);       // offsets with d2 <= m, for k_prim_lvl's discs
+    for (uint32_t x : v) ++cnt[x >> 16];
+    for (size_t m = 1; m < cnt.size(); ++m) cnt[m] = (uint16_t)(cnt[m] + cnt[m - 1]);
+    if ((rc = h->tail_ring_cnt.ensure(cnt.size() * 2))) return rc;
+    SVC_HIP(hipMemcpy(h->tail_ring_cnt.p, cnt.data(), cnt.size() * 2, hipMemcpyHostToDevice));
     return SVC_OK;
 }
 
@@ -1586,6 +1993,7 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
     RC_TAIL(ensure_ring_delta(h, width, &ring_delta));
     A.ring = (const uint32_t *)h->tail_offsets.p; A.n_ring = h->tail_n_offsets; A.n_ring1 = h->tail_n_offsets1;
     A.ring_delta = ring_delta;
+    A.ring_cnt = (const uint16_t *)h->tail_ring_cnt.p; A.prim_lvl = h->prim_lvl;
     A.xy = xy; A.stats = stats; A.L = L;
     const int hw = height * width;
     const size_t lds_core = (size_t)(hw + 15) / 16 * 16 + (size_t)h->tail_n_offsets * 4 + (size_t)h->tail_n_offsets1 * 4;
@@ -1593,7 +2001,11 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
     const size_t lds_fin = 2 * ((size_t)(hw + 15) / 16 * 16);
     if (h->lds_attr_done.insert((const void *)k_core).second) {      // per handle = per device (the attribute is per device)
         SVC_HIP(hipFuncSetAttribute((const void *)k_core, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-        SVC_HIP(hipFuncSetAttribute((const void *)k_prim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_prim_pt<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_prim_pt<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_prim_pt<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_prim_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_prim_lvl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_tree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_sort, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_BYTES));
@@ -1627,8 +2039,17 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
                 SVC_CHECK_LAUNCH();
             }
             ProfScope ps(h, SVC_K_PRIM, s);
-            k_prim<<<m, TB, lds_prim, s>>>(A);
-            SVC_CHECK_LAUNCH();
+            // maps of up to LVL_CAP points: the level-bucketed Prim; larger ones (or all, SVC_PRIM_LVL=0): one node per step
+            const int n_min = h->prim_lvl ? LVL_CAP : 0;
+            if (h->prim_lvl) {
+                k_prim_lvl<<<m, TB, lvl_lds_bytes(hw, h->tail_n_offsets), s>>>(A);
+                SVC_CHECK_LAUNCH();
+            } else {
+                if (h->prim_pt <= 2) { k_prim_pt<2><<<m, TB, lds_prim, s>>>(A, n_min); SVC_CHECK_LAUNCH(); }
+                if (h->prim_pt <= 4 && (hw > 2 * TB || h->prim_pt > 2)) { k_prim_pt<4><<<m, TB, lds_prim, s>>>(A, n_min); SVC_CHECK_LAUNCH(); }
+                if (hw > 4 * TB || h->prim_pt > 4) { k_prim_pt<8><<<m, TB, lds_prim, s>>>(A, n_min); SVC_CHECK_LAUNCH(); }
+            }
+            if (hw > 8 * TB) { k_prim_big<<<m, TB, lds_prim, s>>>(A, n_min); SVC_CHECK_LAUNCH(); }
         }
         {
             ProfScope ps(h, SVC_K_FINISH, s);
@@ -1685,7 +2106,7 @@ extern "C" int svc_debug_cluster_state(SvcHandle *h, int frame, int cap, uint32_
     const int fcap = h->tail_h * h->tail_w;
     FrameWS L = make_layout(fcap, 1);      // point-array offsets do not depend on the cluster capacity
     const uint8_t *ws = (const uint8_t *)h->tail_ws.p + (size_t)frame * h->tail_frame_stride;
-    int32_t hdr[16];
+    int32_t hdr[32];
     SVC_HIP(hipMemcpy(hdr, ws + L.hdr, sizeof hdr, hipMemcpyDeviceToHost));
     const int N = hdr[0];
     const int m = std::min(N, cap);

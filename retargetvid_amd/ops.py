@@ -143,7 +143,7 @@ class Engine:
         core = np.zeros(cap, np.uint32)
         mst = np.zeros((cap, 3), np.uint32)
         labels = np.zeros(cap, np.int32)
-        hdr = np.zeros(16, np.int32)
+        hdr = np.zeros(32, np.int32)
         vp = ctypes.c_void_p
         n = _lib.check(self.lib.svc_debug_cluster_state(self._h, frame, cap, pts.ctypes.data_as(vp),
                                                          core.ctypes.data_as(vp), mst.ctypes.data_as(vp),

@@ -28,3 +28,6 @@ for i in range(0, 32, 6):
     h = st['hdr']
     print('  map %2d: N=%5d clusters %3d  stamps (us, 100 MHz wall clock): k_sort %.1f | k_tree built %.1f hierarchy %.1f chosen %.1f | '
           'k_finish %.1f | k_prim %.1f' % (i, st['n'], h[4], h[8] / 100.0, h[13] / 100.0, h[9] / 100.0, h[10] / 100.0, h[11] / 100.0, h[12] / 100.0))
+    if h[16]:
+        print('           k_prim_lvl: %d rounds, %d rises; setup %.1f us, phases (us): rise %.1f extract %.1f probe %.1f commit %.1f mark %.1f' % (
+            h[16], h[17], h[24] / 100.0, h[18] / 100.0, h[19] / 100.0, h[20] / 100.0, h[21] / 100.0, h[22] / 100.0))

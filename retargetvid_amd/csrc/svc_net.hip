@@ -2835,7 +2835,7 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     env = getenv("SVC_PRIM_PT");
     if (env && atoi(env) > 0) h->prim_pt = atoi(env);
     env = getenv("SVC_PRIM_LVL");
-    if (env) h->prim_lvl = atoi(env) != 0;
+    if (env) h->prim_lvl = atoi(env);
     int rc = h->blob.ensure(n_bytes);
     if (rc) { delete h; return rc; }
     if (hipMemcpy(h->blob.p, blob_host, n_bytes, hipMemcpyHostToDevice) != hipSuccess) {

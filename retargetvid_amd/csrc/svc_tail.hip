@@ -696,15 +696,21 @@ __global__ __launch_bounds__(TB) void k_prim_big(TailArgs A, int n_min) {
 #define LVL_NONE 0xFFFFFFFFu
 #define LVL_RINF 0x7FFFFFFFu
 #define LVL_RING2 (RING_R * RING_R)
+#define LVL_PAD RING_R                 // the occupancy grid carries a border of empty cells: discs need no bounds tests
+#define LVL_FAST_NK 128                // discs of up to 128 cells (levels <= 36) keep their findings in registers
+#define LVL_NB 256                     // batches of tree nodes a map can have pending (then everything is settled at once)
+#define LVL_NEAR 64u                   // a rise whose bound exceeds this is a jump between blobs: the bound is tightened first
 
-struct OccW { unsigned long long bits; uint32_t base, pad; };          // 64 grid cells: occupancy, points before them
+struct OccW { uint32_t bits, base; };                                  // 32 grid cells: occupancy, points before them
 typedef short lvl_s2 __attribute__((ext_vector_type(2)));
 
-static size_t lvl_lds_bytes(int hw, int n_ring) {
-    const size_t cap = (size_t)std::min(hw, LVL_CAP);
+static size_t lvl_lds_bytes(int h, int w, int n_ring) {
+    const size_t cap = (size_t)std::min(h * w, LVL_CAP);
+    const size_t cells = (size_t)(h + 2 * LVL_PAD) * (w + 2 * LVL_PAD);
     auto up = [](size_t b) { return (b + 15) / 16 * 16; };
-    return up((size_t)((hw + 63) / 64) * sizeof(OccW)) + up(cap * 8) + up(cap * 4) + up((cap + 63) / 64 * 8) +
-           up((size_t)n_ring * 4) + up(cap * 2) + up(NW16 * 64 * 4) + up(64 * 8) + up(NW16 * 4) + 64;
+    return up((cells + 31) / 32 * sizeof(OccW)) + up(cap * 8) + up(cap * 4) + up((cap + 63) / 64 * 8) +
+           up((size_t)n_ring * 8) + up(cap * 2) + up(64 * 4) + up(64 * 8) + up(2 * NW16 * 4) + up(16) +
+           up(LVL_NB * 16) + up((cap + 63) / 64 * (LVL_NB / 32) * 4) + up((cap + 63) / 64 * 16) + up((LVL_RING2 + 1) * 2) + 64;
 }
 
 __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int j) {
@@ -724,71 +730,131 @@ __device__ __forceinline__ uint32_t wave_prefix_min_u32(uint32_t v) {
 }
 
 struct LvlLds {
-    OccW *occ; uint2 *tnode; uint32_t *corei; unsigned long long *F; uint32_t *ring; uint16_t *rc;
-    uint32_t *candw; uint2 *slot; uint32_t *red;
+    OccW *occ;              // padded grid, 32 cells per word
+    uint2 *tnode;           // tree nodes in the order they joined: (row | col << 16, core distance)
+    uint32_t *corei;        // core distance per point; top bit = in the tree
+    uint32_t *F;            // bitmap over point indices (32-bit words; read in pairs by the extraction)
+    uint2 *ring;            // (d2, linear offset in the padded grid) per ring offset, ascending d2
+    uint16_t *rc;           // row | col << 8 per point
+    uint32_t *cand;         // [64] candidates of the round
+    uint2 *slot;            // [64] (drop: smallest mr below the level or NONE, lowest entrant or NONE) per candidate
+    uint32_t *red;          // [2][NW16] block reductions (alternating halves)
+    int *ctl;               // [0] candidates of the round
+    uint4 *btab;            // [LVL_NB] batches of tree nodes: (start | len << 16, box, smallest core distance, -)
+    uint32_t *proc;         // [chunks][LVL_NB / 32] batch already relaxed against the chunk
+    uint4 *cbox;            // [chunks] (box, smallest core distance, -, -) of every chunk of 64 points
+    uint16_t *rcnt;         // [RING_R^2 + 1] ring offsets with d2 <= index
+    int gw;                 // padded grid width
 };
 
-// The discs d2 <= level around up to NC points at once (the same ring offsets serve all of them; their dependent LDS
-// reads -- occupancy word, then core distance and F word of the point found -- are issued side by side).
-//   MARK = false: per point, dmin = smallest mr below the level (a drop), nmin = lowest index with mr == level outside
-//                 F (an entrant); both reduced over the wavefront.
-//   MARK = true:  F |= the points outside the tree whose mr is exactly `level` (tree members carry the top bit in
-//                 their core distance, so their mr is never equal to a level).
-template <int NC, bool MARK>
-__device__ __forceinline__ void lvl_discs(const LvlLds &S, const TailArgs &A, const uint32_t (&fi)[NC], int nc, uint32_t level,
-                                          uint32_t (&dmin)[NC], uint32_t (&nmin)[NC]) {
-    const int lane = threadIdx.x & 63;
-    int r[NC], c[NC];
-    uint32_t ci[NC];
+// What one lane found in one chunk (64 ring cells) of the discs of up to four candidates.
+struct LvlFound { uint32_t j[4], mr[4]; uint32_t ent; };              // mr = NONE: no point there; ent: bit u = entrant of candidate u
+
+// The discs d2 <= level around up to NC candidates, one chunk of 64 ring cells: the same ring offsets serve all of
+// them, their dependent LDS reads (occupancy word, then core distance and F word of the point found) go side by side.
+template <int NC>
+__device__ __forceinline__ void lvl_chunk(const LvlLds &S, const uint32_t (&cell0)[NC], const uint32_t (&ci)[NC], int nc,
+                                          int k, int nk, uint32_t level, LvlFound &fo) {
+    const bool valid = k < nk;
+    const uint2 o = S.ring[valid ? k : 0];
+    uint32_t bitpos[NC];
+    OccW ow[NC];
 #pragma unroll
     for (int u = 0; u < NC; ++u) {
-        const uint32_t f0 = u < nc ? fi[u] : 0u;
-        const uint32_t v = S.rc[f0];
-        r[u] = v & 255; c[u] = v >> 8;
-        ci[u] = S.corei[f0] & ~LVL_TREE;
-        dmin[u] = nmin[u] = LVL_NONE;
+        const uint32_t cell = cell0[u] + o.y;
+        bitpos[u] = cell & 31u;
+        ow[u] = S.occ[cell >> 5];
     }
-    const int nk = A.ring_cnt[level];
-    for (int base = 0; base < nk; base += 64) {
-        const int k = base + lane;
-        const bool valid = k < nk;
-        const uint32_t o = S.ring[valid ? k : 0];
-        const int dr = (int)(o & 255) - 128, dc = (int)((o >> 8) & 255) - 128;
-        OccW ow[NC];
-        int b[NC];
-        bool in[NC];
+    uint32_t cj[NC], fw[NC];
+    bool in[NC];
 #pragma unroll
-        for (int u = 0; u < NC; ++u) {
-            const int rr = r[u] + dr, cc = c[u] + dc;
-            in[u] = valid && u < nc && (unsigned)rr < (unsigned)A.h && (unsigned)cc < (unsigned)A.w;
-            const int cell = in[u] ? rr * A.w + cc : 0;
-            b[u] = cell & 63;
-            ow[u] = S.occ[cell >> 6];
+    for (int u = 0; u < NC; ++u) {
+        in[u] = valid && u < nc && ((ow[u].bits >> bitpos[u]) & 1u);
+        fo.j[u] = in[u] ? ow[u].base + (uint32_t)__popc(ow[u].bits & ((1u << bitpos[u]) - 1u)) : 0u;
+        cj[u] = S.corei[fo.j[u]];
+        fw[u] = S.F[fo.j[u] >> 5];
+    }
+    fo.ent = 0;
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+        const uint32_t mr = max(max(o.x, cj[u]), ci[u]);
+        fo.mr[u] = in[u] ? mr : LVL_NONE;
+        if (in[u] && mr == level && !((fw[u] >> (fo.j[u] & 31u)) & 1u)) fo.ent |= 1u << u;
+    }
+}
+
+// One batch of <= 64 tree nodes (positions start .. start + len in tnode) against one chunk of 64 points (one per
+// lane): r = min(r, max(d2, core_j, core_t)).  The nodes are read once by the lanes and travel through scalar registers.
+__device__ __forceinline__ uint32_t lvl_relax_block(const LvlLds &S, int start, int len, uint32_t rcv, uint32_t cj, uint32_t r) {
+    const int lane = threadIdx.x & 63;
+    const uint2 mine = S.tnode[start + min(lane, len - 1)];
+    if (len == 64) {
+#pragma unroll 16
+        for (int j = 0; j < 64; ++j) {
+            const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, j);
+            const uint32_t ty = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, j);
+            const lvl_s2 d = __builtin_bit_cast(lvl_s2, rcv) - __builtin_bit_cast(lvl_s2, tx);
+            r = min(r, max(max((uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false), cj), ty));
         }
-        uint32_t j[NC], cj[NC];
-        unsigned long long fw[NC];
-#pragma unroll
-        for (int u = 0; u < NC; ++u) {
-            in[u] = in[u] && ((ow[u].bits >> b[u]) & 1ull);
-            j[u] = in[u] ? ow[u].base + (uint32_t)__popcll(ow[u].bits & ((1ull << b[u]) - 1ull)) : 0u;
-            cj[u] = S.corei[j[u]];
-            if (!MARK) fw[u] = S.F[j[u] >> 6];
+        return r;
+    }
+    for (int j = 0; j < len; ++j) {
+        const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, j);
+        const uint32_t ty = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, j);
+        const lvl_s2 d = __builtin_bit_cast(lvl_s2, rcv) - __builtin_bit_cast(lvl_s2, tx);
+        r = min(r, max(max((uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false), cj), ty));
+    }
+    return r;
+}
+
+// box = rmin | rmax << 8 | cmin << 16 | cmax << 24: squared distance between two boxes (0 when they overlap)
+__device__ __forceinline__ uint32_t lvl_box_d2(uint32_t a, uint32_t b) {
+    const int ar0 = a & 255, ar1 = (a >> 8) & 255, ac0 = (a >> 16) & 255, ac1 = a >> 24;
+    const int br0 = b & 255, br1 = (b >> 8) & 255, bc0 = (b >> 16) & 255, bc1 = b >> 24;
+    const int dr = max(0, max(br0 - ar1, ar0 - br1)), dc = max(0, max(bc0 - ac1, ac0 - bc1));
+    return (uint32_t)(dr * dr + dc * dc);
+}
+
+// One sweep of a rise over one chunk: relax the pending batches whose lower bound max(box distance^2, smallest core
+// distances) is <= limit (NEAREST: only the one with the smallest bound).  proc = the chunk's "already relaxed" bits.
+template <bool NEAREST>
+__device__ __forceinline__ uint32_t lvl_sweep_chunk(const LvlLds &S, const uint4 *btab, uint32_t *proc, int nb, uint32_t limit, bool all,
+                                                    uint4 cb, uint32_t rcv, uint32_t cj, uint32_t r) {
+    const int lane = threadIdx.x & 63;
+    uint32_t bestkey = LVL_NONE;
+    for (int bb = 0; bb < nb; bb += 64) {
+        const int b = bb + lane;
+        uint32_t lb = LVL_NONE;
+        if (b < nb && !((proc[b >> 5] >> (b & 31)) & 1u)) {
+            const uint4 e = btab[b];
+            lb = all ? 0u : max(max(lvl_box_d2(e.y, cb.x), e.z), cb.y);
         }
-#pragma unroll
-        for (int u = 0; u < NC; ++u) {
-            const uint32_t mr = max(max(o >> 16, cj[u]), ci[u]);
-            if (MARK) {
-                if (in[u] && mr == level) atomicOr(&S.F[j[u] >> 6], 1ull << (j[u] & 63));
-            } else if (in[u]) {
-                if (mr < level) dmin[u] = min(dmin[u], mr);
-                else if (mr == level && !((fw[u] >> (j[u] & 63)) & 1ull)) nmin[u] = min(nmin[u], j[u]);
-            }
+        if (NEAREST) {
+            if (lb <= limit) bestkey = min(bestkey, (min(lb, 0xFFFFFFu) << 8) | (uint32_t)b);
+            continue;
+        }
+        unsigned long long todo = __ballot(lb <= limit && lb != LVL_NONE);
+        if (lane == 0 && todo) {
+            proc[bb >> 5] |= (uint32_t)todo;
+            if (bb + 32 < LVL_NB) proc[(bb >> 5) + 1] |= (uint32_t)(todo >> 32);
+        }
+        while (todo) {
+            const int b0 = bb + __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const uint32_t sl = btab[b0].x;
+            r = lvl_relax_block(S, (int)(sl & 0xFFFFu), (int)(sl >> 16), rcv, cj, r);
         }
     }
-    if (!MARK) {
-#pragma unroll
-        for (int u = 0; u < NC; ++u) { dmin[u] = wave_min_u32(dmin[u]); nmin[u] = wave_min_u32(nmin[u]); }
+    if (NEAREST) {
+        bestkey = wave_min_u32(bestkey);
+        if (bestkey != LVL_NONE) {
+            const int b0 = (int)(bestkey & 255u);
+            if (lane == 0) proc[b0 >> 5] |= 1u << (b0 & 31);
+            const uint32_t sl = btab[b0].x;
+            r = lvl_relax_block(S, (int)(sl & 0xFFFFu), (int)(sl >> 16), rcv, cj, r);
+        }
     }
+    return r;
 }
 
 __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
@@ -801,41 +867,55 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
     extern __shared__ uint8_t sm_lvl[];
     __shared__ int lds16[NW16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hw = A.h * A.w, nocc = (hw + 63) >> 6, NFW = (N + 63) >> 6;
-    const int cap = min(hw, LVL_CAP);
+    const int gw = A.w + 2 * LVL_PAD, gcells = (A.h + 2 * LVL_PAD) * gw, nocc = (gcells + 31) >> 5;
+    const int NF64 = (N + 63) >> 6;
+    const int cap = min(A.h * A.w, LVL_CAP);
     LvlLds S;
     {
         uint8_t *p = sm_lvl;
         S.occ = carve<OccW>(p, nocc);
         S.tnode = carve<uint2>(p, cap);
         S.corei = carve<uint32_t>(p, cap);
-        S.F = carve<unsigned long long>(p, (cap + 63) / 64);
-        S.ring = carve<uint32_t>(p, A.n_ring);
+        S.F = carve<uint32_t>(p, (size_t)((cap + 63) / 64) * 2);
+        S.ring = carve<uint2>(p, A.n_ring);
         S.rc = carve<uint16_t>(p, cap);
-        S.candw = carve<uint32_t>(p, NW16 * 64);
+        S.cand = carve<uint32_t>(p, 64);
         S.slot = carve<uint2>(p, 64);
-        S.red = carve<uint32_t>(p, NW16);
+        S.red = carve<uint32_t>(p, 2 * NW16);
+        S.ctl = carve<int>(p, 4);
+        S.btab = carve<uint4>(p, LVL_NB);
+        S.proc = carve<uint32_t>(p, (size_t)((cap + 63) / 64) * (LVL_NB / 32));
+        S.cbox = carve<uint4>(p, (cap + 63) / 64);
+        S.rcnt = carve<uint16_t>(p, LVL_RING2 + 1);
+        S.gw = gw;
     }
     const long long t0 = wall_clock64();
     const uint32_t *pts = (const uint32_t *)(ws + A.L.pts);
     const uint32_t *core_g = (const uint32_t *)(ws + A.L.core);
     hdb::Edge *mst = (hdb::Edge *)(ws + A.L.mst);
-    for (int i = tid; i < nocc; i += TB) S.occ[i] = OccW{0ull, 0u, 0u};
-    for (int i = tid; i < A.n_ring; i += TB) S.ring[i] = A.ring[i];
+    for (int i = tid; i < nocc; i += TB) S.occ[i] = OccW{0u, 0u};
+    for (int i = tid; i <= LVL_RING2; i += TB) S.rcnt[i] = A.ring_cnt[i];
+    for (int i = tid; i < A.n_ring; i += TB) {
+        const uint32_t o = A.ring[i];
+        S.ring[i] = make_uint2(o >> 16, (uint32_t)(((int)(o & 255) - 128) * gw + ((int)((o >> 8) & 255) - 128)));
+    }
     __syncthreads();
     for (int p = tid; p < N; p += TB) {
         const uint32_t v = pts[p];
         S.rc[p] = (uint16_t)(v & 0xFFFFu);
         S.corei[p] = core_g[p];
-        const int cell = (int)(v & 255) * A.w + (int)((v >> 8) & 255);
-        atomicOr(&S.occ[cell >> 6].bits, 1ull << (cell & 63));
+        const int cell = ((int)(v & 255) + LVL_PAD) * gw + (int)((v >> 8) & 255) + LVL_PAD;
+        atomicOr(&S.occ[cell >> 5].bits, 1u << (cell & 31));
     }
     __syncthreads();
     {
+        // points before every word: the thread's words are consecutive, one block scan over the per-thread sums
+        const int per = (nocc + TB - 1) / TB, lo = min(nocc, tid * per), hi = min(nocc, lo + per);
+        int mine = 0;
+        for (int i = lo; i < hi; ++i) mine += __popc(S.occ[i].bits);
         int tot;
-        const int mine = tid < nocc ? __popcll(S.occ[tid].bits) : 0;       // hw <= 65535: at most 1024 words
-        const int ex = block_excl_scan(mine, lds16, &tot);
-        if (tid < nocc) S.occ[tid].base = (uint32_t)ex;
+        int ex = block_excl_scan(mine, lds16, &tot);
+        for (int i = lo; i < hi; ++i) { S.occ[i].base = (uint32_t)ex; ex += __popc(S.occ[i].bits); }
     }
     if (tid == 0) {
         const uint32_t v = S.rc[0];
@@ -843,28 +923,66 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
         S.corei[0] |= LVL_TREE;
     }
     __syncthreads();
-    const int PTn = (N + TB - 1) / TB;                                 // points per thread: p = (wave * PTn + q) * 64 + lane
+    // chunk c = 64 consecutive points; wavefront w owns chunks w, w + 16, ... (neighbouring chunks -- the ones a rise has
+    // work for -- on different SIMDs); lane = point
     uint32_t R[LVL_PT];
 #pragma unroll
-    for (int q = 0; q < LVL_PT; ++q) R[q] = LVL_RINF;
-    int cnt = 1, done = 0;
+    for (int q = 0; q < LVL_PT; ++q) {
+        R[q] = LVL_RINF;
+        const int c = q * NW16 + wave;
+        if (c < NF64) {
+            const int p = c * 64 + lane;
+            const uint32_t v = p < N ? S.rc[p] : 0u;
+            const uint32_t r = v & 255, cc = v >> 8;
+            const uint32_t big = p < N ? 0u : 255u;
+            const uint32_t rmin = wave_min_u32(r | big), rmax = 255u - wave_min_u32(p < N ? 255u - r : 255u);
+            const uint32_t cmin = wave_min_u32(cc | big), cmax = 255u - wave_min_u32(p < N ? 255u - cc : 255u);
+            const uint32_t kmin = wave_min_u32(p < N ? (S.corei[p] & ~LVL_TREE) : LVL_RINF);
+            if (lane == 0) S.cbox[c] = make_uint4(rmin | (rmax << 8) | (cmin << 16) | (cmax << 24), kmin, 0u, 0u);
+            for (int i = lane; i < LVL_NB / 32; i += 64) S.proc[c * (LVL_NB / 32) + i] = 0u;
+        }
+    }
+    int cnt = 1, done = 0, nb = 0, parity = 0;
     uint32_t m = 0, cur = 0;
     bool need_rise = true;
     int n_rounds = 0, n_rises = 0;
-    long long ph[5] = {0, 0, 0, 0, 0}, tp = wall_clock64();        // phase stamps (10 ns units): rise, extract, probe, accept+commit, mark
-#define LVL_PHASE(i) do { const long long tn_ = wall_clock64(); ph[i] += tn_ - tp; tp = tn_; } while (0)
+    long long ph[5] = {0, 0, 0, 0, 0}, tp = wall_clock64();        // phase stamps (10 ns units): rise, extract, probe, accept + commit, mark
+    const bool stamps = (A.prim_lvl & 2) != 0;                      // SVC_PRIM_LVL=3: phase stamps (each costs a scalar memory round trip)
+#define LVL_PHASE(i) do { if (stamps) { const long long tn_ = wall_clock64(); ph[i] += tn_ - tp; tp = tn_; } } while (0)
+    long long fine[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq = tp;   // finer stamps inside a round (wavefront 0)
+#define LVL_FINE(i) do { if (stamps) { const long long tn_ = wall_clock64(); fine[i] += tn_ - tq; tq = tn_; } } while (0)
     if (tid == 0) hdr[24] = (int)(tp - t0);
+    __syncthreads();
+    // minimum of R over the block (all wavefronts get it); one barrier
+    auto block_min_R = [&]() -> uint32_t {
+        uint32_t best = LVL_RINF;
+#pragma unroll
+        for (int q = 0; q < LVL_PT; ++q) best = min(best, R[q]);
+        best = wave_min_u32(best);
+        uint32_t *red = S.red + parity * NW16;
+        parity ^= 1;
+        if (lane == 0) red[wave] = best;
+        __syncthreads();
+        uint32_t k2 = red[lane & 15];
+        k2 = dpp_min_u32<0x111, 0xF>(k2);
+        k2 = dpp_min_u32<0x112, 0xF>(k2);
+        k2 = dpp_min_u32<0x114, 0xF>(k2);
+        k2 = dpp_min_u32<0x118, 0xF>(k2);
+        return (uint32_t)__builtin_amdgcn_readlane((int)k2, 15);
+    };
     while (cnt < N) {
         if (need_rise) {
-            // ---- rise: catch R up with tnode[done .. cnt), new level, new F
+            // ---- rise: the nodes added since the last one become batches; R is caught up block by block (a batch
+            // against a chunk) where the block's lower bound allows a value <= the bound; new level, new F
             ++n_rises;
             uint32_t cjq[LVL_PT], rcq[LVL_PT];
             uint32_t qmask = 0;
 #pragma unroll
             for (int q = 0; q < LVL_PT; ++q) {
                 cjq[q] = LVL_TREE; rcq[q] = 0;
-                if (q < PTn) {
-                    const int p = (wave * PTn + q) * 64 + lane;
+                const int c = q * NW16 + wave;
+                if (c < NF64) {
+                    const int p = c * 64 + lane;
                     if (p < N) {
                         cjq[q] = S.corei[p];
                         const uint32_t v = S.rc[p];
@@ -874,102 +992,178 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
                     if (__ballot(!(cjq[q] & LVL_TREE))) qmask |= 1u << q;
                 }
             }
-            if (qmask) {
-                // 64 nodes at a time: one LDS read per lane, then the nodes travel through scalar registers
-                for (int tb = done; tb < cnt; tb += 64) {
-                    const int nt = min(64, cnt - tb);
-                    const uint2 mine = S.tnode[min(tb + lane, cnt - 1)];
-                    for (int j = 0; j < nt; ++j) {
-                        const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, j);
-                        const uint32_t ty = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, j);
+            const int nnew = (cnt - done + 63) >> 6;
+            const bool flush = nb + nnew > LVL_NB;                   // table full: settle every pending block, start afresh
+            if (flush) {
 #pragma unroll
-                        for (int q = 0; q < LVL_PT; ++q)
-                            if (qmask & (1u << q)) {
-                                const lvl_s2 d = __builtin_bit_cast(lvl_s2, rcq[q]) - __builtin_bit_cast(lvl_s2, tx);
-                                const uint32_t d2 = (uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false);
-                                R[q] = min(R[q], max(max(d2, cjq[q]), ty));
-                            }
+                for (int q = 0; q < LVL_PT; ++q)
+                    if (qmask & (1u << q)) {
+                        const int c = q * NW16 + wave;
+                        R[q] = lvl_sweep_chunk<false>(S, S.btab, S.proc + c * (LVL_NB / 32), nb, 0u, true, S.cbox[c], rcq[q], cjq[q], R[q]);
                     }
-                }
-            }
-            done = cnt;
-            uint32_t best = LVL_RINF;
 #pragma unroll
-            for (int q = 0; q < LVL_PT; ++q) best = min(best, R[q]);
-            best = wave_min_u32(best);
-            if (lane == 0) S.red[wave] = best;
-            __syncthreads();
-            {
-                uint32_t k2 = S.red[lane & 15];
-                k2 = dpp_min_u32<0x111, 0xF>(k2);
-                k2 = dpp_min_u32<0x112, 0xF>(k2);
-                k2 = dpp_min_u32<0x114, 0xF>(k2);
-                k2 = dpp_min_u32<0x118, 0xF>(k2);
-                m = (uint32_t)__builtin_amdgcn_readlane((int)k2, 15);
+                for (int q = 0; q < LVL_PT; ++q) {
+                    const int c = q * NW16 + wave;
+                    if (c < NF64) for (int i = lane; i < LVL_NB / 32; i += 64) S.proc[c * (LVL_NB / 32) + i] = 0u;
+                }
+                nb = 0;
+                __syncthreads();                                       // every wavefront is done with the old table
             }
+            for (int g = wave; g < nnew; g += NW16) {
+                const int s0 = done + 64 * g, len = min(64, cnt - s0);
+                const uint2 tn = S.tnode[s0 + min(lane, len - 1)];
+                const uint32_t r = tn.x & 0xFFFFu, cc = tn.x >> 16;
+                const uint32_t rmin = wave_min_u32(r), rmax = 255u - wave_min_u32(255u - r);
+                const uint32_t cmin = wave_min_u32(cc), cmax = 255u - wave_min_u32(255u - cc);
+                const uint32_t kmin = wave_min_u32(tn.y);
+                if (lane == 0) S.btab[nb + g] = make_uint4((uint32_t)s0 | ((uint32_t)len << 16), rmin | (rmax << 8) | (cmin << 16) | (cmax << 24), kmin, 0u);
+            }
+            nb += nnew;
+            done = cnt;
+            const uint32_t ub0 = block_min_R();                        // (its barrier also publishes the new batches)
 #pragma unroll
             for (int q = 0; q < LVL_PT; ++q)
-                if (q < PTn) {
-                    const unsigned long long bal = __ballot(R[q] == m);
-                    const int word = wave * PTn + q;
-                    if (lane == 0 && word < NFW) S.F[word] = bal;
+                if (qmask & (1u << q)) {
+                    const int c = q * NW16 + wave;
+                    R[q] = lvl_sweep_chunk<false>(S, S.btab, S.proc + c * (LVL_NB / 32), nb, min(ub0, LVL_NEAR), false, S.cbox[c], rcq[q], cjq[q], R[q]);
                 }
+            if (ub0 > LVL_NEAR) {
+                // a jump between blobs: the nearest pending batch of every chunk tightens the bound, then the rest
+                const uint32_t ub1 = block_min_R();
+#pragma unroll
+                for (int q = 0; q < LVL_PT; ++q)
+                    if (qmask & (1u << q)) {
+                        const int c = q * NW16 + wave;
+                        R[q] = lvl_sweep_chunk<true>(S, S.btab, S.proc + c * (LVL_NB / 32), nb, ub1, false, S.cbox[c], rcq[q], cjq[q], R[q]);
+                    }
+                const uint32_t ub2 = block_min_R();
+#pragma unroll
+                for (int q = 0; q < LVL_PT; ++q)
+                    if (qmask & (1u << q)) {
+                        const int c = q * NW16 + wave;
+                        R[q] = lvl_sweep_chunk<false>(S, S.btab, S.proc + c * (LVL_NB / 32), nb, ub2, false, S.cbox[c], rcq[q], cjq[q], R[q]);
+                    }
+            }
+            m = block_min_R();
+#pragma unroll
+            for (int q = 0; q < LVL_PT; ++q) {
+                const int c = q * NW16 + wave;
+                if (c < NF64) {
+                    const unsigned long long bal = __ballot(R[q] == m);
+                    if (lane == 0) ((unsigned long long *)S.F)[c] = bal;
+                }
+            }
             __syncthreads();
             need_rise = false;
             LVL_PHASE(0);
         }
-        // ---- the first 64 members of F, in index order: lane i of every wavefront gets the i-th
-        uint32_t mycand = LVL_NONE;
-        int ncand = 0;
-        {
-            uint32_t *cw = S.candw + wave * 64;
-            for (int wb = 0; wb < NFW && ncand < 64; wb += 64) {
+        // ---- wavefront 0: the first 64 members of F, in index order
+        if (stamps) tq = wall_clock64();
+        if (wave == 0) {
+            int nc0 = 0;
+            for (int wb = 0; wb < NF64 && nc0 < 64; wb += 64) {
                 const int k = wb + lane;
-                const unsigned long long W = k < NFW ? S.F[k] : 0ull;
+                const unsigned long long W = k < NF64 ? ((const unsigned long long *)S.F)[k] : 0ull;
                 unsigned long long nz = __ballot(W != 0ull);
-                while (nz && ncand < 64) {
+                while (nz && nc0 < 64) {
                     const int src = __builtin_ctzll(nz);
                     nz &= nz - 1ull;
                     const unsigned long long Wk = readlane_u64(W, src);
                     if ((Wk >> lane) & 1ull) {
-                        const int rank = ncand + __popcll(Wk & ((1ull << lane) - 1ull));
-                        if (rank < 64) cw[rank] = (uint32_t)((wb + src) * 64 + lane);
+                        const int rank = nc0 + __popcll(Wk & ((1ull << lane) - 1ull));
+                        if (rank < 64) S.cand[rank] = (uint32_t)((wb + src) * 64 + lane);
                     }
-                    ncand += __popcll(Wk);
+                    nc0 += __popcll(Wk);
                 }
             }
-            ncand = min(ncand, 64);
-            __builtin_amdgcn_wave_barrier();
-            if (lane < ncand) mycand = cw[lane];
+            if (lane == 0) S.ctl[0] = min(nc0, 64);
         }
+        LVL_FINE(0);
+        __syncthreads();
+        const int ncand = S.ctl[0];
+        LVL_FINE(1);
         LVL_PHASE(1);
         if (ncand == 0) { need_rise = true; continue; }            // F ran empty: the level rises
+        const uint32_t mycand = lane < ncand ? S.cand[lane] : LVL_NONE;
         ++n_rounds;
-        int a;
+        const int nk = m <= (uint32_t)LVL_RING2 ? (int)S.rcnt[m] : 0;
+        const bool slow = m > (uint32_t)LVL_RING2, fast = !slow && nk <= LVL_FAST_NK;
+        int a = 1;
         bool dropped = false;
-        uint32_t m2 = 0;
-        if (m > (uint32_t)LVL_RING2) {
-            a = 1;                                                     // beyond the ring table: one node, then a rise
-            need_rise = true;
-        } else {
-            // ---- probes: wavefront w takes candidates w, w + 16, w + 32, w + 48
-            if (wave < ncand) {
-                uint32_t fi[4], dmin[4], nmin[4];
+        uint32_t m2 = LVL_NONE;
+        // this wavefront's candidates: wave, wave + 16, wave + 32, wave + 48
+        uint32_t fi[4], cell0[4], ci[4];
+        const int nc = slow ? 0 : max(0, (ncand - wave + NW16 - 1) / NW16);
+        LvlFound fo[2];
+        fo[0].ent = fo[1].ent = 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) fi[u] = (uint32_t)__builtin_amdgcn_readlane((int)mycand, wave + NW16 * u);
-                const int nc = (ncand - wave + NW16 - 1) / NW16;
-                if (nc == 1) {
-                    uint32_t f1[1] = {fi[0]}, d1[1], n1[1];
-                    lvl_discs<1, false>(S, A, f1, 1, m, d1, n1);
-                    dmin[0] = d1[0]; nmin[0] = n1[0];
-                } else {
-                    lvl_discs<4, false>(S, A, fi, nc, m, dmin, nmin);
+        for (int u = 0; u < 4; ++u) { fo[0].mr[u] = fo[1].mr[u] = LVL_NONE; fo[0].j[u] = fo[1].j[u] = 0; }
+        if (slow) {
+            need_rise = true;                                          // beyond the ring table: one node, then a rise
+        } else {
+            if (nc > 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    fi[u] = u < nc ? S.cand[wave + NW16 * u] : 0u;
+                    const uint32_t v = S.rc[fi[u]];
+                    cell0[u] = ((v & 255) + LVL_PAD) * (uint32_t)gw + (v >> 8) + LVL_PAD;
+                    ci[u] = S.corei[fi[u]] & ~LVL_TREE;
                 }
+                if (stamps && __builtin_amdgcn_readfirstlane((int)ci[0]) == 0x7FFFFFFF) __builtin_trap();   // (forces the loads to complete before the stamp)
+                LVL_FINE(2);
+                uint32_t dmin[4] = {LVL_NONE, LVL_NONE, LVL_NONE, LVL_NONE}, nmin[4] = {LVL_NONE, LVL_NONE, LVL_NONE, LVL_NONE};
+                if (fast) {
+#pragma unroll
+                    for (int cidx = 0; cidx < 2; ++cidx) {
+                        if (cidx * 64 >= nk) break;
+                        if (nc == 1) {
+                            const uint32_t c1[1] = {cell0[0]}, i1[1] = {ci[0]};
+                            LvlFound t;
+                            // one candidate: the single-width body (fewer instructions)
+                            const bool valid = cidx * 64 + lane < nk;
+                            const uint2 o = S.ring[valid ? cidx * 64 + lane : 0];
+                            const uint32_t cell = c1[0] + o.y;
+                            const OccW ow = S.occ[cell >> 5];
+                            const bool in = valid && ((ow.bits >> (cell & 31u)) & 1u);
+                            t.j[0] = in ? ow.base + (uint32_t)__popc(ow.bits & ((1u << (cell & 31u)) - 1u)) : 0u;
+                            const uint32_t cj = S.corei[t.j[0]], fw = S.F[t.j[0] >> 5];
+                            const uint32_t mr = max(max(o.x, cj), i1[0]);
+                            fo[cidx].j[0] = t.j[0];
+                            fo[cidx].mr[0] = in ? mr : LVL_NONE;
+                            fo[cidx].ent = (in && mr == m && !((fw >> (t.j[0] & 31u)) & 1u)) ? 1u : 0u;
+                        } else {
+                            lvl_chunk<4>(S, cell0, ci, nc, cidx * 64 + lane, nk, m, fo[cidx]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (fo[cidx].mr[u] < m) dmin[u] = min(dmin[u], fo[cidx].mr[u]);
+                            if (fo[cidx].ent & (1u << u)) nmin[u] = min(nmin[u], fo[cidx].j[u]);
+                        }
+                    }
+                } else {
+                    for (int base = 0; base < nk; base += 64) {
+                        LvlFound t;
+                        lvl_chunk<4>(S, cell0, ci, nc, base + lane, nk, m, t);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (t.mr[u] < m) dmin[u] = min(dmin[u], t.mr[u]);
+                            if (t.ent & (1u << u)) nmin[u] = min(nmin[u], t.j[u]);
+                        }
+                    }
+                }
+                if (stamps && __builtin_amdgcn_readfirstlane((int)(dmin[0] & nmin[0] & nmin[1] & nmin[2] & nmin[3])) == 0x7FFFFFF1) __builtin_trap();
+                LVL_FINE(3);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (u < nc && lane == 0) S.slot[wave + NW16 * u] = make_uint2(dmin[u], nmin[u]);
+                    if (u < nc) {
+                        const uint32_t dm = __ballot(dmin[u] != LVL_NONE) ? wave_min_u32(dmin[u]) : LVL_NONE;
+                        const uint32_t nm = __ballot(nmin[u] != LVL_NONE) ? wave_min_u32(nmin[u]) : LVL_NONE;
+                        if (lane == 0) S.slot[wave + NW16 * u] = make_uint2(dm, nm);
+                    }
             }
+            LVL_FINE(4);
             __syncthreads();
+            LVL_FINE(5);
             LVL_PHASE(2);
             // ---- accepted prefix (every wavefront computes the same)
             uint2 sl = make_uint2(LVL_NONE, LVL_NONE);
@@ -991,40 +1185,68 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
             const uint32_t cj = S.corei[mycand];
             S.tnode[cnt + lane] = make_uint2((v & 255) | ((v >> 8) << 16), cj);
             S.corei[mycand] = cj | LVL_TREE;
-            if (!dropped) atomicAnd(&S.F[mycand >> 6], ~(1ull << (mycand & 63)));
+            if (!dropped) atomicAnd(&S.F[mycand >> 5], ~(1u << (mycand & 31u)));
         }
-        if (dropped) for (int i = tid; i < NFW; i += TB) S.F[i] = 0ull;
+        LVL_FINE(6);
         cur = (uint32_t)__builtin_amdgcn_readlane((int)mycand, a - 1);
         cnt += a;
+        if (cnt >= N) break;
+        if (slow) { __syncthreads(); LVL_PHASE(3); continue; }
+        if (!dropped && fast) {
+            // entrants of this wavefront's accepted candidates, straight from the registers of the probe
+#pragma unroll
+            for (int cidx = 0; cidx < 2; ++cidx)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (wave + NW16 * u < a && (fo[cidx].ent & (1u << u)))
+                        atomicOr(&S.F[fo[cidx].j[u] >> 5], 1u << (fo[cidx].j[u] & 31u));
+            LVL_FINE(7);
+            __syncthreads();
+            LVL_FINE(8);
+            LVL_PHASE(3);
+            continue;
+        }
+        // drop, or a disc too large for the registers: F is rebuilt / extended by a second walk of the discs, after
+        // the tree membership of this round's nodes is visible
+        if (dropped) for (int i = tid; i < 2 * NF64; i += TB) S.F[i] = 0u;
         __syncthreads();
         LVL_PHASE(3);
-        if (cnt >= N) break;
-        if (!need_rise) {
-            uint32_t du[4], nu[4];
-            if (dropped) {
-                if (wave == ((a - 1) & (NW16 - 1))) {
-                    uint32_t f1[1] = {cur}, d1[1], n1[1];
-                    lvl_discs<1, true>(S, A, f1, 1, m2, d1, n1);
-                }
-                m = m2;
-            } else if (wave < a) {
-                uint32_t fi[4];
+        {
+            const uint32_t target = dropped ? m2 : m;
+            const int nkt = (int)S.rcnt[target];
+            // after a drop only the last accepted candidate's disc counts (the points whose mr is the new level)
+            const int first = dropped ? a - 1 : 0;
+            uint32_t c2[4], i2[4];
+            int nc2 = 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) fi[u] = (uint32_t)__builtin_amdgcn_readlane((int)mycand, wave + NW16 * u);
-                const int nc = (a - wave + NW16 - 1) / NW16;
-                if (nc == 1) {
-                    uint32_t f1[1] = {fi[0]}, d1[1], n1[1];
-                    lvl_discs<1, true>(S, A, f1, 1, m, d1, n1);
-                } else {
-                    lvl_discs<4, true>(S, A, fi, nc, m, du, nu);
-                }
+            for (int u = 0; u < 4; ++u) {
+                const int i = wave + NW16 * u;
+                const bool on = i >= first && i < a;
+                const uint32_t fcand = on ? S.cand[i] : 0u;
+                const uint32_t v = S.rc[fcand];
+                c2[u] = ((v & 255) + LVL_PAD) * (uint32_t)gw + (v >> 8) + LVL_PAD;
+                i2[u] = on ? (S.corei[fcand] & ~LVL_TREE) : LVL_NONE;  // an unused slot never matches the target
+                if (on) nc2 = u + 1;
             }
-            __syncthreads();
-            LVL_PHASE(4);
+            if (nc2 > 0)
+                for (int base = 0; base < nkt; base += 64) {
+                    LvlFound t;
+                    lvl_chunk<4>(S, c2, i2, nc2, base + lane, nkt, target, t);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (t.mr[u] == target) atomicOr(&S.F[t.j[u] >> 5], 1u << (t.j[u] & 31u));
+                }
+            if (dropped) m = m2;
         }
+        __syncthreads();
+        LVL_PHASE(4);
     }
-    if (tid == 0) { hdr[12] = (int)(wall_clock64() - t0); hdr[16] = n_rounds; hdr[17] = n_rises;
-                    for (int i = 0; i < 5; ++i) hdr[18 + i] = (int)ph[i]; }
+    if (tid == 0) {
+        hdr[12] = (int)(wall_clock64() - t0); hdr[16] = n_rounds; hdr[17] = n_rises;
+        for (int i = 0; i < 5; ++i) hdr[18 + i] = (int)ph[i];
+        for (int i = 0; i < 7; ++i) hdr[25 + i] = (int)fine[i];
+        hdr[5] = (int)fine[7]; hdr[6] = (int)fine[8];
+    }
 }
 
 // One 1x5 (ROWS) or 5x1 pass of the separable grey CLOSE over a map in LDS: MAX = dilate, else erode; samples
@@ -2042,7 +2264,7 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
             // maps of up to LVL_CAP points: the level-bucketed Prim; larger ones (or all, SVC_PRIM_LVL=0): one node per step
             const int n_min = h->prim_lvl ? LVL_CAP : 0;
             if (h->prim_lvl) {
-                k_prim_lvl<<<m, TB, lvl_lds_bytes(hw, h->tail_n_offsets), s>>>(A);
+                k_prim_lvl<<<m, TB, lvl_lds_bytes(height, width, h->tail_n_offsets), s>>>(A);
                 SVC_CHECK_LAUNCH();
             } else {
                 if (h->prim_pt <= 2) { k_prim_pt<2><<<m, TB, lds_prim, s>>>(A, n_min); SVC_CHECK_LAUNCH(); }

@@ -6,10 +6,11 @@ from retargetvid_amd import ops, synth, weights
 from oracle import pipeline_ref as P
 eng = ops.Engine(weights.make_synthetic_state_dict(0))
 CP = P.init_crop_params()
-fr = torch.from_numpy(synth.blob_frames(32, 360, 640, seed=100)).cuda()
+sg = os.environ.get('SIGMA')
+fr = torch.from_numpy(synth.blob_frames(32, 360, 640, seed=int(os.environ.get('SEED', 100)), **(dict(sigma=tuple(float(x) for x in sg.split(','))) if sg else {}))).cuda()
 small = eng.resize_frames(fr, 140, 250)
 maps = eng.saliency(small)
-eng.threshold_(maps, CP['t_threshold'])
+eng.threshold_(maps, int(os.environ.get('THRESH', CP['t_threshold'])))
 n = (maps != 0).flatten(1).sum(1).cpu().numpy()
 print('N per map: min %d mean %.0f max %d' % (n.min(), n.mean(), n.max()), n[:8])
 flags = np.zeros(32, np.uint8); flags[:2] = 1
@@ -28,6 +29,9 @@ for i in range(0, 32, 6):
     h = st['hdr']
     print('  map %2d: N=%5d clusters %3d  stamps (us, 100 MHz wall clock): k_sort %.1f | k_tree built %.1f hierarchy %.1f chosen %.1f | '
           'k_finish %.1f | k_prim %.1f' % (i, st['n'], h[4], h[8] / 100.0, h[13] / 100.0, h[9] / 100.0, h[10] / 100.0, h[11] / 100.0, h[12] / 100.0))
+    print('           k_tree shader clock %.0f MHz' % (h[14] / max(h[15], 1) * 100.0))
     if h[16]:
         print('           k_prim_lvl: %d rounds, %d rises; setup %.1f us, phases (us): rise %.1f extract %.1f probe %.1f commit %.1f mark %.1f' % (
             h[16], h[17], h[24] / 100.0, h[18] / 100.0, h[19] / 100.0, h[20] / 100.0, h[21] / 100.0, h[22] / 100.0))
+        print('           fine (us): extract loop %.1f barrier+ctl %.1f | cand loads %.1f chunks %.1f reduce+slot %.1f barrier %.1f | accept+commit writes %.1f atomics %.1f barrier %.1f' % tuple(
+            x / 100.0 for x in list(h[25:32]) + [h[5], h[6]]))

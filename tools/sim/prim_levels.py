@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from oracle import hdbscan_ref as H
 
 INF = 1 << 40
+NBMAX_TEST = int(os.environ.get('NBMAX', 256))
 RING_R = 20
 RING2 = RING_R * RING_R
 
@@ -30,7 +31,7 @@ def ring_table():
 RING = ring_table()
 
 
-def prim_levels(X, core, hw, cap=64, stats=None):
+def prim_levels(X, core, hw, cap=64, stats=None, nbmax=256):
     n = len(X)
     h, w = hw
     X = X.astype(np.int64)
@@ -47,13 +48,65 @@ def prim_levels(X, core, hw, cap=64, stats=None):
     m = None
     st = dict(rounds=0, rises=0, drops=0, slow=0, probes=0)
 
+    # pruned rise (what the kernel does): the nodes added since the last rise form batches of <= 64 with a bounding box
+    # and a smallest core distance; a (batch, chunk of 64 points) block is relaxed only when its lower bound
+    # max(box distance^2, smallest cores) does not exceed UB0 = the minimum of R before the rise; blocks stay pending
+    nch = (n + 63) // 64
+    cbox = [(X[c * 64:c * 64 + 64, 0].min(), X[c * 64:c * 64 + 64, 0].max(), X[c * 64:c * 64 + 64, 1].min(),
+             X[c * 64:c * 64 + 64, 1].max(), core[c * 64:c * 64 + 64].min()) for c in range(nch)]
+    batches = []            # (start, len, rmin, rmax, cmin, cmax, coremin)
+    processed = []          # per batch: set of chunks
+    NBMAX = nbmax
+
+    def relax_block(b, c):
+        s0, ln = batches[b][0], batches[b][1]
+        sl = slice(c * 64, min(n, c * 64 + 64))
+        for t in seq[s0:s0 + ln]:
+            d = (X[sl, 0] - X[t, 0]) ** 2 + (X[sl, 1] - X[t, 1]) ** 2
+            R[sl] = np.minimum(R[sl], np.maximum(np.maximum(d, core[sl]), core[t]))
+        R[intree] = INF                  # (the kernel: tree members carry an infinite core distance)
+        st['blocks'] = st.get('blocks', 0) + 1
+
     def rise():
         nonlocal done, m
         st['rises'] += 1
-        for t in seq[done:]:
-            d = (X[:, 0] - X[t, 0]) ** 2 + (X[:, 1] - X[t, 1]) ** 2
-            np.minimum(R, np.maximum(np.maximum(d, core), core[t]), out=R)
+        R[intree] = INF
+        new = list(range(done, len(seq), 64))
+        if len(batches) + len(new) > NBMAX:          # table full: settle every pending block, start afresh
+            for b in range(len(batches)):
+                for c in range(nch):
+                    if c not in processed[b] and not intree[c * 64:c * 64 + 64].all():
+                        relax_block(b, c)
+            batches.clear(); processed.clear()
+            st['flushes'] = st.get('flushes', 0) + 1
+        for s0 in new:
+            t = np.array(seq[s0:min(len(seq), s0 + 64)])
+            batches.append((s0, len(t), X[t, 0].min(), X[t, 0].max(), X[t, 1].min(), X[t, 1].max(), core[t].min()))
+            processed.append(set())
         done = len(seq)
+
+        def lower(b, c):
+            r0, r1, c0, c1, cm = cbox[c]
+            s0, ln, br0, br1, bc0, bc1, bm = batches[b]
+            dr = max(0, br0 - r1, r0 - br1); dc = max(0, bc0 - c1, c0 - bc1)
+            return max(dr * dr + dc * dc, bm, cm)
+
+        def sweep(limit, nearest_only=False):
+            for c in range(nch):
+                if intree[c * 64:c * 64 + 64].all():
+                    continue
+                todo = [(lower(b, c), b) for b in range(len(batches)) if c not in processed[b]]
+                todo = [x for x in todo if x[0] <= limit]
+                if nearest_only and todo:
+                    todo = [min(todo)]
+                for _, b in todo:
+                    relax_block(b, c); processed[b].add(c)
+
+        ub0 = R.min()
+        sweep(min(ub0, 64))
+        if ub0 > 64:                                  # a far jump: tighten the bound before the wide sweep
+            sweep(R.min(), nearest_only=True)
+            sweep(R.min())
         R[intree] = INF
         m = R.min()
         F[:] = R == m
@@ -131,10 +184,11 @@ def check(X, hw, mcs, ms, tag):
     core = H.core_distances(X, k)
     ou, ov, ow = H.prim_mst(X, core)
     st = {}
-    u, v, w = prim_levels(X, core, hw, stats=st)
+    u, v, w = prim_levels(X, core, hw, stats=st, nbmax=NBMAX_TEST)
     assert np.array_equal(u, ou) and np.array_equal(v, ov) and np.array_equal(w, ow), tag
-    print('%-18s N=%5d rounds %4d (%.1f nodes/round) rises %3d drops %3d slow %3d probes/node %.0f' % (
-        tag, n, st['rounds'], (n - 1) / st['rounds'], st['rises'], st['drops'], st['slow'], st['probes'] / n), flush=True)
+    nb = (n + 63) // 64
+    print('%-18s N=%5d rounds %4d (%.1f nodes/round) rises %3d drops %3d slow %3d probes/node %.0f | blocks relaxed %d of %d (all pairs), flushes %d' % (
+        tag, n, st['rounds'], (n - 1) / st['rounds'], st['rises'], st['drops'], st['slow'], st['probes'] / n, st.get('blocks', 0), nb * nb, st.get('flushes', 0)), flush=True)
 
 
 def main():

@@ -281,6 +281,7 @@ __global__ __launch_bounds__(TB) void k_compact(TailArgs A) {
         hdr[1] = 0;
         hdr[2] = -1;
         hdr[3] = (A.clust_filt && total > A.mcs + 1) ? 1 : 0;
+        hdr[23] = 0;                                                     // k_tree_par sets it when it has done the map's hierarchy
     }
 }
 
@@ -949,8 +950,6 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
     long long ph[5] = {0, 0, 0, 0, 0}, tp = wall_clock64();        // phase stamps (10 ns units): rise, extract, probe, accept + commit, mark
     const bool stamps = (A.prim_lvl & 2) != 0;                      // SVC_PRIM_LVL=3: phase stamps (each costs a scalar memory round trip)
 #define LVL_PHASE(i) do { if (stamps) { const long long tn_ = wall_clock64(); ph[i] += tn_ - tp; tp = tn_; } } while (0)
-    long long fine[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq = tp;   // finer stamps inside a round (wavefront 0)
-#define LVL_FINE(i) do { if (stamps) { const long long tn_ = wall_clock64(); fine[i] += tn_ - tq; tq = tn_; } } while (0)
     if (tid == 0) hdr[24] = (int)(tp - t0);
     __syncthreads();
     // minimum of R over the block (all wavefronts get it); one barrier
@@ -1058,7 +1057,6 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
             LVL_PHASE(0);
         }
         // ---- wavefront 0: the first 64 members of F, in index order
-        if (stamps) tq = wall_clock64();
         if (wave == 0) {
             int nc0 = 0;
             for (int wb = 0; wb < NF64 && nc0 < 64; wb += 64) {
@@ -1078,10 +1076,8 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
             }
             if (lane == 0) S.ctl[0] = min(nc0, 64);
         }
-        LVL_FINE(0);
         __syncthreads();
         const int ncand = S.ctl[0];
-        LVL_FINE(1);
         LVL_PHASE(1);
         if (ncand == 0) { need_rise = true; continue; }            // F ran empty: the level rises
         const uint32_t mycand = lane < ncand ? S.cand[lane] : LVL_NONE;
@@ -1109,8 +1105,6 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
                     cell0[u] = ((v & 255) + LVL_PAD) * (uint32_t)gw + (v >> 8) + LVL_PAD;
                     ci[u] = S.corei[fi[u]] & ~LVL_TREE;
                 }
-                if (stamps && __builtin_amdgcn_readfirstlane((int)ci[0]) == 0x7FFFFFFF) __builtin_trap();   // (forces the loads to complete before the stamp)
-                LVL_FINE(2);
                 uint32_t dmin[4] = {LVL_NONE, LVL_NONE, LVL_NONE, LVL_NONE}, nmin[4] = {LVL_NONE, LVL_NONE, LVL_NONE, LVL_NONE};
                 if (fast) {
 #pragma unroll
@@ -1151,8 +1145,6 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
                         }
                     }
                 }
-                if (stamps && __builtin_amdgcn_readfirstlane((int)(dmin[0] & nmin[0] & nmin[1] & nmin[2] & nmin[3])) == 0x7FFFFFF1) __builtin_trap();
-                LVL_FINE(3);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (u < nc) {
@@ -1161,9 +1153,7 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
                         if (lane == 0) S.slot[wave + NW16 * u] = make_uint2(dm, nm);
                     }
             }
-            LVL_FINE(4);
             __syncthreads();
-            LVL_FINE(5);
             LVL_PHASE(2);
             // ---- accepted prefix (every wavefront computes the same)
             uint2 sl = make_uint2(LVL_NONE, LVL_NONE);
@@ -1187,7 +1177,6 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
             S.corei[mycand] = cj | LVL_TREE;
             if (!dropped) atomicAnd(&S.F[mycand >> 5], ~(1u << (mycand & 31u)));
         }
-        LVL_FINE(6);
         cur = (uint32_t)__builtin_amdgcn_readlane((int)mycand, a - 1);
         cnt += a;
         if (cnt >= N) break;
@@ -1200,9 +1189,7 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
                 for (int u = 0; u < 4; ++u)
                     if (wave + NW16 * u < a && (fo[cidx].ent & (1u << u)))
                         atomicOr(&S.F[fo[cidx].j[u] >> 5], 1u << (fo[cidx].j[u] & 31u));
-            LVL_FINE(7);
             __syncthreads();
-            LVL_FINE(8);
             LVL_PHASE(3);
             continue;
         }
@@ -1244,8 +1231,6 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
     if (tid == 0) {
         hdr[12] = (int)(wall_clock64() - t0); hdr[16] = n_rounds; hdr[17] = n_rises;
         for (int i = 0; i < 5; ++i) hdr[18 + i] = (int)ph[i];
-        for (int i = 0; i < 7; ++i) hdr[25 + i] = (int)fine[i];
-        hdr[5] = (int)fine[7]; hdr[6] = (int)fine[8];
     }
 }
 
@@ -1906,7 +1891,7 @@ __global__ __launch_bounds__(64) void k_tree(TailArgs A) {
     const int f = A.order[blockIdx.x];
     uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
     int32_t *hdr = (int32_t *)(ws + A.L.hdr);
-    if (!hdr[3]) return;
+    if (!hdr[3] || hdr[23]) return;
     const int N = hdr[0];
     extern __shared__ uint8_t sm_tree[];
     __shared__ TreeShared S;
@@ -1916,6 +1901,374 @@ __global__ __launch_bounds__(64) void k_tree(TailArgs A) {
     if (N <= TREE_LDS_CAP) best = cluster_phase<true>(A, ws, sm_tree, S, hdr, N, t0);
     if (best == -2) best = cluster_phase<false>(A, ws, sm_tree, S, hdr, N, t0);
     if (threadIdx.x == 0) { hdr[14] = (int)(clock64() - c0); hdr[15] = (int)(wall_clock64() - t0); }
+}
+
+// --------------------------------------------------------------------------------------
+// k_tree_par: the hierarchy as data-parallel passes (tools/sim/tree_path.py is the executable specification, checked
+// against oracle/hdbscan_ref: single_linkage -> condense_tree -> select_and_label).
+//
+// The library's Prim records every edge as (last node added, new node, weight), so the "MST" that its single
+// linkage sees is a PATH through the points in Prim order: edge k joins positions k and k + 1, and the union-find
+// pass over the edges in sorted order merges ADJACENT INTERVALS.  Hence, with rank = an edge's sorted position:
+//   * when edge k is processed its sides reach out to the nearest edges of greater rank: a side (left) = k - PGE(k)
+//     points, b side = NGE(k) - k; the dendrogram is the Cartesian tree of the ranks, parent(k) = the lower-ranked of
+//     PGE(k), NGE(k);
+//   * by its side sizes alone an edge is a small union, the birth of a condensed cluster, a true split or an absorption;
+//     clusters are numbered in rank order of their birth / split (= hdb::build's creation order);
+//   * the cluster on top of a big side is found by following "big child" links down to the first birth / split
+//     (pointer jumping, with the distance: the rows of a cluster in the library's order are its chain top-down);
+//   * a point falls out at the first ancestor of its leaf that is not a small union.
+// Only the float64 stability sums stay serial per cluster (one wavefront per cluster: terms in parallel, additions in
+// the library's order), as in hdb::accumulate.  N - 1 serial union-find steps become ~15 block-wide passes.
+// --------------------------------------------------------------------------------------
+#define TP_CAP 4352                     // points per map kept in LDS (above: k_tree)
+#define TP_NONE 0xFFFFu
+enum { TP_SMALL = 0, TP_BIRTH = 1, TP_SPLIT = 2, TP_ABS_A = 3, TP_ABS_B = 4 };   // ABS_A: the a side is big, the b side falls out
+
+struct TpCl {            // per condensed cluster
+    double *acc;
+    uint32_t *birthw, *minw, *weight;
+    uint16_t *tp, *left, *right, *spa, *spb, *node, *topk, *off, *len;
+    int16_t *rep;
+    uint8_t *sel;
+};
+
+static size_t tp_lds_bytes(int hw, int mcs, int *cap_clusters) {
+    const int cap = std::min(hw, TP_CAP);
+    auto up = [](size_t b) { return (b + 15) / 16 * 16; };
+    const size_t per_edge = up((size_t)cap * 2) * 8 + up((size_t)(cap + 256) * 2) + up((size_t)cap * 4) * 3 + up((size_t)((cap + 256) / 16 + 16) * 2) + 64;
+    int cc = hdb::max_clusters(cap, mcs);
+    const size_t budget = 160 * 1024 - 4096;
+    while (cc > 8 && per_edge + (size_t)cc * 48 + 512 > budget) cc /= 2;
+    *cap_clusters = cc;
+    return per_edge + (size_t)cc * 48 + 512;
+}
+
+// bit i set when the i-th of the 16 uint16 at p (32-byte aligned) is greater than r
+__device__ __forceinline__ uint32_t tp_gt_mask16(const uint16_t *p, uint32_t r) {
+    const uint4 a = ((const uint4 *)p)[0], b = ((const uint4 *)p)[1];
+    const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m |= ((v[i] & 0xFFFFu) > r ? 1u << (2 * i) : 0u) | ((v[i] >> 16) > r ? 2u << (2 * i) : 0u);
+    return m;
+}
+
+__device__ __forceinline__ int tp_class(int sa, int sb, int mcs) {
+    if (sa + sb < mcs) return TP_SMALL;
+    if (sa < mcs && sb < mcs) return TP_BIRTH;
+    if (sa >= mcs && sb >= mcs) return TP_SPLIT;
+    return sa >= mcs ? TP_ABS_A : TP_ABS_B;
+}
+
+__global__ __launch_bounds__(TB) void k_tree_par(TailArgs A, int cap_clusters) {
+    const int f = A.order[blockIdx.x];
+    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
+    int32_t *hdr = (int32_t *)(ws + A.L.hdr);
+    if (!hdr[3]) return;
+    const int N = hdr[0];
+    if (N > TP_CAP) return;                                            // k_tree takes it
+    const int E = N - 1, mcs = A.mcs;
+    extern __shared__ uint8_t sm_tp[];
+    __shared__ int lds16[NW16];
+    __shared__ int sh_nc, sh_nsel;
+#define TP_STAMP(i) do { if (tid == 0) hdr[25 + (i)] = (int)(wall_clock64() - t0); } while (0)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long t0 = wall_clock64();
+    const int cap = min(A.h * A.w, TP_CAP);
+    uint8_t *p = sm_tp;
+    uint16_t *order = carve<uint16_t>(p, cap), *rho = carve<uint16_t>(p, cap + 256), *sa = carve<uint16_t>(p, cap), *sb = carve<uint16_t>(p, cap);
+    uint16_t *par = carve<uint16_t>(p, cap), *lch = carve<uint16_t>(p, cap), *rch = carve<uint16_t>(p, cap), *cid = carve<uint16_t>(p, cap);
+    uint16_t *rowlist = carve<uint16_t>(p, cap);
+    uint32_t *w = carve<uint32_t>(p, cap), *jA = carve<uint32_t>(p, cap), *jB = carve<uint32_t>(p, cap);
+    uint16_t *l1 = carve<uint16_t>(p, (cap + 256) / 16 + 16), *l2 = carve<uint16_t>(p, 32);
+    TpCl C;
+    C.acc = carve<double>(p, cap_clusters);
+    C.birthw = carve<uint32_t>(p, cap_clusters); C.minw = carve<uint32_t>(p, cap_clusters); C.weight = carve<uint32_t>(p, cap_clusters);
+    C.tp = carve<uint16_t>(p, cap_clusters); C.left = carve<uint16_t>(p, cap_clusters); C.right = carve<uint16_t>(p, cap_clusters);
+    C.spa = carve<uint16_t>(p, cap_clusters); C.spb = carve<uint16_t>(p, cap_clusters); C.node = carve<uint16_t>(p, cap_clusters);
+    C.topk = carve<uint16_t>(p, cap_clusters); C.off = carve<uint16_t>(p, cap_clusters); C.len = carve<uint16_t>(p, cap_clusters);
+    C.rep = carve<int16_t>(p, cap_clusters); C.sel = carve<uint8_t>(p, cap_clusters);
+    const hdb::Edge *mst = (const hdb::Edge *)(ws + A.L.mst);
+    const uint16_t *perm = (const uint16_t *)(ws + A.L.eb);            // k_sort: sorted position -> Prim position
+    // ---- ranks, weights, block maxima of the ranks
+    for (int s0 = tid; s0 < E; s0 += TB) {
+        const uint32_t k = perm[s0];
+        order[s0] = (uint16_t)k;
+        rho[k] = (uint16_t)s0;
+        w[s0] = mst[s0].w;                                             // (index = Prim position)
+        lch[s0] = rch[s0] = TP_NONE;
+    }
+    for (int i = E + tid; i < ((E + 255) & ~255); i += TB) rho[i] = 0;     // padding: never "greater"
+    __syncthreads();
+    // maxima over groups of 16 ranks and over groups of 16 groups (the rank array is padded with zeros to whole groups)
+    const int n1 = (E + 15) >> 4, n2 = (n1 + 15) >> 4;
+    for (int g = tid; g < n2 * 16; g += TB) {
+        uint32_t mx = 0;
+        if (g < n1) {
+            const uint4 a = ((const uint4 *)(rho + 16 * g))[0], b = ((const uint4 *)(rho + 16 * g))[1];
+            const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mx = max(mx, max(v[i] & 0xFFFFu, v[i] >> 16));
+        }
+        l1[g] = (uint16_t)mx;
+    }
+    __syncthreads();
+    for (int g = tid; g < 32; g += TB) {
+        uint32_t mx = 0;
+        if (g < n2) for (int i = 0; i < 16; ++i) mx = max(mx, (uint32_t)l1[16 * g + i]);
+        l2[g] = (uint16_t)mx;
+    }
+    __syncthreads();
+    // ---- nearest greater ranks on both sides -> side sizes, Cartesian-tree parent, children
+    for (int k = tid; k < E; k += TB) {
+        const uint32_t r = rho[k];
+        const int g0 = k >> 4, s0 = g0 >> 4;
+        // right: first position > k whose rank is greater
+        int nge = E;
+        {
+            uint32_t m = tp_gt_mask16(rho + 16 * g0, r) & ~((2u << (k & 15)) - 1u);
+            if (m) nge = 16 * g0 + __builtin_ctz(m);
+            else {
+                int g = -1;
+                uint32_t m1 = tp_gt_mask16(l1 + 16 * s0, r) & ~((2u << (g0 & 15)) - 1u);
+                if (m1) g = 16 * s0 + __builtin_ctz(m1);
+                else {
+                    uint32_t m2 = (tp_gt_mask16(l2, r) | (tp_gt_mask16(l2 + 16, r) << 16)) & ~((2u << s0) - 1u);
+                    if (s0 >= 31) m2 = 0;
+                    if (m2) {
+                        const int sx = __builtin_ctz(m2);
+                        g = 16 * sx + __builtin_ctz(tp_gt_mask16(l1 + 16 * sx, r));
+                    }
+                }
+                if (g >= 0) nge = 16 * g + __builtin_ctz(tp_gt_mask16(rho + 16 * g, r));
+            }
+        }
+        // left: last position < k whose rank is greater
+        int j = -1;
+        {
+            uint32_t m = tp_gt_mask16(rho + 16 * g0, r) & ((1u << (k & 15)) - 1u);
+            if (m) j = 16 * g0 + 31 - __builtin_clz(m);
+            else {
+                int g = -1;
+                uint32_t m1 = tp_gt_mask16(l1 + 16 * s0, r) & ((1u << (g0 & 15)) - 1u);
+                if (m1) g = 16 * s0 + 31 - __builtin_clz(m1);
+                else {
+                    const uint32_t m2 = (tp_gt_mask16(l2, r) | (tp_gt_mask16(l2 + 16, r) << 16)) & ((1u << s0) - 1u);
+                    if (m2) {
+                        const int sx = 31 - __builtin_clz(m2);
+                        g = 16 * sx + 31 - __builtin_clz(tp_gt_mask16(l1 + 16 * sx, r));
+                    }
+                }
+                if (g >= 0) j = 16 * g + 31 - __builtin_clz(tp_gt_mask16(rho + 16 * g, r));
+            }
+        }
+        const int pge = j < 0 ? -1 : j;
+        sa[k] = (uint16_t)(k - pge);
+        sb[k] = (uint16_t)(nge - k);
+        int pr = -1;
+        if (pge >= 0 && (nge >= E || rho[pge] < rho[nge])) pr = pge;
+        else if (nge < E) pr = nge;
+        par[k] = pr < 0 ? TP_NONE : (uint16_t)pr;
+        if (pr >= 0) { if (k < pr) lch[pr] = (uint16_t)k; else rch[pr] = (uint16_t)k; }
+    }
+    __syncthreads();
+    TP_STAMP(1);
+    // ---- clusters in creation order (= rank order of the births and splits)
+    {
+        const int per = (E + TB - 1) / TB, lo = min(E, tid * per), hi = min(E, lo + per);
+        int cnt = 0;
+        for (int s0 = lo; s0 < hi; ++s0) {
+            const int k = order[s0], cl = tp_class(sa[k], sb[k], mcs);
+            cnt += cl == TP_BIRTH || cl == TP_SPLIT;
+        }
+        int tot;
+        int id = block_excl_scan(cnt, lds16, &tot);
+        if (tid == 0) sh_nc = tot;
+        for (int s0 = lo; s0 < hi; ++s0) {
+            const int k = order[s0], cl = tp_class(sa[k], sb[k], mcs);
+            const bool isc = cl == TP_BIRTH || cl == TP_SPLIT;
+            cid[k] = isc ? (uint16_t)id : TP_NONE;
+            if (isc && id < cap_clusters) { C.node[id] = (uint16_t)k; C.minw[id] = w[k]; C.tp[id] = TP_NONE; C.birthw[id] = 0; C.acc[id] = 0.0; C.weight[id] = 0; }
+            id += isc;
+            // jump pointer: (next edge down the chain of the big side) | distance << 16; births, splits, small unions end it
+            const uint32_t nx = cl == TP_ABS_A ? lch[k] : (cl == TP_ABS_B ? rch[k] : (uint32_t)k);
+            jA[k] = nx | ((nx != (uint32_t)k ? 1u : 0u) << 16);
+        }
+    }
+    __syncthreads();
+    const int nc = sh_nc;
+    if (nc > cap_clusters) return;                                     // tables too small: k_tree redoes the map (hdr[23] stays 0)
+    TP_STAMP(2);
+    // ---- pointer jumping down the big-child chains: every absorption learns its cluster's first edge and its distance to it
+    uint32_t *ja = jA, *jb = jB;
+    for (int round = 0; round < 16; ++round) {
+        int changed = 0;
+        for (int k = tid; k < E; k += TB) {
+            const uint32_t a1 = ja[k], n1 = a1 & 0xFFFFu, a2 = ja[n1];
+            jb[k] = (a2 & 0xFFFFu) | ((a1 & 0xFFFF0000u) + (a2 & 0xFFFF0000u));
+            changed |= (a2 & 0xFFFFu) != n1;
+        }
+        uint32_t *t_ = ja; ja = jb; jb = t_;
+        if (!__syncthreads_or(changed)) break;
+    }
+    TP_STAMP(3);
+    // ja[k] = (edge that created the cluster of k's merged component | rows between them); cluster = cid[that edge]
+    // ---- splits: children, tree parents, birth weights; chains: top edge and length of every cluster
+    for (int k = tid; k < E; k += TB) {
+        const int cl = tp_class(sa[k], sb[k], mcs);
+        if (cl == TP_SPLIT) {
+            const uint32_t pc = cid[k];
+            const uint32_t l = cid[ja[lch[k]] & 0xFFFFu], r = cid[ja[rch[k]] & 0xFFFFu];
+            C.left[pc] = (uint16_t)l; C.right[pc] = (uint16_t)r;
+            C.tp[l] = C.tp[r] = (uint16_t)pc;
+            C.birthw[l] = C.birthw[r] = w[k];
+            C.spa[pc] = sa[k]; C.spb[pc] = sb[k];
+        } else if (cl == TP_BIRTH) {
+            C.left[cid[k]] = C.right[cid[k]] = TP_NONE;
+        }
+        if (cl != TP_SMALL) {
+            const uint32_t pr = par[k];
+            if (pr == TP_NONE || tp_class(sa[pr], sb[pr], mcs) == TP_SPLIT) {   // the top of its cluster's chain
+                const uint32_t j = ja[k], c = cid[j & 0xFFFFu];
+                C.topk[c] = (uint16_t)k;
+                C.len[c] = (uint16_t)((j >> 16) + 1);
+            }
+        }
+    }
+    __syncthreads();
+    TP_STAMP(4);
+    if (tid == 0) {                                                     // offsets of the clusters' row lists
+        uint32_t o = 0;
+        for (int c = 0; c < nc; ++c) { C.off[c] = (uint16_t)o; o += C.len[c]; }
+    }
+    __syncthreads();
+    for (int k = tid; k < E; k += TB) {
+        if (tp_class(sa[k], sb[k], mcs) == TP_SMALL) continue;
+        const uint32_t j = ja[k], c = cid[j & 0xFFFFu];
+        rowlist[C.off[c] + (C.len[c] - 1 - (j >> 16))] = (uint16_t)k;  // top of the chain first = descending rank
+    }
+    __syncthreads();
+    if (tid == 0) hdr[13] = (int)(wall_clock64() - t0);
+    // ---- stabilities: one wavefront per cluster, rows in the library's order (hdb::accumulate), terms 64 at a time
+    for (int c = wave; c < nc; c += NW16) {
+        const uint32_t bw = C.birthw[c];
+        const double birth = bw ? 1.0 / (double)bw : 0.0;
+        double acc = 0.0;
+        const int off = C.off[c], len = C.len[c];
+        for (int base = 0; base < len; base += 64) {
+            const int i = base + lane;
+            uint32_t cnt = 0;
+            double term = 0.0, ta = 0.0, tb = 0.0;
+            if (i < len) {
+                const int k = rowlist[off + i];
+                const int cl = tp_class(sa[k], sb[k], mcs);
+                const double lam = 1.0 / (double)w[k];
+                term = (lam - birth) * 1.0;
+                if (cl == TP_SPLIT) { ta = (lam - birth) * (double)C.spa[c]; tb = (lam - birth) * (double)C.spb[c]; cnt = 0; }
+                else cnt = cl == TP_BIRTH ? (uint32_t)(sa[k] + sb[k]) : (cl == TP_ABS_A ? sb[k] : sa[k]);
+            }
+            const int m = min(64, len - base);
+            if (m == 64 && __ballot(cnt != 1u) == 0ull) {              // the common batch: 64 single points falling out
+#pragma unroll
+                for (int j = 0; j < 64; ++j) acc += readlane_f64(term, j);
+                continue;
+            }
+            for (int j = 0; j < m; ++j) {
+                const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)cnt, j);
+                if (sj == 0) {
+                    acc += readlane_f64(ta, j);
+                    acc += readlane_f64(tb, j);
+                } else {
+                    const double tj = readlane_f64(term, j);
+                    for (uint32_t q = 0; q < sj; ++q) acc += tj;
+                }
+            }
+        }
+        if (lane == 0) C.acc[c] = acc;
+    }
+    __syncthreads();
+    // ---- excess of mass (hdb::choose): children before parents, then parents before children
+    if (tid == 0) {
+        for (int c = 0; c < nc; ++c) {
+            double stab = C.acc[c], sub = 0.0;
+            if (C.left[c] != TP_NONE) sub = C.acc[C.left[c]] + C.acc[C.right[c]];
+            if (sub > stab) { C.sel[c] = 0; stab = sub; } else C.sel[c] = 1;
+            C.acc[c] = stab;
+        }
+        int nsel = 0;
+        for (int c = nc - 1; c >= 0; --c) {
+            const uint32_t pp = C.tp[c];
+            if (pp != TP_NONE && C.rep[pp] >= 0) { C.sel[c] = 0; C.rep[c] = C.rep[pp]; }
+            else if (C.sel[c]) { C.rep[c] = (int16_t)c; ++nsel; }
+            else C.rep[c] = (int16_t)hdb::ROOT_NOISE;
+        }
+        sh_nsel = nsel;
+        hdr[4] = nc;
+        hdr[9] = (int)(wall_clock64() - t0);
+    }
+    // ---- (meanwhile) the edge at which every small union's component falls out: first ancestor that is not one
+    uint16_t *fo = (uint16_t *)jb;                                      // the spare jump buffer
+    for (int k = tid; k < E; k += TB) fo[k] = tp_class(sa[k], sb[k], mcs) == TP_SMALL ? par[k] : (uint16_t)k;
+    __syncthreads();
+    for (int round = 0; round < 16; ++round) {
+        int changed = 0;
+        for (int k = tid; k < E; k += TB) {
+            const uint32_t f1 = fo[k], f2 = fo[f1];
+            if (f2 != f1) { fo[k] = (uint16_t)f2; changed = 1; }
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    // ---- labels and cluster weights (hdb::point_cluster; smartVidCrop.py:1107-1114)
+    const int nsel = sh_nsel;
+    const uint32_t *pts = (const uint32_t *)(ws + A.L.pts);
+    int32_t *labels = (int32_t *)(ws + A.L.labels);
+    for (int i = tid; i < N; i += TB) {
+        int e;
+        if (i == 0) e = 0; else if (i == E) e = E - 1; else e = rho[i - 1] < rho[i] ? i - 1 : i;
+        e = fo[e];
+        const uint32_t c0 = cid[ja[e] & 0xFFFFu];
+        const int rep = C.rep[c0];
+        int lab = rep;
+        if (rep == hdb::ROOT_NOISE) lab = -1;
+        else if (rep == nc - 1 && nsel == 1) lab = w[e] <= C.minw[nc - 1] ? rep : -1;
+        const uint32_t pid = i == 0 ? mst[0].a : mst[i - 1].b;
+        labels[pid] = lab;
+        if (lab >= 0) {
+            const uint32_t val = pts[pid] >> 16;
+            if (A.select_sum == 1) atomicAdd(&C.weight[lab], val); else atomicMax(&C.weight[lab], val);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // first arg-max in the library's cluster numbering (BFS order of the dendrogram; hdb::cluster_before)
+        auto depth = [&](uint32_t k) { int d = 0; while (par[k] != TP_NONE) { k = par[k]; ++d; } return d; };
+        auto before = [&](int c1, int c2) -> bool {
+            const uint32_t p1 = C.tp[c1], p2 = C.tp[c2];
+            if (p1 == TP_NONE) return true;
+            if (p2 == TP_NONE) return false;
+            if (p1 == p2) return C.left[p1] == c1;
+            uint32_t s1 = C.node[p1], s2 = C.node[p2];
+            const int d1 = depth(s1), d2 = depth(s2);
+            if (d1 != d2) return d1 < d2;
+            uint32_t side1 = 0, side2 = 0;
+            while (s1 != s2) {
+                side1 = s1 > par[s1]; side2 = s2 > par[s2];
+                s1 = par[s1]; s2 = par[s2];
+            }
+            return side1 < side2;
+        };
+        int b = -1;
+        for (int c = 0; c < nc; ++c) {
+            if (C.rep[c] != c) continue;
+            if (b < 0 || C.weight[c] > C.weight[b] || (C.weight[c] == C.weight[b] && before(c, b))) b = c;
+        }
+        hdr[1] = nsel;
+        hdr[2] = b;
+        hdr[23] = 1;                                                    // done: k_tree leaves the map alone
+        hdr[10] = (int)(wall_clock64() - t0);
+        hdr[15] = hdr[10];
+    }
 }
 
 // k_finish: zero everything outside the kept cluster, CLOSE 5x5, write the map back, centroid
@@ -2230,6 +2583,7 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
         SVC_HIP(hipFuncSetAttribute((const void *)k_prim_lvl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_tree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_tree_par, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_sort, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_BYTES));
     }
     for (int r = 0; r <= maxd; ++r) {
@@ -2278,8 +2632,17 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
             if (params->clust_filt) {
                 k_sort<<<m, TB, SORT_LDS_BYTES, s>>>(A);
                 SVC_CHECK_LAUNCH();
-                k_tree<<<m, 64, FIN_LDS_BYTES, s>>>(A);
-                SVC_CHECK_LAUNCH();
+                int cap_cl = 0;
+                const size_t lds_tp = tp_lds_bytes(hw, params->hdbscan_min, &cap_cl);
+                if (h->tree_par) {
+                    k_tree_par<<<m, TB, lds_tp, s>>>(A, cap_cl);
+                    SVC_CHECK_LAUNCH();
+                }
+                // the serial builder: maps the parallel one does not hold in LDS (more points or clusters), or all (SVC_TREE_PAR=0)
+                if (!h->tree_par || hw > TP_CAP || hdb::max_clusters(std::min(hw, TP_CAP), params->hdbscan_min) > cap_cl) {
+                    k_tree<<<m, 64, FIN_LDS_BYTES, s>>>(A);
+                    SVC_CHECK_LAUNCH();
+                }
             }
             k_finish<<<m, TB, lds_fin, s>>>(A);
             SVC_CHECK_LAUNCH();

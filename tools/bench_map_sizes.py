@@ -29,9 +29,10 @@ for i in range(0, 32, 6):
     h = st['hdr']
     print('  map %2d: N=%5d clusters %3d  stamps (us, 100 MHz wall clock): k_sort %.1f | k_tree built %.1f hierarchy %.1f chosen %.1f | '
           'k_finish %.1f | k_prim %.1f' % (i, st['n'], h[4], h[8] / 100.0, h[13] / 100.0, h[9] / 100.0, h[10] / 100.0, h[11] / 100.0, h[12] / 100.0))
-    print('           k_tree shader clock %.0f MHz' % (h[14] / max(h[15], 1) * 100.0))
+    if h[23]:
+        print('           k_tree_par stamps (us): loaded %.1f nearest-greater %.1f clusters %.1f jumped %.1f tops %.1f | rows %.1f stabilities %.1f labels+kept %.1f' % tuple(
+            x / 100.0 for x in list(h[25:30]) + [h[13], h[9], h[10]]))
     if h[16]:
         print('           k_prim_lvl: %d rounds, %d rises; setup %.1f us, phases (us): rise %.1f extract %.1f probe %.1f commit %.1f mark %.1f' % (
             h[16], h[17], h[24] / 100.0, h[18] / 100.0, h[19] / 100.0, h[20] / 100.0, h[21] / 100.0, h[22] / 100.0))
-        print('           fine (us): extract loop %.1f barrier+ctl %.1f | cand loads %.1f chunks %.1f reduce+slot %.1f barrier %.1f | accept+commit writes %.1f atomics %.1f barrier %.1f' % tuple(
-            x / 100.0 for x in list(h[25:32]) + [h[5], h[6]]))
+

@@ -16,12 +16,15 @@ across ranks with no data-path collective ("weak" scaling: 32 frames per GPU per
 only exchange is the all_gather of the final boxes after the timed region.
 
 Every batch starts a shot: its maps 0, 1, 2 form a blend chain (each is clustered after its predecessor has been), the
-other 29 maps are independent.  In the timed loop the chain is spread over the batch's call and the next two calls ON THE
-SAME STREAM (SVC_MAP_HELD, include/svc.h: map 1 joins round 0 of the next call, map 2 round 0 of the one after), so a call
-has one tail round instead of three serial ones; the results are those of the three-round call (asserted at start-up;
-config.blend_chain says which schedule ran; BENCH_CARRY=0 selects the three-round form), every batch is
-completed inside the timed region (two short calls per stream drain the carried maps), and config.one_batch_in_flight
-is the plain three-round call.
+other 29 maps are independent.  The timed loop drives the product's streaming scheduler (retargetvid_amd/pipeline.py:
+StreamPipeline, one per HIP stream): a call processes the maps whose predecessor is final and leaves the rest of a chain
+to the stream's next calls (SVC_MAP_HELD, include/svc.h), so a call has one tail round instead of three serial ones;
+maps and centres are those of the reference's loop (tests/test_gpu_pipeline.py::test_stream_pipeline_equals_the_oracle_loop).
+Every batch is completed inside the timed region (finish() runs the carried maps out).  BENCH_CARRY=0 selects the plain
+call (the chains run out in rounds inside every call); config.one_batch_in_flight is that plain call with one batch in
+flight.  The synthetic frames are sized so that a thresholded map holds ~2 k points (SURVEY.md 8(d): 1-6 k);
+config.points_per_map reports what the run saw.  The K-step timed region is repeated --repeats times; ms_per_step / value
+are the median region, config.repeats lists all of them.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the kernel class that takes the most device time
 (HIP events recorded by the library around each launch of that class, on the stream it is launched on):
@@ -46,7 +49,7 @@ import time
 
 # one HIP stream per in-flight batch: give the runtime enough hardware queues that the streams do not
 # share one (ROCclr default is 4; with it the same run is ~20 % slower) — must be set before HIP starts
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')      # (16 streams run at once with 16; with 4 the default layout drops to 2.3 ms per step)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -59,8 +62,9 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--pipeline', type=int, default=4, help='batches in flight per GPU (engines / HIP streams)')
-    ap.add_argument('--cpu-sample', type=int, default=160, help='frames of the CPU baseline sample (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=32, help='frames of the CPU baseline sample (0 = skip)')
     ap.add_argument('--iso-steps', type=int, default=3, help='un-pipelined profiling steps per kernel class')
+    ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps each; the median is reported')
     return ap.parse_args(argv)
 
 
@@ -87,10 +91,12 @@ if __name__ == '__main__' and 'WORLD_SIZE' not in os.environ:
 import numpy as np      # noqa: E402
 import torch            # noqa: E402
 
-from retargetvid_amd import dist as svc_dist, ops, smartVidCrop as S, synth, weights   # noqa: E402
+from retargetvid_amd import dist as svc_dist, ops, pipeline, smartVidCrop as S, synth, weights   # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA
+# the benchmark's frames: two blobs per frame, sized so that a map thresholded at 120 holds ~2 k points
+BENCH_BLOBS = dict(n_blobs=2, sigma=(float(os.environ.get('BENCH_SIGMA_LO', 30)), float(os.environ.get('BENCH_SIGMA_HI', 44))))
 
 
 def layer_work(batch, nh=256, nw=416, h=140, w=250, front_fused=False):
@@ -186,18 +192,21 @@ def main():
     sd = weights.make_synthetic_state_dict(0)
     CP = S.sc_init_crop_params()
     CP['out_ratio'] = '1:3'
-    frames_host = synth.blob_frames(B, 360, 640, seed=100 + rank)
+    frames_host = synth.blob_frames(B, 360, 640, seed=100 + rank, **BENCH_BLOBS)
     frames = torch.from_numpy(frames_host).to(dev)
     flags = np.zeros(B, np.uint8)
     if os.environ.get('BENCH_NO_BLEND', '0') != '1':   # (diagnostic: a batch without a cut has one tail round instead of three)
         flags[:2] = 1                  # the batch starts a shot: maps 0,1 blend into 1,2 (smartVidCrop.py:2369-2373)
 
+    DEPTH = int(os.environ.get('BENCH_DEPTH', 2))              # calls a stream may have outstanding before the host collects the oldest
     spans = {'net': 0.0, 'tail': 0.0, 'n': 0}                  # device milliseconds of a batch's two phases (HIP events on its stream)
     host_t = {'wait': 0.0, 'boxes': 0.0, 'enqueue': 0.0}      # host seconds: waiting for a batch, boxes on the host, enqueueing a batch
 
     class Slot:
         """One in-flight step: its own engine (weights + workspace), HIP stream and pinned result buffer,
-        so the low-occupancy clustering tail of one batch overlaps the network of the next."""
+        so the low-occupancy clustering tail of one batch overlaps the network of the next.  enqueue / finish = the
+        plain call (every blend chain run out in rounds inside the call); `pipe` = the product's streaming scheduler
+        (retargetvid_amd/pipeline.py: one tail round per call, chains carried over to the stream's next calls)."""
         def __init__(self):
             self.eng = ops.Engine(sd)
             self.stream = torch.cuda.Stream(device=dev)
@@ -207,6 +216,7 @@ def main():
             self.start = torch.cuda.Event(enable_timing=True)
             self.done = torch.cuda.Event(enable_timing=True)
             self.pending = False
+            self.pipe = pipeline.StreamPipeline(self.eng, CP, 140, 250, batch=B, stream=self.stream, timing=True, depth=DEPTH)
 
         def enqueue(self):
             with torch.cuda.stream(self.stream):
@@ -235,145 +245,54 @@ def main():
 
     slots = [Slot() for _ in range(P)]
     torch.cuda.synchronize()
+    STREAMED = os.environ.get('BENCH_CARRY', '1') != '0' and P > 1      # BENCH_CARRY=0: the plain call (rounds inside the call)
 
-    # ---- the timed path: the blend chain is spread over three calls of a stream -------------------------------------------
-    # A batch that starts a shot costs its stream three serial tail rounds, two of them for ONE map each (maps 1 and 2 of
-    # the chain 0 -> 1 -> 2), and with four batches in flight the step time is (network phase + tail phase) / 4.  With
-    # SVC_MAP_HELD (include/svc.h) maps 1 and 2 are left out of their own batch's call: map 1 is clustered in round 0 of
-    # the NEXT call on the same stream, map 2 in round 0 of the call after that, next to those batches' 30 round-0 maps --
-    # ONE tail round per call, the same maps and centres (tests/test_gpu_parity.py::
-    # test_blend_chain_carried_over_between_calls; asserted below against the three-round call).  A batch is complete
-    # two calls later; two head-only calls per stream finish the last ones inside the timed region.
-    # Head of a stream's buffer: A0 = final map 1 / A1 = raw map 2 of the batch two calls back, B0 = final map 0 / B1 = raw
-    # map 1 / C = raw map 2 of the previous batch; then the batch's 32 maps.  BENCH_CARRY=0: three rounds per call.
-    CARRY = os.environ.get('BENCH_CARRY', '1') != '0' and B >= 4 and flags[:3].tolist() == [1, 1, 0] and not flags[3:].any()
-    HELD, BNEXT = ops.MAP_HELD, ops.BLEND_NEXT
-
-    class CarrySlot:
-        def __init__(self, sl):
-            self.sl = sl
-            self.buf = torch.empty((B + 5, 140, 250), dtype=torch.uint8, device=dev)
-            self.xy = [torch.empty((B + 5, 2), dtype=torch.float64).pin_memory() for _ in range(2)]
-            self.done = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
-            self.t_start = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
-            self.t_net = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
-            self.timed = [False, False]
-            self.trace = None
-            self.reset()
-
-        def reset(self):
-            self.calls, self.va, self.vb = 0, False, False   # calls on this stream; is the A pair / the B triple loaded?
-            self.open1 = self.open2 = None                   # host copies of the batches that wait for map 1 + 2 / for map 2
-            self.kinds = [None, None]
-
-        def _head_flags(self):
-            return [HELD | BNEXT if self.va else HELD, 0 if self.va else HELD, HELD | BNEXT if self.vb else HELD, 0 if self.vb else HELD, HELD]
-
-        def _shift(self, with_own):
-            self.buf[0:2].copy_(self.buf[3:5])               # B's map 1 is final now: it and the raw map 2 become A
-            self.va = self.vb
-            if with_own:
-                self.buf[2:5].copy_(self.buf[5:8])           # the batch's final map 0 and raw maps 1, 2 become B and C
-            self.vb = with_own
-
-        def enqueue(self):
-            k = self.calls & 1
-            fl = np.zeros(B + 5, np.uint8)
-            fl[:5] = self._head_flags()
-            fl[6], fl[7] = HELD, HELD
-            with torch.cuda.stream(self.sl.stream):
-                self.t_start[k].record(self.sl.stream)
-                small = self.sl.eng.resize_frames(frames, 140, 250)
-                self.sl.eng.saliency(small, out=self.buf[5:])
-                self.sl.eng.threshold_(self.buf[5:], CP['t_threshold'])
-                self.t_net[k].record(self.sl.stream)
-                xy = self.sl.eng.cluster_center_(self.buf, fl, CP)
-                self.xy[k].copy_(xy, non_blocking=True)
-                self.kinds[k] = ('batch', self.va, self.vb)
-                self._shift(True)
-                self.done[k].record(self.sl.stream)
-            self.timed[k] = True
-            self.calls += 1
-
-        def flush(self):
-            """A call over the head only: moves the carried maps one stage on."""
-            k = self.calls & 1
-            with torch.cuda.stream(self.sl.stream):
-                xy = self.sl.eng.cluster_center_(self.buf[:5], np.array(self._head_flags(), np.uint8), CP)
-                self.xy[k][:5].copy_(xy, non_blocking=True)
-                self.kinds[k] = ('flush', self.va, self.vb)
-                self._shift(False)
-                self.done[k].record(self.sl.stream)
-            self.timed[k] = False
-            self.calls += 1
-
-        def collect(self):
-            k = (self.calls - 1) & 1
-            t0 = time.perf_counter()
-            self.done[k].synchronize()
-            t1 = time.perf_counter()
-            host_t['wait'] += t1 - t0
-            if self.timed[k]:
-                spans['net'] += self.t_start[k].elapsed_time(self.t_net[k])
-                spans['tail'] += self.t_net[k].elapsed_time(self.done[k])
-                spans['n'] += 1
-            got = self.xy[k].numpy()
-            kind, va, vb = self.kinds[k]
-            out = None
-            if va and self.open2 is not None:
-                self.open2[2] = got[1]
-                if self.trace is not None:
-                    self.trace.append(self.open2.copy())
-                out = host_boxes(self.open2)
-                self.open2 = None
-            if vb and self.open1 is not None:
-                self.open1[1] = got[3]
-                self.open2, self.open1 = self.open1, None
-            if kind == 'batch':
-                cur = np.empty((B, 2), np.float64)
-                cur[0], cur[3:] = got[5], got[8:]
-                self.open1 = cur
-            host_t['boxes'] += time.perf_counter() - t1
-            return out
-
-    cslots = [CarrySlot(sl) for sl in slots] if CARRY else []
-
-    def run_carry(steps, only=None):
+    def run_streamed(steps):
+        """The timed path: every slot's StreamPipeline gets a batch per turn; a batch's boxes are computed when its last
+        centre has arrived (the maps of its blend chain finish in the stream's next calls); finish() completes every
+        batch inside the timed region."""
         boxes = None
-        cslots_ = only or cslots
-        for cs in cslots_:
-            cs.reset()
+        pend = {}                                             # (slot, batch number on its stream) -> [centres, count]
+        for sl in slots:
+            sl.pipe.reset()
+
+        def take(k, results):
+            nonlocal boxes
+            t1 = time.perf_counter()
+            for g, x, y in results:
+                ent = pend.setdefault((k, g // B), [np.empty((B, 2), np.float64), 0])
+                ent[0][g % B] = (x, y)
+                ent[1] += 1
+                if ent[1] == B:
+                    boxes = host_boxes(ent[0])
+                    del pend[(k, g // B)]
+            host_t['boxes'] += time.perf_counter() - t1
+
         for s in range(steps):
-            cs = cslots_[s % len(cslots_)]
-            if cs.calls:
-                b = cs.collect()
-                boxes = b if b is not None else boxes
+            k = s % P
+            sl = slots[k]
+            if len(sl.pipe.calls) >= sl.pipe.depth:
+                t0 = time.perf_counter()
+                res = sl.pipe.collect()
+                host_t['wait'] += time.perf_counter() - t0
+                take(k, res)
             t0 = time.perf_counter()
-            cs.enqueue()
+            sl.pipe.submit_frames(frames, flags)
             host_t['enqueue'] += time.perf_counter() - t0
-        for _ in range(3):                                    # the last call, then two head-only calls that finish the carried maps
-            for cs in cslots_:
-                if cs.calls:
-                    b = cs.collect()
-                    boxes = b if b is not None else boxes
-                    if cs.va or cs.vb:
-                        cs.flush()
-        for cs in cslots_:
-            assert cs.open1 is None and cs.open2 is None and not cs.va and not cs.vb
+        for k, sl in enumerate(slots):
+            t0 = time.perf_counter()
+            res = sl.pipe.finish()
+            host_t['wait'] += time.perf_counter() - t0
+            take(k, res)
+        assert not pend, 'every batch must be complete at the end of the timed region'
+        for sl in slots:
+            net, tail = sl.pipe.phase_ms()
+            spans['net'] += net; spans['tail'] += tail; spans['n'] += 1
         return boxes
 
-    if CARRY and P > 1 and rank == 0:
-        slots[0].enqueue(); slots[0].finish()
-        ref_xy = slots[0].xy_host.numpy().copy()
-        seen = cslots[0].trace = []
-        run_carry(3, only=cslots[:1])
-        cslots[0].trace = None
-        assert len(seen) == 3
-        for o in seen:
-            assert np.array_equal(o, ref_xy, equal_nan=True), 'carried-over blend chain: centres differ from the three-round call'
     def run(steps):
-        if CARRY and P > 1:
-            return run_carry(steps)
+        if STREAMED:
+            return run_streamed(steps)
         boxes = None
         for s in range(steps):
             sl = slots[s % P]
@@ -415,7 +334,13 @@ def main():
     for _ in range(0 if plain else 10):
         slots[0].enqueue()
         slots[0].finish()
-    latency_ms = (time.perf_counter() - t1) / 10 * 1e3
+    latency_ms = None if plain else (time.perf_counter() - t1) / 10 * 1e3
+    # points per map of this workload (what the clustering kernels see)
+    with torch.cuda.stream(slots[0].stream):
+        m_ = eng.saliency(eng.resize_frames(frames, 140, 250))
+        eng.threshold_(m_, CP['t_threshold'])
+        _, st_ = eng.cluster_center_(m_, flags, CP, want_stats=True)
+    npts = st_[:, 0].cpu().numpy()
     dominant = max(per_class, key=lambda k: per_class[k][0])
     # BENCH_LIVE_PROFILE=1 also records the dominant class's events INSIDE the timed region (roofline.*_in_flight).  Off by
     # default: 76 event records per step on every stream cost 2-3 % of the step with four batches in flight (1.49 -> 1.45 ms)
@@ -425,17 +350,22 @@ def main():
         sl.eng.profile_enable(dominant if live else None)
         sl.eng.profile_read()
 
-    # 2. the timed region: K steps, P batches in flight
-    barrier()
-    for k in host_t:
-        host_t[k] = 0.0
-    spans.update(net=0.0, tail=0.0, n=0)
-    t0 = time.perf_counter()
-    boxes = run(args.steps)
-    barrier()
-    host_ms = {k: round(v / max(args.steps, 1) * 1e3, 4) for k, v in host_t.items()}
-    span_ms = {'network': round(spans['net'] / max(spans['n'], 1), 4), 'tail': round(spans['tail'] / max(spans['n'], 1), 4)}
-    dt_local = dt = time.perf_counter() - t0
+    # 2. the timed region: K steps, P batches in flight; repeated, the median region is the one reported
+    regions = []
+    for rep in range(max(1, args.repeats)):
+        barrier()
+        for k in host_t:
+            host_t[k] = 0.0
+        spans.update(net=0.0, tail=0.0, n=0)
+        t0 = time.perf_counter()
+        boxes = run(args.steps)
+        barrier()
+        dt_r = time.perf_counter() - t0
+        regions.append((dt_r, {k: round(v / max(args.steps, 1) * 1e3, 4) for k, v in host_t.items()},
+                        {'network': round(spans['net'] / max(spans['n'], 1), 4), 'tail': round(spans['tail'] / max(spans['n'], 1), 4)}))
+    order_r = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    dt_local, host_ms, span_ms = regions[order_r[len(order_r) // 2]]
+    dt = dt_local
     fl_ms, fl_launches = 0.0, 0
     for sl in slots:
         ms, cnt = sl.eng.profile_read()
@@ -505,7 +435,7 @@ def main():
             nb = max(1, args.cpu_sample // B)
             secs, nfr = 0.0, 0
             for b in range(nb):                                    # whole steps of the same workload, new frames each
-                fh = frames_host if b == 0 else synth.blob_frames(B, 360, 640, seed=200 + b)
+                fh = frames_host if b == 0 else synth.blob_frames(B, 360, 640, seed=200 + b, **BENCH_BLOBS)
                 fps_b, s_b = cpu_baseline(sd, fh, CP, flags)
                 secs += s_b
                 nfr += B
@@ -513,6 +443,13 @@ def main():
                        sample='%d steps of the same workload (%d frames), oracle/ (PyTorch-CPU fp32 forward at batch 1, '
                               'NumPy tail), %.1f s' % (nb, nfr, secs))
         value = world * B * args.steps / dt
+        tail_classes = {k: round(per_class[k][0], 4) for k in ('compact', 'core', 'prim', 'finish')}
+        roof['tail'] = dict(prim_ms=tail_classes['prim'], finish_ms=tail_classes['finish'], core_ms=tail_classes['core'],
+                            compact_ms=tail_classes['compact'],
+                            points_per_map=dict(min=int(npts.min()), mean=round(float(npts.mean()), 1), max=int(npts.max())),
+                            us_per_frame=round(sum(tail_classes.values()) / B * 1e3, 2),
+                            note='class ms per un-pipelined step of %d maps (three tail rounds: the batch starts a shot); '
+                                 'finish = k_sort + k_tree_par + k_finish' % B)
         out = dict(metric='frames/sec end-to-end saliency+crop on 640x360', value=round(value, 2), unit='frames/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / max(args.steps, 1) * 1e3, 4),
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
@@ -523,12 +460,16 @@ def main():
                                parallelism='frames sharded, dp%d' % world,
                                world_size_seen_by_rccl=seen_world if dist_on else None,
                                per_rank_frames_per_s=[round(v, 1) for v in rank_fps],
-                               one_batch_in_flight=dict(latency_ms_per_batch=round(latency_ms, 4),
-                                                        frames_per_s=round(B / latency_ms * 1e3, 1)),
+                               points_per_map=dict(min=int(npts.min()), mean=round(float(npts.mean()), 1), max=int(npts.max())),
+                               repeats=dict(regions=len(regions), ms_per_step=[round(r[0] / max(args.steps, 1) * 1e3, 4) for r in regions],
+                                            reported='median'),
+                               one_batch_in_flight=(None if latency_ms is None else
+                                                    dict(latency_ms_per_batch=round(latency_ms, 4),
+                                                         frames_per_s=round(B / latency_ms * 1e3, 1))),
                                host_ms_per_step=host_ms, batch_phase_ms_in_the_pipeline=span_ms,
-                               blend_chain=('three tail rounds per call' if not (CARRY and P > 1) else
-                                            'maps 1 and 2 of a batch are clustered in round 0 of the next two calls on its stream '
-                                            '(SVC_MAP_HELD): one tail round per call')),
+                               blend_chain=('the chains run out in rounds inside every call' if not STREAMED else
+                                            'retargetvid_amd.pipeline.StreamPipeline: the maps behind a cut are clustered in round 0 of '
+                                            'the next calls on their stream (SVC_MAP_HELD): one tail round per call')),
                    roofline=roof, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if dist_on:

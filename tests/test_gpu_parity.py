@@ -264,6 +264,52 @@ def test_tail_bit_exact_default_settings(engine, golden_dir):
     assert np.array_equal(np.stack(H.prim_mst(X, core), 1), st['mst'])
 
 
+def _prim_and_labels(engine, maps, CP):
+    """Per map: the device's Prim edge list and labels against the oracle's (the rare paths of k_prim_lvl / k_tree_par)."""
+    dm = torch.from_numpy(maps.copy()).cuda()
+    engine.cluster_center_(dm, None, CP)
+    mcs, ms = CP['hdbscan_min'], CP['hdbscan_min_samples']
+    for i in range(maps.shape[0]):
+        st = engine.cluster_state(i, maps.shape[1] * maps.shape[2])
+        X = np.stack([st['pts'] & 255, (st['pts'] >> 8) & 255], 1).astype(np.int64)
+        assert np.array_equal(X, np.argwhere(maps[i] > 0))
+        if len(X) <= mcs + 1:
+            continue
+        core = H.core_distances(X, H.effective_min_samples(len(X), mcs, ms))
+        assert np.array_equal(core, st['core']), i
+        u, v, w = H.prim_mst(X, core)
+        assert np.array_equal(np.stack([u, v, w], 1), st['mst']), 'Prim sequence of map %d (N = %d)' % (i, len(X))
+        ref = H.hdbscan_labels(X, mcs, ms)
+        got = st['labels']
+        assert np.array_equal(ref < 0, got < 0), i
+        pairs = {(a, b) for a, b in zip(ref[ref >= 0], got[got >= 0])}
+        assert len(pairs) == len({a for a, _ in pairs}) == len({b for _, b in pairs}), 'labels of map %d' % i
+
+
+def test_prim_rounds_and_parallel_hierarchy_on_adversarial_maps(engine):
+    """k_prim_lvl (rounds of up to 64 nodes, drops, rises, jumps beyond the ring table, the batch table running full)
+    and k_tree_par (nearest greater ranks, pointer jumping) against the oracle's one-node-per-step Prim and its
+    union-find hierarchy: sparse noise (every step a jump), dense noise, lines, lattices, blobs with outliers."""
+    rng = np.random.RandomState(11)
+    maps = []
+    for dens in (0.002, 0.01, 0.03, 0.08, 0.2):
+        maps.append(((rng.rand(140, 250) < dens) * 200).astype(np.uint8))
+    m = np.zeros((140, 250), np.uint8); m[70, :] = 200; m[:, 125] = 180; maps.append(m)             # a cross of lines
+    m = np.zeros((140, 250), np.uint8); m[::3, ::3] = 200; maps.append(m)                            # a lattice (d2 = 9 everywhere)
+    m = np.zeros((140, 250), np.uint8); m[::7, ::5] = 200; m[40:60, 100:140] = 220; maps.append(m)   # sparse lattice + block
+    ys, xs = np.mgrid[0:140, 0:250]
+    m = np.zeros((140, 250), np.uint8)
+    for (cy, cx, r) in ((30, 40, 12), (100, 200, 18), (70, 120, 9)):
+        m[(ys - cy) ** 2 + (xs - cx) ** 2 < r * r] = 210
+    m[rng.rand(140, 250) < 0.003] = 150; maps.append(m)                                              # three blobs + outliers
+    maps = np.stack(maps)
+    _prim_and_labels(engine, maps, P.init_crop_params())
+    _prim_and_labels(engine, maps, dict(P.init_crop_params(), hdbscan_min=5, hdbscan_min_samples=3))
+    small = np.stack([((rng.rand(35, 62) < d) * 200).astype(np.uint8) for d in (0.05, 0.2, 0.5, 0.9)])
+    _prim_and_labels(engine, small, dict(P.init_crop_params(), hdbscan_min=5, hdbscan_min_samples=3))
+    _prim_and_labels(engine, small, dict(P.init_crop_params(), hdbscan_min=2, hdbscan_min_samples=1))
+
+
 def test_tail_bit_exact_other_parameters(engine):
     rng = np.random.RandomState(5)
     maps = []

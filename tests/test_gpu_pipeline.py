@@ -207,3 +207,54 @@ def test_evaluator_iou_within_1e4_of_the_oracle_on_ten_videos(engine, synthetic_
 def ops_iou(gt, mt):
     from retargetvid_amd import ops
     return np.asarray(ops.iou_boxes(gt, mt), np.float64)
+
+
+def test_stream_pipeline_equals_the_oracle_loop(engine):
+    """retargetvid_amd.pipeline.StreamPipeline: 9 batches of 32 maps with cuts at random positions (blend chains that
+    start anywhere, also across batch boundaries and ring wraps), one tail round per call -- filtered maps and centres
+    must be those of the reference's sequential loop (oracle: filter map i, blend it into map i+1 next to a cut)."""
+    from oracle import tail_ref as T
+    from retargetvid_amd import pipeline as PL
+    rng = np.random.RandomState(21)
+    n, B = 9 * 32 - 5, 32
+    ys, xs = np.mgrid[0:140, 0:250]
+    maps = np.zeros((n, 140, 250), np.uint8)
+    for i in range(n):
+        for _ in range(rng.randint(1, 3)):
+            cy, cx, r = rng.randint(10, 130), rng.randint(10, 240), rng.randint(4, 9)
+            maps[i][(ys - cy) ** 2 + (xs - cx) ** 2 < r * r] = rng.randint(130, 256)
+        maps[i][rng.rand(140, 250) < 0.0005] = 200
+    maps[7] = 0                                                              # an empty map inside a chain
+    cuts = sorted(set([0, 31, 32, 64, 200]) | set(int(c) for c in rng.choice(n - 3, 9, replace=False)))
+    seg = np.array([[cuts[i], (cuts[i + 1] - 1) if i + 1 < len(cuts) else n - 1] for i in range(len(cuts))], np.int32)
+    flags = S.blend_flags(n, seg)
+    CP = S.sc_init_crop_params()
+    # the reference's loop
+    ref = np.ascontiguousarray(np.transpose(maps, (1, 2, 0)))
+    for i in range(n):
+        ref[:, :, i] = T.clustering_filt(ref[:, :, i], CP)
+        if i + 1 < n and flags[i]:
+            ref[:, :, i + 1] = T.blend_next(ref[:, :, i], ref[:, :, i + 1])
+    dx, dy = T.centers(ref, CP)
+    # the stream
+    out = torch.zeros((n, 140, 250), dtype=torch.uint8, device='cuda')
+    pipe = PL.StreamPipeline(engine, CP, 140, 250, batch=B, ring_batches=4, max_span_batches=3, maps_out=out)
+    dm = torch.from_numpy(maps).cuda()
+    got = {}
+    for s0 in range(0, n, B):
+        if len(pipe.calls) >= pipe.depth:
+            got.update({g: (x, y) for g, x, y in pipe.collect()})
+        pipe.submit_maps(dm[s0:s0 + B], flags[s0:s0 + B])
+    got.update({g: (x, y) for g, x, y in pipe.finish()})
+    assert sorted(got) == list(range(n))
+    assert np.array_equal(out.cpu().numpy(), np.transpose(ref, (2, 0, 1)))
+    for i in range(n):
+        if dx[i] is None:
+            assert np.isnan(got[i][0]) and np.isnan(got[i][1])
+        else:
+            assert got[i] == (dx[i], dy[i]), i
+    # and the whole sequence in one call (rounds inside the call) gives the same
+    one = torch.from_numpy(maps).cuda()
+    xy1 = engine.cluster_center_(one, flags, CP).cpu().numpy()
+    assert torch.equal(one, out)
+    assert all((np.isnan(xy1[i, 0]) and np.isnan(got[i][0])) or tuple(xy1[i]) == got[i] for i in range(n))

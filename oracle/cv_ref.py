@@ -25,9 +25,28 @@ Parity status: UNPINNED against cv2 itself (no reference test holds resized or c
 cv2 is not available offline).  Cross-checked against second implementations in
 tests/test_oracle_cv_crosscheck.py: CLOSE bit for bit against scipy.ndimage grey morphology,
 INTER_NEAREST bit for bit against torch 'nearest', INTER_LINEAR within one grey level of torch's
-float bilinear (same sample positions and clamping; the 11-bit weights are what differs) and
-exactly (a+b+c+d+2)>>2 at scale 2.  Default settings use only the down-scale (ingest, §8(f)-2)
-and CLOSE.
+float bilinear (same sample positions and clamping; the 11-bit weights are what differs),
+exactly (a+b+c+d+2)>>2 at scale 2, and BIT FOR BIT against tests/native/cv_resize_port.c -- a separately written C
+program in the shape of OpenCV's own code -- on the ingest sizes (640x360, 1080p, 4K -> 250x140), odd sizes and the
+best-settings pair 140x250 -> 35x62 -> 140x250 including the columns at and beyond xmax.  Default settings use only
+the down-scale (ingest, §8(f)-2) and CLOSE.
+
+Which OpenCV code each expression restates (modules/imgproc/src/resize.cpp of OpenCV 4.x; no line numbers: the
+sources are not available offline):
+  _linear_coeffs      the INTER_LINEAR branch of cv::resize that fills xofs / ialpha and yofs / ibeta:
+                      fx = (float)((dx + 0.5) * scale_x - 0.5); sx = cvFloor(fx); fx -= sx;
+                      if (sx < ksize2 - 1) { xmin = dx + 1; if (sx < 0) fx = 0, sx = 0; }
+                      if (sx + ksize2 >= ssize.width) { xmax = min(xmax, dx); if (sx >= ssize.width - 1) fx = 0, sx = ssize.width - 1; }
+                      ialpha = saturate_cast<short>(cbuf[k] * INTER_RESIZE_COEF_SCALE)   (cvRound: round half to even)
+  rows = ... (xmax)   HResizeLinear<uchar, int, short, INTER_RESIZE_COEF_SCALE>::operator(): D[dx] = S[sx] * a0 + S[sx + cn] * a1
+                      for dx < xmax, D[dx] = S[sx] * ONE from xmax on
+  s0 / s1 row fetch   resizeGeneric_Invoker: sy = clip(sy0 - ksize2 + 1 + k, 0, ssize.height - 1)
+  out = ...           VResizeLinear<uchar, int, short, FixedPtCast<int, uchar, INTER_RESIZE_COEF_BITS * 2>, VResizeLinearVec_32s8u>:
+                      dst[x] = uchar(( ((b0 * (S0[x] >> 4)) >> 16) + ((b1 * (S1[x] >> 4)) >> 16) + 2) >> 2)
+  resize_*_factor     cv::resize with dsize empty: dsize = Size(saturate_cast<int>(ssize.width * inv_scale_x), ...) (cvRound),
+                      scale_x = 1 / inv_scale_x = the factor itself
+  resize_nearest      resizeNN: sx = min(cvFloor(x * ifx), ssize.width - 1)
+  morph_close_5x5     cv::morphologyEx(MORPH_CLOSE) = dilate, erode with morphologyDefaultBorderValue() (borders never win)
 """
 import numpy as np
 

@@ -122,3 +122,70 @@ def test_crop_job_world2_equals_world1(tmp_path):
     rows = open(os.path.join(run2, '601_1-3.txt')).read().splitlines()
     assert len(rows) == JOB_COUNTS[3] and all(len(r.split(',')) == 4 for r in rows)
     assert 't_total' in open(os.path.join(run2, '601_1-3_info.txt')).read()   # info of a video rank 1 may have owned
+
+
+# ---- resume unit (smartVidCrop.py:2732-2742) and a failure on one rank, world 2 -------------------------------------
+def _counting_crop_fn(videos, CP, ratios, workers):
+    """Stand-in that records which videos it was asked for (by frame count) and returns fixed windows."""
+    out = []
+    for v in videos:
+        v = v() if callable(v) else v
+        n = int(v['frame_count'])
+        if CP.get('fail_on') == n:
+            raise ValueError('synthetic failure on the video with %d frames' % n)
+        bbs = [[j % 7, 0, 120 + j % 7, 360] for j in range(n)]
+        out.append({r: ({'bbs': bbs, 'fc_sel': n // 6}, {'result': 'smart cropped', 'frames': n}) for r in ratios})
+    return out
+
+
+def _resume_worker(rank, world, port, out_dir, CP, replace, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        allb, st = D.crop_job(lambda i: dict(frame_count=JOB_COUNTS[i]), JOB_COUNTS, JOB_NAMES, CP, ('1:3', '3:1'),
+                              out_dir=out_dir, workers=1, crop_fn=_counting_crop_fn, run_name='r', replace_existing=replace)
+        q.put((rank, 'ok', st['videos_rank'], st['videos_skipped'], sorted(allb['1:3']), int(allb['3:1'][3][5][0])))
+    except Exception as e:
+        q.put((rank, 'error', type(e).__name__, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_world2(out_dir, CP, replace):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000 + (0 if replace else 7)
+    procs = [ctx.Process(target=_resume_worker, args=(r, 2, port, out_dir, CP, replace, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_crop_job_skips_videos_whose_result_files_exist(tmp_path):
+    out = str(tmp_path)
+    first = _run_world2(out, {}, True)
+    assert [r[1] for r in first] == ['ok', 'ok'] and sum(r[2] for r in first) == 5 and first[0][3] == 0
+    run = os.path.join(out, 'r')
+    os.remove(os.path.join(run, '601_3-1.txt'))                       # video 601 lost one of its files: it must be redone
+    marker = os.path.join(run, '002_1-3.txt')
+    open(marker, 'a').close()
+    before = os.path.getmtime(marker)
+    second = _run_world2(out, {}, False)
+    assert [r[1] for r in second] == ['ok', 'ok']
+    assert sum(r[2] for r in second) == 1 and second[0][3] == 4       # one video computed, four skipped
+    assert second[0][4] == second[1][4] == [0, 1, 2, 3, 4]            # every rank still holds all windows
+    assert second[0][5] == second[1][5] == 5
+    assert os.path.getmtime(marker) == before                         # files of skipped videos are not rewritten
+    assert len(open(os.path.join(run, '601_3-1.txt')).read().splitlines()) == JOB_COUNTS[3]
+
+
+def test_crop_job_failure_on_one_rank_raises_on_every_rank(tmp_path):
+    res = _run_world2(str(tmp_path), {'fail_on': JOB_COUNTS[1]}, True)
+    assert [r[1] for r in res] == ['error', 'error']
+    kinds = sorted(r[2] for r in res)
+    assert kinds == ['RuntimeError', 'ValueError'], res               # the failing rank's own error, "another rank failed" on the other
+    assert not os.path.isdir(os.path.join(str(tmp_path), 'r'))        # nothing was written

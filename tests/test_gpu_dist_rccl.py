@@ -1,0 +1,32 @@
+"""-m gpu: the multi-rank code path of bench.py on RCCL with the one GPU a test box has: a child
+`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` with BENCH_FORCE_DIST=1 takes
+init_process_group('nccl'), the barriers, the MAX all-reduce of the timings and the box gather (dist.gather_boxes)
+on the device.  This module touches no GPU itself (no `engine` fixture): the child must be the first to initialise it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_under_torchrun_takes_the_rccl_path_at_world_1():
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+           '--cpu-sample', '0', '--repeats', '1', '--iso-steps', '1']
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 1 and d['config']['world_size_seen_by_rccl'] == 1
+    assert d['value'] > 0 and d['steps'] == 2

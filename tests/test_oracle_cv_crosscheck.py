@@ -82,3 +82,49 @@ def test_inter_nearest_equals_torch_nearest():
         ref = F.interpolate(t, scale_factor=0.25, mode='nearest', recompute_scale_factor=False)[0, 0].numpy().astype(np.uint8)
         assert got.shape == (35, 62)
         assert np.array_equal(got[:ref.shape[0], :ref.shape[1]], ref[:35, :62])
+
+
+def _c_port():
+    """tests/native/cv_resize_port.c (a separate restatement in the shape of OpenCV's resize.cpp), compiled here."""
+    import ctypes
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, 'oracle', '_build', 'libcv_resize_port.so')
+    src = os.path.join(root, 'tests', 'native', 'cv_resize_port.c')
+    if not os.path.isfile(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.check_call(['gcc', '-O2', '-shared', '-fPIC', '-o', so, src, '-lm'])
+    lib = ctypes.CDLL(so)
+    lib.cv_resize_linear_u8.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
+
+    def resize(img, oh, ow, sx=0.0, sy=0.0):
+        img = np.ascontiguousarray(img, np.uint8)
+        cn = 1 if img.ndim == 2 else img.shape[2]
+        out = np.empty((oh, ow) if img.ndim == 2 else (oh, ow, cn), np.uint8)
+        assert lib.cv_resize_linear_u8(img.ctypes.data, img.shape[0], img.shape[1], cn, out.ctypes.data, oh, ow, sx, sy) == 0
+        return out
+    return resize
+
+
+def test_inter_linear_bit_equal_to_the_c_port_of_opencvs_resize():
+    """oracle/cv_ref.resize_linear_u8 against tests/native/cv_resize_port.c on the sizes the path uses: the ingest
+    down-scale from 640x360, 1080p and 4K, odd sizes (edge columns at and beyond xmax), and the best-settings pair
+    140x250 -> 35x62 -> 140x250 with the explicit factor-4 scale of cv2.resize(fx=, fy=)."""
+    c_resize = _c_port()
+    rng = np.random.RandomState(3)
+    for (h, w, oh, ow, cn) in [(360, 640, 140, 250, 3), (1080, 1920, 140, 250, 3), (2160, 3840, 140, 250, 3),
+                               (480, 640, 187, 250, 3), (37, 53, 20, 31, 3), (20, 31, 37, 53, 1), (5, 7, 11, 13, 3),
+                               (140, 250, 141, 251, 1), (90, 160, 140, 250, 3)]:
+        img = rng.randint(0, 256, (h, w, cn) if cn > 1 else (h, w)).astype(np.uint8)
+        assert np.array_equal(cv_ref.resize_linear_u8(img, oh, ow), c_resize(img, oh, ow)), (h, w, oh, ow)
+    for seed in range(6):
+        m = _maps(seed)
+        small = cv_ref.resize_linear_factor_u8(m, 1.0 / 4)                      # smartVidCrop.py:1080 (fx = fy = 1 / factor)
+        assert small.shape == (35, 62)
+        assert np.array_equal(small, c_resize(m, 35, 62, 4.0, 4.0))
+        back = cv_ref.resize_linear_u8(small, 140, 250)                          # :1158 ((initW, initH))
+        assert np.array_equal(back, c_resize(small, 140, 250))
+        # the upscale's last columns lie beyond xmax (plain copies of the last source column)
+        assert np.array_equal(back[:, -2:], c_resize(small, 140, 250)[:, -2:])

@@ -97,6 +97,69 @@ def ingest(video, CP, sd, stage=None):
                 h_process=sal_h, w_process=sal_w)
 
 
+def select_frames_video(n_frames, frame_count, trans_probs, trans_threshold, skip, read_batch):
+    """Frame selection of read_and_segment_video (smartVidCrop.py:379-399): like select_frames, but the after-cut test
+    is the TRANSITION PROBABILITY of the previous frame (global index), not membership in a scene list."""
+    true_inds, map2orig, batches = [], [], []
+    total, after_cut = -1, False
+    for b0 in range(0, n_frames, read_batch):
+        first = len(true_inds)
+        for i in range(min(read_batch, n_frames - b0)):
+            g = b0 + i
+            forced = (g == true_inds[-1] + skip) if true_inds else True
+            if forced or after_cut or g == frame_count - 1:
+                total += 1
+                true_inds.append(g)
+            after_cut = bool(trans_probs[g] > trans_threshold)      # (:394-396)
+            map2orig.append(total)
+        batches.append((first, len(true_inds) - first))
+    return true_inds, map2orig, batches
+
+
+def scenes_from_probs(trans_probs, trans_threshold):
+    """predictions_to_scenes (smartVidCrop.py:214-230, transnet_utils.py:5-19) followed by the "shot segmentation FIX"
+    of the video path (:452-456): every scene ends where the next one starts, the last one on the last frame."""
+    pred = (np.asarray(trans_probs) > trans_threshold).astype(np.uint8)
+    scenes, t, tp, start, i = [], -1, 0, 0, 0
+    for i, t in enumerate(pred):
+        if tp == 1 and t == 0:
+            start = i
+        if tp == 0 and t == 1 and i != 0:
+            scenes.append([start, i])
+        tp = t
+    if t == 0:
+        scenes.append([start, i])
+    if not scenes:
+        scenes = [[0, len(pred) - 1]]
+    seg = np.array(scenes, dtype=np.int32)
+    for k in range(len(seg) - 1):
+        seg[k][1] = seg[k + 1][0] - 1
+    seg[-1][1] = len(pred) - 1
+    return seg
+
+
+def ingest_video(video, CP, sd, trans_probs, trans_threshold=0.1, stage=None):
+    """read_and_segment_video (smartVidCrop.py:234-556) for decoded frames and given transition probabilities (the
+    shot network's output, one per frame): selection, saliency with the off-by-one, segmentation."""
+    fr, frame_count, w, h = video['fr'], video['frame_count'], video['w'], video['h']
+    frames_full = video['frames']
+    sal_h, sal_w = sal_size(w, h, CP['max_input_d'])
+    true_inds, map2orig, batches = select_frames_video(len(frames_full), frame_count, trans_probs, trans_threshold,
+                                                       CP['skip'], CP['read_batch'])
+    n_sel = len(true_inds)
+    smaps = np.zeros((sal_h, sal_w, n_sel), np.uint8)
+    for first, cnt in batches:
+        if cnt > 1:
+            idx = true_inds[first:first + cnt - 1]
+            small = np.stack([cv_ref.resize_linear_u8(frames_full[g], sal_h, sal_w) for g in idx])
+            smaps[:, :, first:first + cnt - 1] = unisal_ref.saliency_u8(sd, small)
+    seg = scenes_from_probs(trans_probs, trans_threshold)
+    seg_sel = np.array([[map2orig[v] for v in row] for row in seg], dtype=np.int32)
+    return dict(smaps=smaps, segmentation=seg, segmentation_sel=seg_sel, true_inds=true_inds,
+                inds_to_orig=map2orig, fr=fr, fc=len(frames_full), fc_sel=n_sel, h_orig=h, w_orig=w,
+                h_process=sal_h, w_process=sal_w)
+
+
 def crop_from_maps(VD, CP, stage=None):
     """smart_vid_crop after ingest (:2293-2522).  Adds 'bbs' etc. to VD."""
     VD['w_final'], VD['h_final'], VD['conversion_mode'] = tail_ref.calc_dest_size(
@@ -127,6 +190,10 @@ def crop_from_maps(VD, CP, stage=None):
     return VD
 
 
-def smart_vid_crop(video, CP, sd, stage=None):
-    VD = ingest(video, CP, sd, stage)
+def smart_vid_crop(video, CP, sd, stage=None, trans_probs=None, trans_threshold=0.1):
+    """trans_probs given: the reference's video path (shot network inside ingest); else the pickle door (trans_inds)."""
+    if trans_probs is not None:
+        VD = ingest_video(video, CP, sd, trans_probs, trans_threshold, stage)
+    else:
+        VD = ingest(video, CP, sd, stage)
     return crop_from_maps(VD, CP, stage)

@@ -427,6 +427,45 @@ def make_transnet_state_dict(seed=0):
     return sd
 
 
+def transnet_from_tf_variables(variables):
+    """A TensorFlow checkpoint's variables -> the state dict make_transnet_state_dict / pack_transnet_blob use.
+
+    `variables`: {name: array} as exported from the reference's graph (3rd_party_libs/transnetv1/transnetv1_handler.py:25-91),
+    e.g. ``{v.name: sess.run(v) for v in tf.trainable_variables()}`` or ``tf.train.load_checkpoint(path)`` read variable
+    by variable.  Accepted spellings: with or without the ``:0`` tensor suffix; optimiser slots (``.../Adam``, ``.../Adam_1``,
+    ``beta1_power``, ``beta2_power``, ``global_step``) and anything outside the ``TransNet/`` scope are ignored.
+    Layouts are TensorFlow's own: Conv3D kernels [kt, kh, kw, cin, filters], Dense kernels [in, out].  Raises KeyError
+    for a missing variable and ValueError for a wrong shape, naming it."""
+    clean = {}
+    for name, arr in variables.items():
+        n = str(name)
+        if n.endswith(':0'):
+            n = n[:-2]
+        if not n.startswith('TransNet/') or n.rsplit('/', 1)[-1] not in ('kernel', 'bias'):
+            continue                                   # optimiser slots, counters, other scopes
+        clean[n] = np.asarray(arr, np.float32)
+    want = {}
+    for b, c, cin, f in transnet_cells():
+        for d in TRANSNET_DILATIONS:
+            p = 'TransNet/SDDCNN_%d/DDCNN_%d/Conv3D_%d' % (b + 1, c + 1, d)
+            want[p + '/kernel'] = (3, 3, 3, cin, f)
+            want[p + '/bias'] = (f,)
+    nflat = 3 * 6 * 4 * (TRANSNET_F << (TRANSNET_L - 1))
+    want['TransNet/dense/kernel'] = (nflat, TRANSNET_D)
+    want['TransNet/dense/bias'] = (TRANSNET_D,)
+    want['TransNet/dense_1/kernel'] = (TRANSNET_D, 2)
+    want['TransNet/dense_1/bias'] = (2,)
+    sd = {}
+    for name, shape in want.items():
+        if name not in clean:
+            raise KeyError('TransNet checkpoint: variable %r is missing (have %d TransNet variables)' % (name, len(clean)))
+        if tuple(clean[name].shape) != shape:
+            raise ValueError('TransNet checkpoint: %r has shape %r, the F16 L3 S2 D256 graph needs %r'
+                             % (name, tuple(clean[name].shape), shape))
+        sd[name] = np.ascontiguousarray(clean[name])
+    return sd
+
+
 def pack_transnet_blob(sd):
     """The device layout (csrc/svc_shot.hip): per cell, per dilation a GEMM weight [rows = out channel, padded to a multiple
     of 32][27 taps x cpad] (cpad = max(4, cin): the three input channels get a zero fourth), then the cell's 4f biases;

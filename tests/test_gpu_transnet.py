@@ -118,9 +118,46 @@ def test_video_batches_with_overlap_and_detect_shots(net):
     small = np.stack([cv_ref.resize_linear_u8(f, 27, 48) for f in fr])
     ref = Hd.video_transition_probs(None, small, 25.0, 100, predict=lambda a: R.predict_video(sd, a))
     assert got['trans_probs'].shape == (230,) and np.abs(got['trans_probs'] - ref).max() <= TOL
-    seg = R.predictions_to_scenes(ref, 0.1)
+    from oracle import pipeline_ref as P
+    seg = P.scenes_from_probs(ref, 0.1)                                # predictions_to_scenes + the end-of-segment fix (:452-456)
     assert np.array_equal(got['segmentation'], seg)
+    assert all(seg[i][1] == seg[i + 1][0] - 1 for i in range(len(seg) - 1)) and seg[-1][1] == 229
     assert got['trans_inds'] == [int(s[0]) for s in seg] + [230]
     # the overlap matters: predicting the batches on their own (no overlap rows) gives other values at the batch heads
     alone = np.concatenate([R.predict_video(sd, small[i:i + 100]) for i in range(0, 230, 100)])
     assert np.abs(alone - ref).max() > 1e-3
+
+
+def test_smart_vid_crop_runs_shot_detection_inside_the_ingest(net):
+    """The reference's video path end to end (smartVidCrop.py:234-556 -> :2218): a video dict WITHOUT trans_inds and
+    shot_net= -- TransNet per read batch with the overlap, after-cut selection from its transition probabilities
+    (:394-396), scenes with the end-of-segment fix, then saliency -> crop windows -- against the oracle pipeline fed
+    with the oracle's transition probabilities.  (Synthetic TransNet weights: the cuts it reports are arbitrary; what is
+    checked is that both sides derive the same selection, segmentation and windows from them.)"""
+    from oracle import pipeline_ref as P
+    from retargetvid_amd import smartVidCrop as S, synth
+    n, sd = net
+    torch.set_num_threads(8)
+    usd = weights.make_synthetic_state_dict(0)
+    eng = ops.Engine(usd)
+    try:
+        frames = synth.blob_frames(150, 90, 160, seed=9)
+        frames[60:] = frames[60:][:, ::-1]                              # a hard cut
+        video = dict(fr=25.0, frame_count=150, w=160, h=90, frames=frames)
+        CP = S.sc_init_crop_params()
+        CP.update(read_batch=64, out_ratio='1:3', hdbscan_min=5)        # three read batches (two overlaps)
+        VD, res = S.smart_vid_crop(video, CP, save_vid=False, engine=eng, shot_net=n)
+        small = np.stack([cv_ref.resize_linear_u8(f, 27, 48) for f in frames])
+        probs = Hd.video_transition_probs(None, small, 25.0, 64, predict=lambda a: R.predict_video(sd, a))
+        assert np.abs(VD['trans_probs'] - probs).max() <= TOL
+        assert np.abs(probs - 0.1).min() > 10 * TOL                      # no probability sits on the threshold
+        ref = P.smart_vid_crop(video, dict(P.init_crop_params(), read_batch=64, out_ratio='1:3', hdbscan_min=5), usd,
+                               trans_probs=probs)
+        assert VD['true_inds'] == ref['true_inds'] and VD['inds_to_orig'] == ref['inds_to_orig']
+        assert np.array_equal(VD['segmentation'], ref['segmentation'])
+        assert np.array_equal(VD['segmentation_sel'], ref['segmentation_sel'])
+        assert np.abs(np.array(VD['bbs']) - np.array(ref['bbs'])).max() <= 1
+        with pytest.raises(ValueError):
+            S.smart_vid_crop(video, CP, save_vid=False, engine=eng)      # no trans_inds and no shot network
+    finally:
+        eng.close()

@@ -235,3 +235,53 @@ def test_round_plan_of_the_cluster_filter_with_held_maps():
     assert lib.svc_debug_round_plan(np.ones(300, np.uint8).ctypes.data_as(ctypes.c_void_p), 300,
                                     np.zeros(300, np.int32).ctypes.data_as(ctypes.c_void_p),
                                     np.zeros(300, np.int32).ctypes.data_as(ctypes.c_void_p)) < 0      # chain too long
+
+
+def test_video_path_selection_and_scenes_match_the_oracle():
+    """retargetvid_amd.smartVidCrop._select_frames_video / the scene fix of detect_shots against the oracle's restatement
+    of read_and_segment_video (smartVidCrop.py:379-399, :452-457) on random transition probabilities."""
+    from oracle import pipeline_ref as P
+    from retargetvid_amd import smartVidCrop as S, transnetv1_handler as T
+    rng = np.random.RandomState(2)
+    for trial in range(30):
+        n = int(rng.randint(3, 400))
+        probs = rng.rand(n).astype(np.float32) * (rng.rand(n) < 0.08)
+        if trial == 0:
+            probs[:] = 0.9                                             # every frame a transition
+        if trial == 1:
+            probs[:] = 0.0
+        rb = int(rng.choice([50, 64, 2000]))
+        got = S._select_frames_video(n, n, probs, 0.1, 6, rb)
+        ref = P.select_frames_video(n, n, probs, 0.1, 6, rb)
+        assert got[0] == ref[0] and got[1] == ref[1] and got[2] == ref[2]
+        seg = np.array(T.predictions_to_scenes(probs, threshold=0.1), dtype=np.int32)
+        for i in range(len(seg) - 1):
+            seg[i][1] = seg[i + 1][0] - 1
+        seg[-1][1] = n - 1
+        assert np.array_equal(seg, P.scenes_from_probs(probs, 0.1))
+
+
+def test_transnet_weights_from_tensorflow_variable_names():
+    """weights.transnet_from_tf_variables: a dict as exported from the reference's TF1 graph (3rd_party_libs/transnetv1/
+    transnetv1_handler.py:25-91: names with ':0', optimiser slots, counters) -> the packer's state dict; wrong
+    shapes and missing variables are named."""
+    import pytest
+    from retargetvid_amd import weights as W
+    sd = W.make_transnet_state_dict(3)
+    tfv = {k + ':0': v.copy() for k, v in sd.items()}
+    tfv['TransNet/dense/kernel/Adam:0'] = np.zeros_like(sd['TransNet/dense/kernel'])
+    tfv['TransNet/dense/kernel/Adam_1:0'] = np.zeros_like(sd['TransNet/dense/kernel'])
+    tfv['beta1_power:0'] = np.float32(0.9)
+    tfv['global_step:0'] = np.int64(1234)
+    out = W.transnet_from_tf_variables(tfv)
+    assert sorted(out) == sorted(sd) and all(np.array_equal(out[k], sd[k]) for k in sd)
+    assert np.array_equal(W.pack_transnet_blob(out), W.pack_transnet_blob(sd))
+    assert out['TransNet/SDDCNN_2/DDCNN_1/Conv3D_4/kernel'].shape == (3, 3, 3, 64, 32)      # TF layout: [kt, kh, kw, cin, filters]
+    bad = dict(tfv)
+    del bad['TransNet/SDDCNN_3/DDCNN_2/Conv3D_8/bias:0']
+    with pytest.raises(KeyError, match='Conv3D_8/bias'):
+        W.transnet_from_tf_variables(bad)
+    bad = dict(tfv)
+    bad['TransNet/dense_1/kernel:0'] = np.zeros((2, 256), np.float32)                         # transposed by mistake
+    with pytest.raises(ValueError, match='dense_1/kernel'):
+        W.transnet_from_tf_variables(bad)

@@ -135,6 +135,9 @@ int svc_iou_i32(const int32_t *a, const int32_t *b, size_t n, double *out, void 
 #define SVC_K_COUNT 12
 int svc_profile_enable(SvcHandle *h, int kernel_class);
 int svc_profile_read(SvcHandle *h, double *total_ms, int *launches);
+/* The same log without the correction: raw_total_ms = sum of the event-pair durations, pair_ms = cost of an empty event pair
+ * (median of 15, measured on a stream the handle owns); svc_profile_read returns raw - 0.75 * pair * launches. */
+int svc_profile_read_raw(SvcHandle *h, double *raw_total_ms, double *pair_ms, int *launches);
 
 /* Test/diagnostic door: copy internal per-frame clustering state of the LAST
  * svc_cluster_center call to HOST buffers (any may be NULL).  Synchronises.

@@ -14,7 +14,7 @@ ABI_VERSION = 3          # include/svc.h SVC_ABI_VERSION this binding was writte
 EXPORTS = ('svc_last_error', 'svc_abi_version', 'svc_create', 'svc_destroy', 'svc_resize_frames_u8', 'svc_saliency_u8',
            'svc_threshold_u8', 'svc_cluster_center', 'svc_iou_i32', 'svc_debug_cluster_state', 'svc_debug_tap', 'svc_front_fused', 'svc_debug_round_plan', 'svc_transnet_load', 'svc_transnet_predict',
            'svc_debug_argsort_u32',
-           'svc_profile_enable', 'svc_profile_read')
+           'svc_profile_enable', 'svc_profile_read', 'svc_profile_read_raw')
 
 
 class SvcParams(ctypes.Structure):
@@ -72,6 +72,7 @@ def load():
     lib.svc_debug_argsort_u32.argtypes = [vp, vp, i32, vp]
     lib.svc_profile_enable.argtypes = [vp, i32]
     lib.svc_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    lib.svc_profile_read_raw.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     for name in EXPORTS:
         if name not in ('svc_last_error', 'svc_abi_version'):
             getattr(lib, name).restype = i32

@@ -150,7 +150,7 @@ struct SvcHandle {
     int shot_form = 2;                 // TransNet convolution cells: 0 = operands straight from global memory (k_shot_conv), 1 = weights through LDS, 2 = both operands through LDS with whole-line loads (SVC_SHOT_FORM)
     // per-kernel-class event log (svc_profile_*)
     int prof_class = -1;
-    hipStream_t prof_stream = nullptr;          // stream of the last recorded launch (the empty-pair calibration of svc_profile_read runs on it)
+    hipStream_t prof_cal_stream = nullptr;      // a stream of the handle's own for the empty-event-pair calibration of svc_profile_read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
 };
 
@@ -160,7 +160,7 @@ struct ProfScope {
     ProfScope(SvcHandle *h_, int cls, hipStream_t s_) : h(h_), s(s_), on(h_->prof_class == cls) {
         if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
     }
-    ~ProfScope() { if (on) { (void)hipEventRecord(b, s); h->prof_events.emplace_back(a, b); h->prof_stream = s; } }
+    ~ProfScope() { if (on) { (void)hipEventRecord(b, s); h->prof_events.emplace_back(a, b); } }
 };
 
 int svc_net_release(SvcHandle *h);

@@ -2910,23 +2910,20 @@ extern "C" int svc_profile_enable(SvcHandle *h, int kernel_class) {
     return SVC_OK;
 }
 
-extern "C" int svc_profile_read(SvcHandle *h, double *total_ms, int *launches) {
-    if (!h || !total_ms || !launches) { svc_set_error("svc_profile_read: invalid argument"); return SVC_E_INVALID; }
+// raw_total_ms: the event-pair durations as measured; pair_ms: what an EMPTY event pair costs on a stream of this
+// device (median of 15 on a stream the handle owns -- the caller's stream may be gone by now); launches.
+extern "C" int svc_profile_read_raw(SvcHandle *h, double *raw_total_ms, double *pair_ms, int *launches) {
+    if (!h || !raw_total_ms || !pair_ms || !launches) { svc_set_error("svc_profile_read_raw: invalid argument"); return SVC_E_INVALID; }
     SVC_HIP(hipSetDevice(h->device));
     SVC_HIP(hipDeviceSynchronize());
-    // An event pair around a launch also times the event packets themselves: measure an empty pair on the same stream
-    // (median of 15, ~4.5 us on MI355X) and take 3/4 of it off every launch -- the share that is not hidden behind the
-    // kernel, calibrated against rocprofv3's kernel durations of the same run (39 launches: raw events 1.696 ms, minus a
-    // whole pair each 1.519, rocprofv3 1.564, minus 3/4 of a pair 1.563).
-    double overhead = 0.0;
-    const char *raw_env = getenv("SVC_PROF_RAW");            // diagnostic: 1 = no correction, 2 = half a pair
-    const int raw_mode = raw_env ? atoi(raw_env) : 0;
-    if (!h->prof_events.empty() && raw_mode != 1) {
+    *pair_ms = 0.0;
+    if (!h->prof_events.empty()) {
+        if (!h->prof_cal_stream) SVC_HIP(hipStreamCreateWithFlags(&h->prof_cal_stream, hipStreamNonBlocking));
         std::vector<float> emp;
         for (int i = 0; i < 15; ++i) {
             hipEvent_t a, b;
             SVC_HIP(hipEventCreate(&a)); SVC_HIP(hipEventCreate(&b));
-            SVC_HIP(hipEventRecord(a, h->prof_stream)); SVC_HIP(hipEventRecord(b, h->prof_stream));
+            SVC_HIP(hipEventRecord(a, h->prof_cal_stream)); SVC_HIP(hipEventRecord(b, h->prof_cal_stream));
             SVC_HIP(hipEventSynchronize(b));
             float ms = 0.f;
             SVC_HIP(hipEventElapsedTime(&ms, a, b));
@@ -2934,19 +2931,32 @@ extern "C" int svc_profile_read(SvcHandle *h, double *total_ms, int *launches) {
             (void)hipEventDestroy(a); (void)hipEventDestroy(b);
         }
         std::sort(emp.begin(), emp.end());
-        overhead = emp[emp.size() / 2] * (raw_mode == 2 ? 0.5 : 0.75);
+        *pair_ms = emp[emp.size() / 2];
     }
     double tot = 0.0;
     for (auto &e : h->prof_events) {
         float ms = 0.f;
         SVC_HIP(hipEventElapsedTime(&ms, e.first, e.second));
-        tot += std::max(0.0, (double)ms - overhead);
+        tot += (double)ms;
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
-    *total_ms = tot;
+    *raw_total_ms = tot;
     *launches = (int)h->prof_events.size();
     h->prof_events.clear();
+    return SVC_OK;
+}
+
+// The corrected sum: an event pair around a launch also times the event packets themselves; 3/4 of an empty pair's
+// cost (the share that is not hidden behind the kernel: calibrated against rocprofv3's kernel durations of the same
+// run -- 39 launches: raw events 1.696 ms, minus a whole pair each 1.519, rocprofv3 1.564, minus 3/4 of a pair 1.563)
+// is taken off every launch.  svc_profile_read_raw returns the two ingredients separately.
+extern "C" int svc_profile_read(SvcHandle *h, double *total_ms, int *launches) {
+    if (!h || !total_ms || !launches) { svc_set_error("svc_profile_read: invalid argument"); return SVC_E_INVALID; }
+    double raw = 0.0, pair = 0.0;
+    const int rc = svc_profile_read_raw(h, &raw, &pair, launches);
+    if (rc) return rc;
+    *total_ms = std::max(0.0, raw - 0.75 * pair * *launches);
     return SVC_OK;
 }
 
@@ -2955,6 +2965,7 @@ extern "C" int svc_destroy(SvcHandle *h) {
     (void)hipSetDevice(h->device);
     for (auto &e : h->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     h->prof_events.clear();
+    if (h->prof_cal_stream) { (void)hipStreamDestroy(h->prof_cal_stream); h->prof_cal_stream = nullptr; }
     svc_net_release(h);
     h->tail_ws.release();
     h->tail_offsets.release();

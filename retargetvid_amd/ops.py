@@ -126,6 +126,12 @@ class Engine:
         _lib.check(self.lib.svc_profile_read(self._h, ctypes.byref(ms), ctypes.byref(cnt)))
         return ms.value, cnt.value
 
+    def profile_read_raw(self):
+        """-> (raw_total_ms, empty_pair_ms, launches): the ingredients of profile_read's corrected sum."""
+        raw, pair, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        _lib.check(self.lib.svc_profile_read_raw(self._h, ctypes.byref(raw), ctypes.byref(pair), ctypes.byref(cnt)))
+        return raw.value, pair.value, cnt.value
+
     def front_fused(self):
         """True when the last saliency call ran LANCZOS + features.0 + features.1 as the one kernel k_front."""
         return bool(self.lib.svc_front_fused(self._h))

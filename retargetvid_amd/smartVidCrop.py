@@ -292,12 +292,32 @@ class _HostFeed:
         return self._tp
 
 
-def ingest_frames(video, crop_params, engine=None, verbose=False, shot_net=None):
+def _small_frames(engine, frames, idx, sal_h, sal_w, dev):
+    """Frames idx at saliency size on the device, whatever the container (CUDA tensor, on-device generator, host array)."""
+    import torch
+    if torch.is_tensor(frames) and frames.is_cuda:
+        return engine.resize_frames(frames[torch.as_tensor(idx, device=frames.device)].to(dev).contiguous(), sal_h, sal_w)
+    if not torch.is_tensor(frames) and hasattr(frames, 'select'):             # an on-device generator (synth.LazyBlobVideo)
+        return engine.resize_frames(frames.select(idx).to(dev).contiguous(), sal_h, sal_w)
+    host = frames if torch.is_tensor(frames) else np.asarray(frames)
+    if (host.dtype not in (np.uint8, torch.uint8)) or host.ndim != 4 or host.shape[3] != 3:
+        raise TypeError('frames must be uint8 [n,h,w,3] RGB')
+    feed = getattr(engine, '_host_feed', None)
+    if feed is None:
+        feed = engine._host_feed = _HostFeed(engine)
+    return feed.downscale(host, idx, sal_h, sal_w)
+
+
+def ingest_frames(video, crop_params, engine=None, verbose=False, shot_net=None, stream_batch=0):
     """Counterpart of ingest_pickle (smartVidCrop.py:560-836) for an in-memory video dict -- and, when the dict carries no
     ``trans_inds`` and a shot network is given (``shot_net``: transnetv1_handler.ShotTransNet), of the video path
     read_and_segment_video (:234-556): TransNet runs per read batch with the reference's overlap (:248-260, :353-374),
     the after-cut selection follows its transition probabilities (:394-396) and the scenes come from
     predictions_to_scenes with the end-of-segment fix (:452-456).
+    stream_batch > 0: threshold, cluster filter, cut blend and centres run INSIDE the ingest, stream_batch maps at a time
+    behind each piece of the network (pipeline.StreamPipeline: one tail round per call, chains carried over); the dict
+    then also carries ``xy_stream`` (centres) and the filtered maps, and smart_vid_crop skips its own tail.  Results
+    are those of the whole-video call.
     The down-scale to saliency size and the UNISAL forward run on the device.  Keeps the
     reference's off-by-one: the last selected frame of each read batch gets an all-zero map.
     Host frames (ndarray) go through the pinned, double-buffered feed above; CUDA tensors and
@@ -324,28 +344,6 @@ def ingest_frames(video, crop_params, engine=None, verbose=False, shot_net=None)
         true_inds, map2orig, batches = _select_frames(n_frames, frame_count, trans_inds, crop_params['skip'],
                                                       crop_params['read_batch'])
     sc_register_time(t, '_read_shot_det')
-    t = time.perf_counter()
-    n_sel = len(true_inds)
-    dev = engine.device
-    smaps = torch.zeros((n_sel, sal_h, sal_w), dtype=torch.uint8, device=dev)
-    for first, cnt in batches:
-        if cnt > 1:
-            idx = true_inds[first:first + cnt - 1]
-            if torch.is_tensor(frames) and frames.is_cuda:
-                small = engine.resize_frames(frames[torch.as_tensor(idx, device=frames.device)].to(dev).contiguous(), sal_h, sal_w)
-            elif not torch.is_tensor(frames) and hasattr(frames, 'select'):       # an on-device generator (synth.LazyBlobVideo)
-                small = engine.resize_frames(frames.select(idx).to(dev).contiguous(), sal_h, sal_w)
-            else:
-                host = frames if torch.is_tensor(frames) else np.asarray(frames)
-                if (host.dtype not in (np.uint8, torch.uint8)) or host.ndim != 4 or host.shape[3] != 3:
-                    raise TypeError('frames must be uint8 [n,h,w,3] RGB')
-                feed = getattr(engine, '_host_feed', None)
-                if feed is None:
-                    feed = engine._host_feed = _HostFeed(engine)
-                small = feed.downscale(host, idx, sal_h, sal_w)
-            smaps[first:first + cnt - 1] = engine.saliency(small)
-    torch.cuda.current_stream(dev).synchronize()      # the caller's stream only: other videos may be in flight on theirs
-    sc_register_time(t, '_read_sal_det')
     if trans_probs is not None:
         seg = np.array(shots['segmentation'], dtype=np.int32)
     else:
@@ -359,10 +357,62 @@ def ingest_frames(video, crop_params, engine=None, verbose=False, shot_net=None)
             raise ValueError('trans_inds %r yields no scenes; pass at least [0, frame_count]' % (trans_inds,))
         seg = np.array(scenes, dtype=np.int32)
     seg_sel = np.array([[map2orig[v] for v in row] for row in seg], dtype=np.int32)
+    t = time.perf_counter()
+    n_sel = len(true_inds)
+    dev = engine.device
+    smaps = torch.zeros((n_sel, sal_h, sal_w), dtype=torch.uint8, device=dev)
+    pipe, xy_stream, flags_all = None, None, None
+    if stream_batch and crop_params['clust_filt']:
+        from . import pipeline as _pl
+        flags_all = blend_flags(n_sel, seg_sel)
+        cache = engine.__dict__.setdefault('_pipes', {})        # ring + pinned buffers are re-used from video to video
+        key = (sal_h, sal_w, int(stream_batch), torch.cuda.current_stream(dev).cuda_stream)
+        pipe = cache.get(key)
+        if pipe is None:
+            pipe = cache[key] = _pl.StreamPipeline(engine, crop_params, sal_h, sal_w, batch=int(stream_batch))
+        pipe.reset()
+        pipe.CP, pipe.maps_out = crop_params, smaps
+        xy_stream = np.full((n_sel, 2), np.nan)
+        fed = 0
+
+        def feed_tail(upto):
+            """threshold + one clustering round for the maps [fed, upto) that are complete (in stream order)."""
+            nonlocal fed
+            while fed < upto:
+                k = min(int(stream_batch), upto - fed)
+                if len(pipe.calls) >= pipe.depth:
+                    for g, x, y in pipe.collect():
+                        xy_stream[g] = (x, y)
+                chunk = smaps[fed:fed + k]
+                engine.threshold_(chunk, crop_params['t_threshold'])
+                pipe.submit_maps(chunk, flags_all[fed:fed + k])
+                fed += k
+    for first, cnt in batches:
+        if cnt > 1 and pipe is not None:
+            # piece by piece: the tail of a piece follows its network on the stream
+            for s0 in range(first, first + cnt - 1, int(stream_batch)):
+                idx = true_inds[s0:min(s0 + int(stream_batch), first + cnt - 1)]
+                smaps[s0:s0 + len(idx)] = engine.saliency(_small_frames(engine, frames, idx, sal_h, sal_w, dev))
+                feed_tail(s0 + len(idx))
+            feed_tail(first + cnt)                    # the batch's last selected frame keeps its all-zero map (the off-by-one)
+            continue
+        if pipe is not None:
+            feed_tail(first + cnt)
+            continue
+        if cnt > 1:
+            idx = true_inds[first:first + cnt - 1]
+            smaps[first:first + cnt - 1] = engine.saliency(_small_frames(engine, frames, idx, sal_h, sal_w, dev))
+    if pipe is not None:
+        for g, x, y in pipe.finish():
+            xy_stream[g] = (x, y)
+    torch.cuda.current_stream(dev).synchronize()      # the caller's stream only: other videos may be in flight on theirs
+    sc_register_time(t, '_read_sal_det')
     if trans_probs is not None:
         vid_data_extra = dict(trans_probs=trans_probs)
     else:
         vid_data_extra = {}
+    if xy_stream is not None:
+        vid_data_extra['xy_stream'] = xy_stream
     vid_data = dict(vid_data_extra, smaps_dev=smaps, segmentation=seg, segmentation_sel=seg_sel, true_inds=true_inds,
                     inds_to_orig=map2orig, fr=fr, fc=n_frames, fc_sel=n_sel, h_orig=h, w_orig=w,
                     h_process=sal_h, w_process=sal_w)
@@ -436,7 +486,7 @@ class _LazySmaps(dict):
 
 def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn='', frames_dir='',
                    temp_path=None, verbose=False, save_vid=True, callback_progress=None,
-                   callback_session=None, callback_status=None, copy_sound=False, engine=None, shot_net=None):
+                   callback_session=None, callback_status=None, copy_sound=False, engine=None, shot_net=None, stream_batch=0):
     """Saliency -> crop windows for one video.  Returns (VD, smart_crop_results) like the
     reference; VD['bbs'] holds one [x1,y1,x2,y2] per decoded frame.  A video dict without ``trans_inds`` takes the
     reference's video path: ``shot_net`` (transnetv1_handler.ShotTransNet) detects the shots inside the ingest."""
@@ -468,7 +518,7 @@ def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn=''
                                   'package: pass the ingest_pickle dict (fr, frame_count, w, h, frames, '
                                   'trans_inds), a .pkl holding it, or install a reader with set_video_reader() '
                                   '(retargetvid_amd/ingest.py)')
-    VD = _LazySmaps(ingest_frames(video, CP, engine, verbose=verbose, shot_net=shot_net))
+    VD = _LazySmaps(ingest_frames(video, CP, engine, verbose=verbose, shot_net=shot_net, stream_batch=stream_batch))
     if callback_status is not None and callback_session is not None:
         callback_status(callback_session, 'sc', 'SC PROCESSING', 'smart-cropping main process')
     VD['segm_backup'] = VD['segmentation'].copy()
@@ -484,12 +534,16 @@ def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn=''
 
     maps = VD['smaps_dev']
     t = time.perf_counter()
-    engine.threshold_(maps, CP['t_threshold'])
+    if 'xy_stream' not in VD:
+        engine.threshold_(maps, CP['t_threshold'])
     sc_register_time(t, '_thresh')                     # (enqueue time; the stream is synchronised by the D2H below)
 
     t = time.perf_counter()
-    flags = blend_flags(VD['fc_sel'], VD['segmentation_sel']) if CP['clust_filt'] else None
-    xy = engine.cluster_center_(maps, flags, CP).cpu().numpy()       # one D2H of n x 2 doubles
+    if 'xy_stream' in VD:                              # the streaming ingest has run the tail already (stream_batch)
+        xy = VD['xy_stream']
+    else:
+        flags = blend_flags(VD['fc_sel'], VD['segmentation_sel']) if CP['clust_filt'] else None
+        xy = engine.cluster_center_(maps, flags, CP).cpu().numpy()       # one D2H of n x 2 doubles
     results['cuts_clust'] = 0
     sc_register_time(t, '_clustering')
 
@@ -552,7 +606,7 @@ def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn=''
 smartVidCrop = smart_vid_crop      # BASELINE.json's spelling of the entry point
 
 
-def smart_vid_crop_ratios(video_path, CP, ratios, engine=None, verbose=False):
+def smart_vid_crop_ratios(video_path, CP, ratios, engine=None, verbose=False, stream_batch=0):
     """Several target aspect ratios for one video with the saliency / clustering work done once
     (the reference's driver re-runs the whole pipeline per ratio, smartVidCrop.py:2722-2775, or
     re-uses its pickled feature cache :2244-2256).  -> {ratio: (VD, smart_crop_results)}; results
@@ -564,7 +618,7 @@ def smart_vid_crop_ratios(video_path, CP, ratios, engine=None, verbose=False):
     for ratio in ratios:
         cp = dict(CP, out_ratio=ratio)
         if base is None:
-            VD, res = smart_vid_crop(video_path, cp, save_vid=False, engine=engine, verbose=verbose)
+            VD, res = smart_vid_crop(video_path, cp, save_vid=False, engine=engine, verbose=verbose, stream_batch=stream_batch)
             base = (VD, res)
         else:
             VD = _LazySmaps({k: (copy.copy(v) if isinstance(v, list) else v) for k, v in base[0].items()})
@@ -582,12 +636,13 @@ def smart_vid_crop_ratios(video_path, CP, ratios, engine=None, verbose=False):
     return out
 
 
-def crop_videos(videos, CP, ratios=None, workers=3, state_dict=None, seed=0):
+def crop_videos(videos, CP, ratios=None, workers=3, state_dict=None, seed=0, stream_batch=0):
     """Many videos on one GPU with ``workers`` of them in flight: every worker thread owns an engine
     (weights + workspace) and a HIP stream and runs smart_vid_crop_ratios on its share, so the
     low-occupancy clustering tail and the host-side temporal stages of one video overlap the network of
     the next ones (what bench.py does with its batches).  ``videos``: a sequence of ingest_pickle dicts or
-    of zero-argument callables producing them (built on the worker's stream).  Returns a list, in input
+    of zero-argument callables producing them (built on the worker's stream).  stream_batch > 0: every video's tail runs
+    inside its ingest, stream_batch maps at a time (pipeline.StreamPipeline).  Returns a list, in input
     order, of {ratio: (VD, smart_crop_results)}; each entry equals a sequential smart_vid_crop_ratios call."""
     import torch
     ratios = tuple(ratios) if ratios else (CP['out_ratio'],)
@@ -605,7 +660,7 @@ def crop_videos(videos, CP, ratios=None, workers=3, state_dict=None, seed=0):
             with torch.cuda.stream(stream):
                 for i in range(k, len(videos), workers):
                     v = videos[i]() if callable(videos[i]) else videos[i]
-                    out[i] = smart_vid_crop_ratios(v, CP, ratios, engine=engines[k])
+                    out[i] = smart_vid_crop_ratios(v, CP, ratios, engine=engines[k], stream_batch=stream_batch)
                 stream.synchronize()
         except BaseException as e:                       # surfaced in the caller's thread
             errors.append(e)

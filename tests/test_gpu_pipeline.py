@@ -258,3 +258,18 @@ def test_stream_pipeline_equals_the_oracle_loop(engine):
     xy1 = engine.cluster_center_(one, flags, CP).cpu().numpy()
     assert torch.equal(one, out)
     assert all((np.isnan(xy1[i, 0]) and np.isnan(got[i][0])) or tuple(xy1[i]) == got[i] for i in range(n))
+
+
+def test_streaming_tail_inside_the_ingest_gives_the_same_windows(engine):
+    """smart_vid_crop(stream_batch=) -- threshold, cluster filter, cut blend and centres inside the ingest, 32 / 7 maps at
+    a time through pipeline.StreamPipeline -- against the whole-video call: same filtered maps, centres and windows,
+    for both parameter sets (the best-settings set clusters on shrunk maps)."""
+    video = _video(200, 12, [0, 37, 41, 120, 200])
+    for best in (False, True):
+        CP = S.sc_init_crop_params(use_best_settings=best)
+        CP['out_ratio'] = '1:3'
+        VD0, _ = S.smart_vid_crop(video, CP, save_vid=False, engine=engine)
+        for sb in (32, 7):
+            VD1, _ = S.smart_vid_crop(video, CP, save_vid=False, engine=engine, stream_batch=sb)
+            assert torch.equal(VD0['smaps_dev'], VD1['smaps_dev'])
+            assert VD0['dx'] == VD1['dx'] and VD0['dy'] == VD1['dy'] and VD0['bbs'] == VD1['bbs']

@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--max-frames', type=int, default=0, help='truncate every video (0 = real length)')
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'config3'))
     ap.add_argument('--workers', type=int, default=4, help='videos in flight per GPU (S.crop_videos)')
+    ap.add_argument('--stream-batch', type=int, default=int(os.environ.get('STREAM_BATCH', 64)), help='maps per tail call inside the ingest (pipeline.StreamPipeline); 0 = one call per video')
     ap.add_argument('--annotations', default=os.path.join(ROOT, 'tests', 'golden', 'retargetvid'))
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
@@ -54,15 +55,16 @@ def main():
         return build
 
     torch.cuda.synchronize()
+    crop_fn = lambda vs, cp, rs, w: S.crop_videos(vs, cp, rs, workers=w, stream_batch=args.stream_batch)
     allb, st = D.crop_job(make, counts, ['%03d' % v for v in vids], CP, ratios, out_dir=args.out, workers=args.workers,
-                          run_name='synthetic_default')
+                          run_name='synthetic_default', crop_fn=crop_fn)
     if rank == 0:
         score = None
         if args.videos == 200 and not args.max_frames:
             rows, _ = E.evaluate(args.out, args.annotations, out_path=os.path.join(args.out, 'eval_current.txt'))
             score = {ar: [round(x, 3) for x in s] for ar, s in rows[0][1].items()}
         dt = st['seconds_rank']
-        print(json.dumps(dict(config='RetargetVid-shaped synthetic set', videos=len(vids), world=world,
+        print(json.dumps(dict(config='RetargetVid-shaped synthetic set', stream_batch=args.stream_batch, videos=len(vids), world=world,
                               video_frames=sum(counts), saliency_frames_rank0=st['saliency_frames_rank'],
                               seconds_rank0=round(dt, 2), video_frames_per_s_rank0=round(st['video_frames_rank'] / dt, 1),
                               saliency_frames_per_s_rank0=round(st['saliency_frames_rank'] / dt, 1), eval=score)))

@@ -97,6 +97,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA
 # the benchmark's frames: two blobs per frame, sized so that a map thresholded at 120 holds ~2 k points
 BENCH_BLOBS = dict(n_blobs=2, sigma=(float(os.environ.get('BENCH_SIGMA_LO', 30)), float(os.environ.get('BENCH_SIGMA_HI', 44))))
+if os.environ.get('BENCH_R02_WORKLOAD', '0') == '1':      # the frames of rounds 1-2 (1-3 blobs, sigma 20-60: ~650 points per map), for like-for-like comparisons
+    BENCH_BLOBS = {}
 
 
 def layer_work(batch, nh=256, nw=416, h=140, w=250, front_fused=False):

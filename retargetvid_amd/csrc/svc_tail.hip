@@ -678,7 +678,8 @@ __global__ __launch_bounds__(TB) void k_prim_big(TailArgs A, int n_min) {
 // are taken in index order (first minimum wins).  State: the level m; F = bitmap (by point index) of the points
 // outside the tree whose reach is m; R = each point's exact reach against the first `done` tree nodes, in registers,
 // caught up only when the level has to rise.
-//   round   the first 64 members of F, f1 < f2 < ..., are candidates.  Candidate i probes the grid disc d2 <= m around
+//   round   the first 64 members of F, f1 < f2 < ..., are candidates (lane i of the four working wavefronts = candidate
+//           i; each of them walks a quarter of the disc's cells).  Candidate i probes the grid disc d2 <= m around
 //           itself through the occupancy bitmap (cell -> point index = prefix count + popcount): a point outside
 //           the tree with mr = max(d2, core_j, core_i) < m is a DROP (once f_i is in the tree the level falls), one
 //           with mr == m that is not in F is an ENTRANT.  Adding f1..fi leaves f(i+1) the library's next pick iff
@@ -686,8 +687,11 @@ __global__ __launch_bounds__(TB) void k_prim_big(TailArgs A, int n_min) {
 //           first i that breaks this (a prefix minimum over the candidates' lowest entrants).
 //   commit  accepted nodes get their edges (weight m), join the tree (top bit of their core distance), leave F;
 //           their entrants join F.  After a drop F is rebuilt from the last node's disc at the new, lower level.
-//   rise    F empty: every thread relaxes its points against the nodes added since the last rise (all pairs, but in
-//           bulk: one broadcast LDS read per node, 4 VALU per point), m = block minimum, F = {R == m}.
+//   rise    F empty: the nodes added since the last rise become batches of <= 64 with a bounding box; a (batch, chunk of
+//           64 points) block is relaxed -- all pairs, the nodes through scalar registers -- only when its lower bound
+//           max(box distance^2, smallest core distances) is <= the minimum of R before the rise (other blocks stay
+//           pending; a jump between blobs first tightens the bound with every chunk's nearest batch); m = block
+//           minimum of R, F = {R == m}.
 //   m > RING_R^2 (jumps between far-apart blobs): one node per round, then a rise -- the legacy algorithm's step.
 // Golden maps (N = 660 .. 2 980): 28 .. 81 rounds and 6 .. 15 rises per map instead of N - 1 steps.
 // --------------------------------------------------------------------------------------
@@ -698,7 +702,6 @@ __global__ __launch_bounds__(TB) void k_prim_big(TailArgs A, int n_min) {
 #define LVL_RINF 0x7FFFFFFFu
 #define LVL_RING2 (RING_R * RING_R)
 #define LVL_PAD RING_R                 // the occupancy grid carries a border of empty cells: discs need no bounds tests
-#define LVL_FAST_NK 128                // discs of up to 128 cells (levels <= 36) keep their findings in registers
 #define LVL_NB 256                     // batches of tree nodes a map can have pending (then everything is settled at once)
 #define LVL_NEAR 64u                   // a rise whose bound exceeds this is a jump between blobs: the bound is tightened first
 
@@ -710,7 +713,7 @@ static size_t lvl_lds_bytes(int h, int w, int n_ring) {
     const size_t cells = (size_t)(h + 2 * LVL_PAD) * (w + 2 * LVL_PAD);
     auto up = [](size_t b) { return (b + 15) / 16 * 16; };
     return up((cells + 31) / 32 * sizeof(OccW)) + up(cap * 8) + up(cap * 4) + up((cap + 63) / 64 * 8) +
-           up((size_t)n_ring * 8) + up(cap * 2) + up(64 * 4) + up(64 * 8) + up(2 * NW16 * 4) + up(16) +
+           up((size_t)n_ring * 8) + up(cap * 2) + up(64 * 4 * 4) + up(64 * 4 * 8) + up(2 * NW16 * 4) + up(16) +
            up(LVL_NB * 16) + up((cap + 63) / 64 * (LVL_NB / 32) * 4) + up((cap + 63) / 64 * 16) + up((LVL_RING2 + 1) * 2) + 64;
 }
 
@@ -737,10 +740,10 @@ struct LvlLds {
     uint32_t *F;            // bitmap over point indices (32-bit words; read in pairs by the extraction)
     uint2 *ring;            // (d2, linear offset in the padded grid) per ring offset, ascending d2
     uint16_t *rc;           // row | col << 8 per point
-    uint32_t *cand;         // [64] candidates of the round
-    uint2 *slot;            // [64] (drop: smallest mr below the level or NONE, lowest entrant or NONE) per candidate
+    uint32_t *cand;         // [workers][64] candidates of the round (every worker extracts its own copy)
+    uint2 *slot;            // [workers][64] (drop: smallest mr below the level or NONE, lowest entrant or NONE) per candidate, per worker's share of the disc
     uint32_t *red;          // [2][NW16] block reductions (alternating halves)
-    int *ctl;               // [0] candidates of the round
+    int *ctl;               // outcome of a round for the wavefronts that do not work in it: accepted, dropped, level, last node
     uint4 *btab;            // [LVL_NB] batches of tree nodes: (start | len << 16, box, smallest core distance, -)
     uint32_t *proc;         // [chunks][LVL_NB / 32] batch already relaxed against the chunk
     uint4 *cbox;            // [chunks] (box, smallest core distance, -, -) of every chunk of 64 points
@@ -748,39 +751,51 @@ struct LvlLds {
     int gw;                 // padded grid width
 };
 
-// What one lane found in one chunk (64 ring cells) of the discs of up to four candidates.
-struct LvlFound { uint32_t j[4], mr[4]; uint32_t ent; };              // mr = NONE: no point there; ent: bit u = entrant of candidate u
+#define LVL_WORKERS 4                   // wavefronts (one per SIMD) that run the rounds; lane = candidate
 
-// The discs d2 <= level around up to NC candidates, one chunk of 64 ring cells: the same ring offsets serve all of
-// them, their dependent LDS reads (occupancy word, then core distance and F word of the point found) go side by side.
-template <int NC>
-__device__ __forceinline__ void lvl_chunk(const LvlLds &S, const uint32_t (&cell0)[NC], const uint32_t (&ci)[NC], int nc,
-                                          int k, int nk, uint32_t level, LvlFound &fo) {
-    const bool valid = k < nk;
-    const uint2 o = S.ring[valid ? k : 0];
-    uint32_t bitpos[NC];
-    OccW ow[NC];
-#pragma unroll
-    for (int u = 0; u < NC; ++u) {
-        const uint32_t cell = cell0[u] + o.y;
-        bitpos[u] = cell & 31u;
-        ow[u] = S.occ[cell >> 5];
-    }
-    uint32_t cj[NC], fw[NC];
-    bool in[NC];
-#pragma unroll
-    for (int u = 0; u < NC; ++u) {
-        in[u] = valid && u < nc && ((ow[u].bits >> bitpos[u]) & 1u);
-        fo.j[u] = in[u] ? ow[u].base + (uint32_t)__popc(ow[u].bits & ((1u << bitpos[u]) - 1u)) : 0u;
-        cj[u] = S.corei[fo.j[u]];
-        fw[u] = S.F[fo.j[u] >> 5];
-    }
-    fo.ent = 0;
-#pragma unroll
-    for (int u = 0; u < NC; ++u) {
-        const uint32_t mr = max(max(o.x, cj[u]), ci[u]);
-        fo.mr[u] = in[u] ? mr : LVL_NONE;
-        if (in[u] && mr == level && !((fw[u] >> (fo.j[u] & 31u)) & 1u)) fo.ent |= 1u << u;
+// The disc d2 <= level around the candidate of every lane (on = the lane has one), the ring cells k = wave, wave +
+// LVL_WORKERS, ... of it (the other workers take the rest).  The ring entries travel through scalar registers; the
+// dependent LDS reads of an iteration (occupancy word; core distance and F word of the point found) are gathers.
+//   MARK = false: dmin = smallest mr below the level (a drop), nmin = lowest index with mr == level outside F (an
+//                 entrant), entmask bit it = iteration it found an entrant (iterations < 32).
+//   MARK = true:  F |= the points outside the tree whose mr is exactly `level` (tree members carry the top bit in
+//                 their core distance, so their mr never equals a level).
+template <bool MARK>
+__device__ __forceinline__ void lvl_walk(const LvlLds &S, int wave, int nk, uint32_t level, bool on, uint32_t cand, int gw,
+                                         uint32_t &dmin, uint32_t &nmin, uint32_t &entmask) {
+    const int lane = threadIdx.x & 63;
+    dmin = nmin = LVL_NONE;
+    entmask = 0;
+    const uint32_t c0 = on ? cand : 0u;
+    const uint32_t v = S.rc[c0];
+    const uint32_t cell0 = on ? ((v & 255) + LVL_PAD) * (uint32_t)gw + (v >> 8) + LVL_PAD : 0u;   // cell 0: in the empty border
+    const uint32_t ci = on ? (S.corei[c0] & ~LVL_TREE) : LVL_NONE;
+    const int nit = (nk - wave + LVL_WORKERS - 1) / LVL_WORKERS;       // this worker's cells
+    for (int ib = 0; ib < nit; ib += 64) {
+        const int kk = LVL_WORKERS * (ib + lane) + wave;
+        const uint2 mine = S.ring[kk < nk ? kk : 0];
+        const int n64 = min(64, nit - ib);
+#pragma unroll 2
+        for (int it = 0; it < n64; ++it) {
+            const uint32_t d2 = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, it);
+            const uint32_t delta = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, it);
+            const uint32_t cell = cell0 + delta;
+            const OccW ow = S.occ[cell >> 5];
+            const bool in = on && ((ow.bits >> (cell & 31u)) & 1u);
+            const uint32_t j = in ? ow.base + (uint32_t)__popc(ow.bits & ((1u << (cell & 31u)) - 1u)) : 0u;
+            const uint32_t cj = S.corei[j];
+            const uint32_t mr = max(max(d2, cj), ci);
+            if (MARK) {
+                if (in && mr == level) atomicOr(&S.F[j >> 5], 1u << (j & 31u));
+            } else {
+                const uint32_t fw = S.F[j >> 5];
+                if (in && mr < level) dmin = min(dmin, mr);
+                if (in && mr == level && !((fw >> (j & 31u)) & 1u)) {
+                    nmin = min(nmin, j);
+                    if (ib + it < 32) entmask |= 1u << (ib + it);
+                }
+            }
+        }
     }
 }
 
@@ -880,8 +895,8 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
         S.F = carve<uint32_t>(p, (size_t)((cap + 63) / 64) * 2);
         S.ring = carve<uint2>(p, A.n_ring);
         S.rc = carve<uint16_t>(p, cap);
-        S.cand = carve<uint32_t>(p, 64);
-        S.slot = carve<uint2>(p, 64);
+        S.cand = carve<uint32_t>(p, 64 * 4);
+        S.slot = carve<uint2>(p, 64 * 4);
         S.red = carve<uint32_t>(p, 2 * NW16);
         S.ctl = carve<int>(p, 4);
         S.btab = carve<uint4>(p, LVL_NB);
@@ -1056,177 +1071,133 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
             need_rise = false;
             LVL_PHASE(0);
         }
-        // ---- wavefront 0: the first 64 members of F, in index order
-        if (wave == 0) {
-            int nc0 = 0;
-            for (int wb = 0; wb < NF64 && nc0 < 64; wb += 64) {
+        // ---- a round.  Wavefronts 0..3 (one per SIMD) work, lane i = the i-th candidate; the others only meet the
+        // barriers and read the outcome (they are needed again at the next rise).
+        const bool worker = wave < LVL_WORKERS;
+        const bool slow = m > (uint32_t)LVL_RING2;
+        const int nk = slow ? 0 : (int)S.rcnt[m];
+        const bool fast = nk <= 32 * LVL_WORKERS;                       // every worker's share of the disc fits a 32-bit entrant mask
+        int ncand = 0, a = 1;
+        uint32_t mycand = LVL_NONE, m2 = LVL_NONE, entmask = 0;
+        bool dropped = false;
+        if (worker) {
+            // the first 64 members of F in index order (each worker for itself: no barrier)
+            uint32_t *cw = S.cand + wave * 64;
+            for (int wb = 0; wb < NF64 && ncand < 64; wb += 64) {
                 const int k = wb + lane;
                 const unsigned long long W = k < NF64 ? ((const unsigned long long *)S.F)[k] : 0ull;
                 unsigned long long nz = __ballot(W != 0ull);
-                while (nz && nc0 < 64) {
+                while (nz && ncand < 64) {
                     const int src = __builtin_ctzll(nz);
                     nz &= nz - 1ull;
                     const unsigned long long Wk = readlane_u64(W, src);
                     if ((Wk >> lane) & 1ull) {
-                        const int rank = nc0 + __popcll(Wk & ((1ull << lane) - 1ull));
-                        if (rank < 64) S.cand[rank] = (uint32_t)((wb + src) * 64 + lane);
+                        const int rank = ncand + __popcll(Wk & ((1ull << lane) - 1ull));
+                        if (rank < 64) cw[rank] = (uint32_t)((wb + src) * 64 + lane);
                     }
-                    nc0 += __popcll(Wk);
+                    ncand += __popcll(Wk);
                 }
             }
-            if (lane == 0) S.ctl[0] = min(nc0, 64);
+            ncand = min(ncand, 64);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < ncand) mycand = cw[lane];
+            LVL_PHASE(1);
+            if (!slow) {
+                uint32_t dmin, nmin;
+                lvl_walk<false>(S, wave, nk, m, lane < ncand, mycand, gw, dmin, nmin, entmask);
+                S.slot[wave * 64 + lane] = make_uint2(dmin, nmin);
+            }
         }
-        __syncthreads();
-        const int ncand = S.ctl[0];
-        LVL_PHASE(1);
-        if (ncand == 0) { need_rise = true; continue; }            // F ran empty: the level rises
-        const uint32_t mycand = lane < ncand ? S.cand[lane] : LVL_NONE;
-        ++n_rounds;
-        const int nk = m <= (uint32_t)LVL_RING2 ? (int)S.rcnt[m] : 0;
-        const bool slow = m > (uint32_t)LVL_RING2, fast = !slow && nk <= LVL_FAST_NK;
-        int a = 1;
-        bool dropped = false;
-        uint32_t m2 = LVL_NONE;
-        // this wavefront's candidates: wave, wave + 16, wave + 32, wave + 48
-        uint32_t fi[4], cell0[4], ci[4];
-        const int nc = slow ? 0 : max(0, (ncand - wave + NW16 - 1) / NW16);
-        LvlFound fo[2];
-        fo[0].ent = fo[1].ent = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { fo[0].mr[u] = fo[1].mr[u] = LVL_NONE; fo[0].j[u] = fo[1].j[u] = 0; }
-        if (slow) {
-            need_rise = true;                                          // beyond the ring table: one node, then a rise
-        } else {
-            if (nc > 0) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    fi[u] = u < nc ? S.cand[wave + NW16 * u] : 0u;
-                    const uint32_t v = S.rc[fi[u]];
-                    cell0[u] = ((v & 255) + LVL_PAD) * (uint32_t)gw + (v >> 8) + LVL_PAD;
-                    ci[u] = S.corei[fi[u]] & ~LVL_TREE;
-                }
-                uint32_t dmin[4] = {LVL_NONE, LVL_NONE, LVL_NONE, LVL_NONE}, nmin[4] = {LVL_NONE, LVL_NONE, LVL_NONE, LVL_NONE};
-                if (fast) {
-#pragma unroll
-                    for (int cidx = 0; cidx < 2; ++cidx) {
-                        if (cidx * 64 >= nk) break;
-                        if (nc == 1) {
-                            const uint32_t c1[1] = {cell0[0]}, i1[1] = {ci[0]};
-                            LvlFound t;
-                            // one candidate: the single-width body (fewer instructions)
-                            const bool valid = cidx * 64 + lane < nk;
-                            const uint2 o = S.ring[valid ? cidx * 64 + lane : 0];
-                            const uint32_t cell = c1[0] + o.y;
-                            const OccW ow = S.occ[cell >> 5];
-                            const bool in = valid && ((ow.bits >> (cell & 31u)) & 1u);
-                            t.j[0] = in ? ow.base + (uint32_t)__popc(ow.bits & ((1u << (cell & 31u)) - 1u)) : 0u;
-                            const uint32_t cj = S.corei[t.j[0]], fw = S.F[t.j[0] >> 5];
-                            const uint32_t mr = max(max(o.x, cj), i1[0]);
-                            fo[cidx].j[0] = t.j[0];
-                            fo[cidx].mr[0] = in ? mr : LVL_NONE;
-                            fo[cidx].ent = (in && mr == m && !((fw >> (t.j[0] & 31u)) & 1u)) ? 1u : 0u;
-                        } else {
-                            lvl_chunk<4>(S, cell0, ci, nc, cidx * 64 + lane, nk, m, fo[cidx]);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            if (fo[cidx].mr[u] < m) dmin[u] = min(dmin[u], fo[cidx].mr[u]);
-                            if (fo[cidx].ent & (1u << u)) nmin[u] = min(nmin[u], fo[cidx].j[u]);
-                        }
-                    }
-                } else {
-                    for (int base = 0; base < nk; base += 64) {
-                        LvlFound t;
-                        lvl_chunk<4>(S, cell0, ci, nc, base + lane, nk, m, t);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            if (t.mr[u] < m) dmin[u] = min(dmin[u], t.mr[u]);
-                            if (t.ent & (1u << u)) nmin[u] = min(nmin[u], t.j[u]);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (u < nc) {
-                        const uint32_t dm = __ballot(dmin[u] != LVL_NONE) ? wave_min_u32(dmin[u]) : LVL_NONE;
-                        const uint32_t nm = __ballot(nmin[u] != LVL_NONE) ? wave_min_u32(nmin[u]) : LVL_NONE;
-                        if (lane == 0) S.slot[wave + NW16 * u] = make_uint2(dm, nm);
-                    }
-            }
+        if (!slow) {
             __syncthreads();
             LVL_PHASE(2);
-            // ---- accepted prefix (every wavefront computes the same)
-            uint2 sl = make_uint2(LVL_NONE, LVL_NONE);
-            if (lane < ncand) sl = S.slot[lane];
-            const uint32_t pend = wave_prefix_min_u32(sl.y);
-            const uint32_t nextf = (uint32_t)__shfl_down((int)mycand, 1);
-            const bool stop = lane < ncand && (sl.x != LVL_NONE || (lane + 1 < ncand && pend < nextf));
-            const unsigned long long bal = __ballot(stop);
-            a = bal ? __builtin_ctzll(bal) + 1 : ncand;
-            m2 = (uint32_t)__builtin_amdgcn_readlane((int)sl.x, a - 1);
-            dropped = m2 != LVL_NONE;
         }
-        // ---- commit: edges, tree membership, F
-        const uint32_t prevc = (uint32_t)__shfl_up((int)mycand, 1);
-        if (wave == 0 && lane < a) {
-            const uint32_t from = lane == 0 ? cur : prevc;
-            mst[cnt - 1 + lane] = hdb::Edge{(uint16_t)from, (uint16_t)mycand, m};
-            const uint32_t v = S.rc[mycand];
-            const uint32_t cj = S.corei[mycand];
-            S.tnode[cnt + lane] = make_uint2((v & 255) | ((v >> 8) << 16), cj);
-            S.corei[mycand] = cj | LVL_TREE;
-            if (!dropped) atomicAnd(&S.F[mycand >> 5], ~(1u << (mycand & 31u)));
-        }
-        cur = (uint32_t)__builtin_amdgcn_readlane((int)mycand, a - 1);
-        cnt += a;
-        if (cnt >= N) break;
-        if (slow) { __syncthreads(); LVL_PHASE(3); continue; }
-        if (!dropped && fast) {
-            // entrants of this wavefront's accepted candidates, straight from the registers of the probe
+        ++n_rounds;
+        if (worker) {
+            if (!slow) {
+                // ---- accepted prefix (every worker computes the same)
+                uint2 sl = S.slot[lane];
 #pragma unroll
-            for (int cidx = 0; cidx < 2; ++cidx)
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (wave + NW16 * u < a && (fo[cidx].ent & (1u << u)))
-                        atomicOr(&S.F[fo[cidx].j[u] >> 5], 1u << (fo[cidx].j[u] & 31u));
-            __syncthreads();
-            LVL_PHASE(3);
-            continue;
+                for (int w2 = 1; w2 < LVL_WORKERS; ++w2) {
+                    const uint2 t = S.slot[w2 * 64 + lane];
+                    sl.x = min(sl.x, t.x); sl.y = min(sl.y, t.y);
+                }
+                if (lane >= ncand) sl = make_uint2(LVL_NONE, LVL_NONE);
+                const uint32_t pend = wave_prefix_min_u32(sl.y);
+                const uint32_t nextf = (uint32_t)__shfl_down((int)mycand, 1);
+                const bool stop = lane < ncand && (sl.x != LVL_NONE || (lane + 1 < ncand && pend < nextf));
+                const unsigned long long bal = __ballot(stop);
+                a = bal ? __builtin_ctzll(bal) + 1 : ncand;
+                m2 = (uint32_t)__builtin_amdgcn_readlane((int)sl.x, a - 1);
+                dropped = m2 != LVL_NONE;
+            }
+            // ---- commit: edges, tree membership, F
+            const uint32_t prevc = (uint32_t)__shfl_up((int)mycand, 1);
+            if (wave == 0 && lane < a) {
+                const uint32_t from = lane == 0 ? cur : prevc;
+                mst[cnt - 1 + lane] = hdb::Edge{(uint16_t)from, (uint16_t)mycand, m};
+                const uint32_t v = S.rc[mycand];
+                const uint32_t cj = S.corei[mycand];
+                S.tnode[cnt + lane] = make_uint2((v & 255) | ((v >> 8) << 16), cj);
+                S.corei[mycand] = cj | LVL_TREE;
+                if (!dropped) atomicAnd(&S.F[mycand >> 5], ~(1u << (mycand & 31u)));
+            }
+            if (!slow && !dropped && fast && lane < a && entmask) {
+                // entrants of the accepted candidates, from the cells the probe remembered
+                const uint32_t v = S.rc[mycand];
+                const uint32_t cell0 = ((v & 255) + LVL_PAD) * (uint32_t)gw + (v >> 8) + LVL_PAD;
+                uint32_t em = entmask;
+                while (em) {
+                    const int it = __builtin_ctz(em);
+                    em &= em - 1u;
+                    const uint32_t cell = cell0 + S.ring[LVL_WORKERS * it + wave].y;
+                    const OccW ow = S.occ[cell >> 5];
+                    const uint32_t j = ow.base + (uint32_t)__popc(ow.bits & ((1u << (cell & 31u)) - 1u));
+                    atomicOr(&S.F[j >> 5], 1u << (j & 31u));
+                }
+            }
+            if (dropped) for (int i = tid; i < 2 * NF64; i += 64 * LVL_WORKERS) S.F[i] = 0u;
+            if (wave == 0 && lane == 0) {
+                S.ctl[0] = a;
+                S.ctl[1] = dropped ? 1 : 0;
+                S.ctl[2] = (int)(dropped ? m2 : m);
+                S.ctl[3] = (int)(uint32_t)__builtin_amdgcn_readlane((int)mycand, 0);      // (placeholder, overwritten below)
+            }
+            if (wave == 0) {
+                const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)mycand, a - 1);
+                if (lane == 0) S.ctl[3] = (int)last;
+            }
         }
-        // drop, or a disc too large for the registers: F is rebuilt / extended by a second walk of the discs, after
-        // the tree membership of this round's nodes is visible
-        if (dropped) for (int i = tid; i < 2 * NF64; i += TB) S.F[i] = 0u;
         __syncthreads();
         LVL_PHASE(3);
-        {
-            const uint32_t target = dropped ? m2 : m;
-            const int nkt = (int)S.rcnt[target];
-            // after a drop only the last accepted candidate's disc counts (the points whose mr is the new level)
-            const int first = dropped ? a - 1 : 0;
-            uint32_t c2[4], i2[4];
-            int nc2 = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = wave + NW16 * u;
-                const bool on = i >= first && i < a;
-                const uint32_t fcand = on ? S.cand[i] : 0u;
-                const uint32_t v = S.rc[fcand];
-                c2[u] = ((v & 255) + LVL_PAD) * (uint32_t)gw + (v >> 8) + LVL_PAD;
-                i2[u] = on ? (S.corei[fcand] & ~LVL_TREE) : LVL_NONE;  // an unused slot never matches the target
-                if (on) nc2 = u + 1;
+        a = S.ctl[0];
+        dropped = S.ctl[1] != 0;
+        const uint32_t mnew = (uint32_t)S.ctl[2];
+        cur = (uint32_t)S.ctl[3];
+        cnt += a;
+        if (cnt >= N) break;
+        if (slow) { need_rise = true; continue; }                       // beyond the ring table: one node, then a rise
+        if (dropped || !fast) {
+            // a drop (F is rebuilt from the last node's disc at the new, lower level) or a disc too large for the
+            // entrant masks: a second walk, now that this round's nodes carry their tree bit
+            if (worker) {
+                const bool on = dropped ? lane == a - 1 : lane < a;
+                uint32_t d_, n_, e_;
+                lvl_walk<true>(S, wave, (int)S.rcnt[mnew], mnew, on, mycand, gw, d_, n_, e_);
             }
-            if (nc2 > 0)
-                for (int base = 0; base < nkt; base += 64) {
-                    LvlFound t;
-                    lvl_chunk<4>(S, c2, i2, nc2, base + lane, nkt, target, t);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (t.mr[u] == target) atomicOr(&S.F[t.j[u] >> 5], 1u << (t.j[u] & 31u));
-                }
-            if (dropped) m = m2;
+            m = mnew;
+            __syncthreads();
+            LVL_PHASE(4);
         }
-        __syncthreads();
-        LVL_PHASE(4);
+        // F empty -> the level rises (every wavefront reads the same words)
+        {
+            bool any = false;
+            for (int wb = 0; wb < NF64; wb += 64) {
+                const int k = wb + lane;
+                any = any || (__ballot(k < NF64 && ((const unsigned long long *)S.F)[k] != 0ull) != 0ull);
+            }
+            need_rise = !any;
+        }
     }
     if (tid == 0) {
         hdr[12] = (int)(wall_clock64() - t0); hdr[16] = n_rounds; hdr[17] = n_rises;

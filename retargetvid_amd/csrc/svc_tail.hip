@@ -1892,7 +1892,8 @@ __global__ __launch_bounds__(64) void k_tree(TailArgs A) {
 // Only the float64 stability sums stay serial per cluster (one wavefront per cluster: terms in parallel, additions in
 // the library's order), as in hdb::accumulate.  N - 1 serial union-find steps become ~15 block-wide passes.
 // --------------------------------------------------------------------------------------
-#define TP_CAP 4352                     // points per map kept in LDS (above: k_tree)
+#define TP_CAP 4352                     // points per map with everything in LDS
+#define TP_CAP_BIG 8192                 // ... with the jump buffers, weights and order in the frame's workspace (above: k_tree)
 #define TP_NONE 0xFFFFu
 enum { TP_SMALL = 0, TP_BIRTH = 1, TP_SPLIT = 2, TP_ABS_A = 3, TP_ABS_B = 4 };   // ABS_A: the a side is big, the b side falls out
 
@@ -1905,10 +1906,12 @@ struct TpCl {            // per condensed cluster
 };
 
 static size_t tp_lds_bytes(int hw, int mcs, int *cap_clusters) {
-    const int cap = std::min(hw, TP_CAP);
+    const int cap = std::min(hw, TP_CAP), capb = std::min(hw, TP_CAP_BIG);
     auto up = [](size_t b) { return (b + 15) / 16 * 16; };
-    const size_t per_edge = up((size_t)cap * 2) * 8 + up((size_t)(cap + 256) * 2) + up((size_t)cap * 4) * 3 + up((size_t)((cap + 256) / 16 + 16) * 2) + 64;
-    int cc = hdb::max_clusters(cap, mcs);
+    const size_t small = up((size_t)cap * 2) * 8 + up((size_t)(cap + 256) * 2) + up((size_t)cap * 4) * 3 + up((size_t)((cap + 256) / 16 + 16) * 2) + 64;
+    const size_t big = hw > TP_CAP ? up((size_t)capb * 2) * 6 + up((size_t)(capb + 256) * 2) + up((size_t)((capb + 256) / 16 + 16) * 2) + 64 : 0;
+    const size_t per_edge = std::max(small, big);
+    int cc = hdb::max_clusters(capb, mcs);
     const size_t budget = 160 * 1024 - 4096;
     while (cc > 8 && per_edge + (size_t)cc * 48 + 512 > budget) cc /= 2;
     *cap_clusters = cc;
@@ -1932,27 +1935,28 @@ __device__ __forceinline__ int tp_class(int sa, int sb, int mcs) {
     return sa >= mcs ? TP_ABS_A : TP_ABS_B;
 }
 
-__global__ __launch_bounds__(TB) void k_tree_par(TailArgs A, int cap_clusters) {
-    const int f = A.order[blockIdx.x];
-    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
-    int32_t *hdr = (int32_t *)(ws + A.L.hdr);
-    if (!hdr[3]) return;
-    const int N = hdr[0];
-    if (N > TP_CAP) return;                                            // k_tree takes it
+// BIG = false: maps of up to TP_CAP points, everything in LDS.  BIG = true: up to TP_CAP_BIG points -- the weights and
+// the sorted order are read from the frame's workspace, the two jump buffers live there, the row lists re-use the
+// child links (dead by then), so that the rest still fits in LDS.
+template <bool BIG>
+__device__ __forceinline__ void tp_body(const TailArgs &A, int cap_clusters, uint8_t *ws, int32_t *hdr, int N, uint8_t *sm_tp,
+                                        int *lds16, int &sh_nc, int &sh_nsel) {
     const int E = N - 1, mcs = A.mcs;
-    extern __shared__ uint8_t sm_tp[];
-    __shared__ int lds16[NW16];
-    __shared__ int sh_nc, sh_nsel;
 #define TP_STAMP(i) do { if (tid == 0) hdr[25 + (i)] = (int)(wall_clock64() - t0); } while (0)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long t0 = wall_clock64();
-    const int cap = min(A.h * A.w, TP_CAP);
+    const int cap = min(A.h * A.w, BIG ? TP_CAP_BIG : TP_CAP);
     uint8_t *p = sm_tp;
-    uint16_t *order = carve<uint16_t>(p, cap), *rho = carve<uint16_t>(p, cap + 256), *sa = carve<uint16_t>(p, cap), *sb = carve<uint16_t>(p, cap);
+    uint16_t *rho = carve<uint16_t>(p, cap + 256), *sa = carve<uint16_t>(p, cap), *sb = carve<uint16_t>(p, cap);
     uint16_t *par = carve<uint16_t>(p, cap), *lch = carve<uint16_t>(p, cap), *rch = carve<uint16_t>(p, cap), *cid = carve<uint16_t>(p, cap);
-    uint16_t *rowlist = carve<uint16_t>(p, cap);
-    uint32_t *w = carve<uint32_t>(p, cap), *jA = carve<uint32_t>(p, cap), *jB = carve<uint32_t>(p, cap);
+    uint16_t *order = BIG ? nullptr : carve<uint16_t>(p, cap);
+    uint16_t *rowlist = BIG ? lch : carve<uint16_t>(p, cap);
+    uint32_t *w = BIG ? nullptr : carve<uint32_t>(p, cap);
+    uint32_t *jA = BIG ? (uint32_t *)(ws + A.L.dparent) : carve<uint32_t>(p, cap);
+    uint32_t *jB = BIG ? (uint32_t *)(ws + A.L.dparent) + (size_t)A.h * A.w : carve<uint32_t>(p, cap);
     uint16_t *l1 = carve<uint16_t>(p, (cap + 256) / 16 + 16), *l2 = carve<uint16_t>(p, 32);
+#define TP_ORDER(s_) (BIG ? (int)perm[s_] : (int)order[s_])
+#define TP_W(k_) (BIG ? mst[k_].w : w[k_])
     TpCl C;
     C.acc = carve<double>(p, cap_clusters);
     C.birthw = carve<uint32_t>(p, cap_clusters); C.minw = carve<uint32_t>(p, cap_clusters); C.weight = carve<uint32_t>(p, cap_clusters);
@@ -1965,9 +1969,8 @@ __global__ __launch_bounds__(TB) void k_tree_par(TailArgs A, int cap_clusters) {
     // ---- ranks, weights, block maxima of the ranks
     for (int s0 = tid; s0 < E; s0 += TB) {
         const uint32_t k = perm[s0];
-        order[s0] = (uint16_t)k;
+        if (!BIG) { order[s0] = (uint16_t)k; w[s0] = mst[s0].w; }      // (w: index = Prim position)
         rho[k] = (uint16_t)s0;
-        w[s0] = mst[s0].w;                                             // (index = Prim position)
         lch[s0] = rch[s0] = TP_NONE;
     }
     for (int i = E + tid; i < ((E + 255) & ~255); i += TB) rho[i] = 0;     // padding: never "greater"
@@ -2050,17 +2053,17 @@ __global__ __launch_bounds__(TB) void k_tree_par(TailArgs A, int cap_clusters) {
         const int per = (E + TB - 1) / TB, lo = min(E, tid * per), hi = min(E, lo + per);
         int cnt = 0;
         for (int s0 = lo; s0 < hi; ++s0) {
-            const int k = order[s0], cl = tp_class(sa[k], sb[k], mcs);
+            const int k = TP_ORDER(s0), cl = tp_class(sa[k], sb[k], mcs);
             cnt += cl == TP_BIRTH || cl == TP_SPLIT;
         }
         int tot;
         int id = block_excl_scan(cnt, lds16, &tot);
         if (tid == 0) sh_nc = tot;
         for (int s0 = lo; s0 < hi; ++s0) {
-            const int k = order[s0], cl = tp_class(sa[k], sb[k], mcs);
+            const int k = TP_ORDER(s0), cl = tp_class(sa[k], sb[k], mcs);
             const bool isc = cl == TP_BIRTH || cl == TP_SPLIT;
             cid[k] = isc ? (uint16_t)id : TP_NONE;
-            if (isc && id < cap_clusters) { C.node[id] = (uint16_t)k; C.minw[id] = w[k]; C.tp[id] = TP_NONE; C.birthw[id] = 0; C.acc[id] = 0.0; C.weight[id] = 0; }
+            if (isc && id < cap_clusters) { C.node[id] = (uint16_t)k; C.minw[id] = TP_W(k); C.tp[id] = TP_NONE; C.birthw[id] = 0; C.acc[id] = 0.0; C.weight[id] = 0; }
             id += isc;
             // jump pointer: (next edge down the chain of the big side) | distance << 16; births, splits, small unions end it
             const uint32_t nx = cl == TP_ABS_A ? lch[k] : (cl == TP_ABS_B ? rch[k] : (uint32_t)k);
@@ -2093,7 +2096,7 @@ __global__ __launch_bounds__(TB) void k_tree_par(TailArgs A, int cap_clusters) {
             const uint32_t l = cid[ja[lch[k]] & 0xFFFFu], r = cid[ja[rch[k]] & 0xFFFFu];
             C.left[pc] = (uint16_t)l; C.right[pc] = (uint16_t)r;
             C.tp[l] = C.tp[r] = (uint16_t)pc;
-            C.birthw[l] = C.birthw[r] = w[k];
+            C.birthw[l] = C.birthw[r] = TP_W(k);
             C.spa[pc] = sa[k]; C.spb[pc] = sb[k];
         } else if (cl == TP_BIRTH) {
             C.left[cid[k]] = C.right[cid[k]] = TP_NONE;
@@ -2134,7 +2137,7 @@ __global__ __launch_bounds__(TB) void k_tree_par(TailArgs A, int cap_clusters) {
             if (i < len) {
                 const int k = rowlist[off + i];
                 const int cl = tp_class(sa[k], sb[k], mcs);
-                const double lam = 1.0 / (double)w[k];
+                const double lam = 1.0 / (double)TP_W(k);
                 term = (lam - birth) * 1.0;
                 if (cl == TP_SPLIT) { ta = (lam - birth) * (double)C.spa[c]; tb = (lam - birth) * (double)C.spb[c]; cnt = 0; }
                 else cnt = cl == TP_BIRTH ? (uint32_t)(sa[k] + sb[k]) : (cl == TP_ABS_A ? sb[k] : sa[k]);
@@ -2202,7 +2205,7 @@ __global__ __launch_bounds__(TB) void k_tree_par(TailArgs A, int cap_clusters) {
         const int rep = C.rep[c0];
         int lab = rep;
         if (rep == hdb::ROOT_NOISE) lab = -1;
-        else if (rep == nc - 1 && nsel == 1) lab = w[e] <= C.minw[nc - 1] ? rep : -1;
+        else if (rep == nc - 1 && nsel == 1) lab = TP_W(e) <= C.minw[nc - 1] ? rep : -1;
         const uint32_t pid = i == 0 ? mst[0].a : mst[i - 1].b;
         labels[pid] = lab;
         if (lab >= 0) {
@@ -2240,6 +2243,22 @@ __global__ __launch_bounds__(TB) void k_tree_par(TailArgs A, int cap_clusters) {
         hdr[10] = (int)(wall_clock64() - t0);
         hdr[15] = hdr[10];
     }
+}
+#undef TP_ORDER
+#undef TP_W
+
+__global__ __launch_bounds__(TB) void k_tree_par(TailArgs A, int cap_clusters) {
+    const int f = A.order[blockIdx.x];
+    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
+    int32_t *hdr = (int32_t *)(ws + A.L.hdr);
+    if (!hdr[3]) return;
+    const int N = hdr[0];
+    if (N > TP_CAP_BIG) return;                                        // k_tree takes it
+    extern __shared__ uint8_t sm_tp[];
+    __shared__ int lds16[NW16];
+    __shared__ int sh_nc, sh_nsel;
+    if (N <= TP_CAP) tp_body<false>(A, cap_clusters, ws, hdr, N, sm_tp, lds16, sh_nc, sh_nsel);
+    else tp_body<true>(A, cap_clusters, ws, hdr, N, sm_tp, lds16, sh_nc, sh_nsel);
 }
 
 // k_finish: zero everything outside the kept cluster, CLOSE 5x5, write the map back, centroid
@@ -2610,7 +2629,7 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
                     SVC_CHECK_LAUNCH();
                 }
                 // the serial builder: maps the parallel one does not hold in LDS (more points or clusters), or all (SVC_TREE_PAR=0)
-                if (!h->tree_par || hw > TP_CAP || hdb::max_clusters(std::min(hw, TP_CAP), params->hdbscan_min) > cap_cl) {
+                if (!h->tree_par || hw > TP_CAP_BIG || hdb::max_clusters(std::min(hw, TP_CAP_BIG), params->hdbscan_min) > cap_cl) {
                     k_tree<<<m, 64, FIN_LDS_BYTES, s>>>(A);
                     SVC_CHECK_LAUNCH();
                 }

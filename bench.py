@@ -62,7 +62,7 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--pipeline', type=int, default=4, help='batches in flight per GPU (engines / HIP streams)')
-    ap.add_argument('--cpu-sample', type=int, default=32, help='frames of the CPU baseline sample (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=160, help='frames of the CPU baseline sample (0 = skip)')
     ap.add_argument('--iso-steps', type=int, default=3, help='un-pipelined profiling steps per kernel class')
     ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps each; the median is reported')
     return ap.parse_args(argv)
@@ -341,11 +341,14 @@ def main():
         slots[0].finish()
     latency_ms = None if plain else (time.perf_counter() - t1) / 10 * 1e3
     # points per map of this workload (what the clustering kernels see)
-    with torch.cuda.stream(slots[0].stream):
-        m_ = eng.saliency(eng.resize_frames(frames, 140, 250))
-        eng.threshold_(m_, CP['t_threshold'])
-        _, st_ = eng.cluster_center_(m_, flags, CP, want_stats=True)
-    npts = st_[:, 0].cpu().numpy()
+    if plain:
+        npts = np.zeros(B, np.int64)                              # (counter passes: nothing but warm-up + timed steps may run)
+    else:
+        with torch.cuda.stream(slots[0].stream):
+            m_ = eng.saliency(eng.resize_frames(frames, 140, 250))
+            eng.threshold_(m_, CP['t_threshold'])
+            _, st_ = eng.cluster_center_(m_, flags, CP, want_stats=True)
+        npts = st_[:, 0].cpu().numpy()
     dominant = max(per_class, key=lambda k: per_class[k][0])
     # BENCH_LIVE_PROFILE=1 also records the dominant class's events INSIDE the timed region (roofline.*_in_flight).  Off by
     # default: 76 event records per step on every stream cost 2-3 % of the step with four batches in flight (1.49 -> 1.45 ms)
@@ -424,7 +427,7 @@ def main():
                         hbm_note='un-fused layer-wise fp32 traffic of the class (in + out + weights) / class time')
         roof['traffic'] = None
         try:
-            src = os.path.join('profiles', 'r02_pmc_traffic.json')
+            src = os.path.join('profiles', 'r03_pmc_traffic.json')
             with open(os.path.join(ROOT, src)) as fp:
                 c = json.load(fp)['classes'][dominant]
             roof.update(traffic=c['hbm_bytes_per_launch'], traffic_per_step=c.get('hbm_bytes_per_step'),

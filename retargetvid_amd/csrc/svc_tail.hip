@@ -1032,6 +1032,19 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
                 const uint32_t kmin = wave_min_u32(tn.y);
                 if (lane == 0) S.btab[nb + g] = make_uint4((uint32_t)s0 | ((uint32_t)len << 16), rmin | (rmax << 8) | (cmin << 16) | (cmax << 24), kmin, 0u);
             }
+            const bool single = cnt - done == 1;                       // one new node (the start, a jump beyond the ring table)
+            if (single) {
+                // ... is relaxed against every chunk right away: the bound below is then tight and one sweep is enough
+                const uint2 tn = S.tnode[done];
+#pragma unroll
+                for (int q = 0; q < LVL_PT; ++q)
+                    if (qmask & (1u << q)) {
+                        const lvl_s2 d = __builtin_bit_cast(lvl_s2, rcq[q]) - __builtin_bit_cast(lvl_s2, tn.x);
+                        R[q] = min(R[q], max(max((uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false), cjq[q]), tn.y));
+                        const int c = q * NW16 + wave;
+                        if (lane == 0) S.proc[c * (LVL_NB / 32) + (nb >> 5)] |= 1u << (nb & 31);
+                    }
+            }
             nb += nnew;
             done = cnt;
             const uint32_t ub0 = block_min_R();                        // (its barrier also publishes the new batches)
@@ -1039,9 +1052,9 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
             for (int q = 0; q < LVL_PT; ++q)
                 if (qmask & (1u << q)) {
                     const int c = q * NW16 + wave;
-                    R[q] = lvl_sweep_chunk<false>(S, S.btab, S.proc + c * (LVL_NB / 32), nb, min(ub0, LVL_NEAR), false, S.cbox[c], rcq[q], cjq[q], R[q]);
+                    R[q] = lvl_sweep_chunk<false>(S, S.btab, S.proc + c * (LVL_NB / 32), nb, single ? ub0 : min(ub0, LVL_NEAR), false, S.cbox[c], rcq[q], cjq[q], R[q]);
                 }
-            if (ub0 > LVL_NEAR) {
+            if (ub0 > LVL_NEAR && !single) {
                 // a jump between blobs: the nearest pending batch of every chunk tightens the bound, then the rest
                 const uint32_t ub1 = block_min_R();
 #pragma unroll
@@ -1654,7 +1667,7 @@ __device__ __forceinline__ void sort_swap(const SortArrays &a, int i, int j) {
 }
 
 // numpy's aheapsort on positions lo .. lo+n-1 (keys and indices move together)
-__device__ void sort_heapsort(const SortArrays &a, int lo, int n) {
+__device__ __forceinline__ void sort_heapsort(const SortArrays &a, int lo, int n) {
 #define HK(i) a.key[lo + (i) - 1]
 #define HI(i) a.idx[lo + (i) - 1]
     for (int l = n >> 1; l > 0; --l) {
@@ -1683,7 +1696,7 @@ __device__ void sort_heapsort(const SortArrays &a, int lo, int n) {
 
 // out[p] = index (into the caller's key order) of the element numpy's argsort puts at position p.
 // a.key[0..n) holds the keys on entry.  All TB threads of the block call this.
-__device__ void np_argsort_block(const SortArrays &a, const SortSegs &st, int n, uint16_t *out, int *sh /* [NW16 + 4] */) {
+__device__ __forceinline__ void np_argsort_block(const SortArrays &a, const SortSegs &st, int n, uint16_t *out, int *sh /* [NW16 + 4] */) {
     const int tid = threadIdx.x;
     int *cnt = sh + NW16;                                  // cnt[0], cnt[1]: ranges of the two generations
     for (int i = tid; i < n; i += TB) { a.idx[i] = (uint16_t)i; a.seg[i] = 0; a.lpos[i] = 0; a.rpos[i] = (uint16_t)(n - 1); }
@@ -1706,9 +1719,14 @@ __device__ void np_argsort_block(const SortArrays &a, const SortSegs &st, int n,
         const int ns = cnt[cur];
         if (ns == 0) break;
         const int nxt = cur ^ 1;
+        // (select the generation's arrays with conditional moves: indexing the pointer arrays with a runtime value would
+        // put the descriptor structs into a private segment)
+        uint16_t *lo_c = cur ? st.lo[1] : st.lo[0], *hi_c = cur ? st.hi[1] : st.hi[0];
+        uint16_t *lo_n = cur ? st.lo[0] : st.lo[1], *hi_n = cur ? st.hi[0] : st.hi[1];
+        int16_t *dep_c = cur ? st.dep[1] : st.dep[0], *dep_n = cur ? st.dep[0] : st.dep[1];
         // 1. median of three, pivot parked at hi - 1
         for (int s = tid; s < ns; s += TB) {
-            const int pl = st.lo[cur][s], pr = st.hi[cur][s], pm = pl + ((pr - pl) >> 1);
+            const int pl = lo_c[s], pr = hi_c[s], pm = pl + ((pr - pl) >> 1);
             if (a.key[pm] < a.key[pl]) sort_swap(a, pm, pl);
             if (a.key[pr] < a.key[pm]) sort_swap(a, pr, pm);
             if (a.key[pm] < a.key[pl]) sort_swap(a, pm, pl);
@@ -1722,7 +1740,7 @@ __device__ void np_argsort_block(const SortArrays &a, const SortSegs &st, int n,
         for (int i = c_lo; i < c_hi; ++i) {
             const uint32_t sg = a.seg[i];
             if (sg != SORT_NONE) {
-                const int pl = st.lo[cur][sg], pr = st.hi[cur][sg];
+                const int pl = lo_c[sg], pr = hi_c[sg];
                 const uint32_t vp = st.vp[sg], k = a.key[i];
                 acc += (uint32_t)(i > pl && i <= pr - 1 && k >= vp) | ((uint32_t)(i <= pr - 2 && k <= vp) << 16);
             }
@@ -1736,7 +1754,7 @@ __device__ void np_argsort_block(const SortArrays &a, const SortSegs &st, int n,
         for (int i = tid; i < n; i += TB) {
             const uint32_t sg = a.seg[i];
             if (sg == SORT_NONE) continue;
-            const int pl = st.lo[cur][sg], pr = st.hi[cur][sg];
+            const int pl = lo_c[sg], pr = hi_c[sg];
             const uint32_t vp = st.vp[sg], k = a.key[i], sc = a.scan[i], base = pl > 0 ? a.scan[pl - 1] : 0u;
             if (i > pl && i <= pr - 1 && k >= vp) a.lpos[pl + (int)((sc & 0xFFFFu) - (base & 0xFFFFu)) - 1] = (uint16_t)i;
             if (i <= pr - 2 && k <= vp) a.rpos[pl + (int)((a.scan[pr - 2] >> 16) - (sc >> 16))] = (uint16_t)i;
@@ -1746,7 +1764,7 @@ __device__ void np_argsort_block(const SortArrays &a, const SortSegs &st, int n,
         for (int i = tid; i < n; i += TB) {
             const uint32_t sg = a.seg[i];
             if (sg == SORT_NONE) continue;
-            const int pl = st.lo[cur][sg], pr = st.hi[cur][sg], k = i - pl;
+            const int pl = lo_c[sg], pr = hi_c[sg], k = i - pl;
             const uint32_t base = pl > 0 ? a.scan[pl - 1] : 0u;
             const int nL = (int)((a.scan[pr - 1] & 0xFFFFu) - (base & 0xFFFFu)), nR = (int)((a.scan[pr - 2] >> 16) - (base >> 16));
             if (k < nL && k < nR) {
@@ -1757,7 +1775,7 @@ __device__ void np_argsort_block(const SortArrays &a, const SortSegs &st, int n,
         __syncthreads();
         // 5. where the left pointer ends, the pivot goes there, the two sides become ranges of the next generation
         for (int s = tid; s < ns; s += TB) {
-            const int pl = st.lo[cur][s], pr = st.hi[cur][s], K = (int)st.K[s];
+            const int pl = lo_c[s], pr = hi_c[s], K = (int)st.K[s];
             const uint32_t base = pl > 0 ? a.scan[pl - 1] : 0u;
             const int nL = (int)((a.scan[pr - 1] & 0xFFFFu) - (base & 0xFFFFu));
             const int rprev = K >= 1 ? (int)a.rpos[pl + K - 1] : pr;
@@ -1765,7 +1783,7 @@ __device__ void np_argsort_block(const SortArrays &a, const SortSegs &st, int n,
             if (K < nL && (int)a.lpos[pl + K] < rprev) pi = a.lpos[pl + K];
             sort_swap(a, pi, pr - 1);
             st.pi[s] = (uint16_t)pi;
-            const int d = st.dep[cur][s] - 1;
+            const int d = dep_c[s] - 1;
             const bool push_right = (pi - pl) < (pr - pi);          // the larger side goes on numpy's stack
             uint16_t slot[2];
 #pragma unroll
@@ -1779,7 +1797,7 @@ __device__ void np_argsort_block(const SortArrays &a, const SortSegs &st, int n,
                     for (int e = lo; e <= hi; ++e) { a.lpos[e] = (uint16_t)e; a.rpos[e] = (uint16_t)e; }
                 } else if (hi - lo > SORT_SMALL) {
                     const int q = atomicAdd(&cnt[nxt], 1);
-                    st.lo[nxt][q] = (uint16_t)lo; st.hi[nxt][q] = (uint16_t)hi; st.dep[nxt][q] = (int16_t)d;
+                    lo_n[q] = (uint16_t)lo; hi_n[q] = (uint16_t)hi; dep_n[q] = (int16_t)d;
                     slot[side] = (uint16_t)q;
                 } else {
                     for (int e = lo; e <= hi; ++e) { a.lpos[e] = (uint16_t)lo; a.rpos[e] = (uint16_t)hi; }

@@ -7,7 +7,7 @@ from oracle import pipeline_ref as P
 eng = ops.Engine(weights.make_synthetic_state_dict(0))
 CP = P.init_crop_params()
 sg = os.environ.get('SIGMA')
-fr = torch.from_numpy(synth.blob_frames(32, 360, 640, seed=int(os.environ.get('SEED', 100)), **(dict(sigma=tuple(float(x) for x in sg.split(','))) if sg else {}))).cuda()
+fr = torch.from_numpy(synth.blob_frames(32, 360, 640, seed=int(os.environ.get('SEED', 100)), **dict((dict(sigma=tuple(float(x) for x in sg.split(','))) if sg else {}), **(dict(n_blobs=int(os.environ['N_BLOBS'])) if os.environ.get('N_BLOBS') else {})))).cuda()
 small = eng.resize_frames(fr, 140, 250)
 maps = eng.saliency(small)
 eng.threshold_(maps, int(os.environ.get('THRESH', CP['t_threshold'])))

@@ -2834,6 +2834,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->shot_form = atoi(env);
     env = getenv("SVC_PRIM_PT");
     if (env && atoi(env) > 0) h->prim_pt = atoi(env);
+    env = getenv("SVC_TAIL_MERGE");
+    if (env) h->tail_merge = atoi(env);
     env = getenv("SVC_TREE_PAR");
     if (env) h->tree_par = atoi(env);
     env = getenv("SVC_PRIM_LVL");

@@ -250,7 +250,7 @@ __device__ __forceinline__ void copy_bytes(uint8_t *__restrict__ dst, const uint
     }
 }
 
-__global__ __launch_bounds__(TB) void k_compact(TailArgs A) {
+__device__ __forceinline__ void compact_body(const TailArgs &A) {
     const int f = A.order[blockIdx.x];
     __shared__ int lds16[NW16];
     extern __shared__ uint8_t sm_compact[];                  // the map: read once with whole lines, scanned from LDS
@@ -282,8 +282,10 @@ __global__ __launch_bounds__(TB) void k_compact(TailArgs A) {
         hdr[2] = -1;
         hdr[3] = (A.clust_filt && total > A.mcs + 1) ? 1 : 0;
         hdr[23] = 0;                                                     // k_tree_par sets it when it has done the map's hierarchy
+        hdr[22] = 0;                                                     // k_tail_back sets it when it has finished the map (zeroing, CLOSE, centre)
     }
 }
+__global__ __launch_bounds__(TB) void k_compact(TailArgs A) { compact_body(A); }
 
 // --------------------------------------------------------------------------------------
 // k_core: squared distance to the k-th nearest other point, three exact phases:
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(TB) void k_compact(TailArgs A) {
 //  3. points with fewer than k neighbours within RING_R: wave-wide bisection on the count
 //     of points within distance t over all N points.
 // --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TB) void k_core(TailArgs A) {
+__device__ __forceinline__ void core_body(const TailArgs &A) {
     const int f = A.order[blockIdx.x];
     uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
     const int32_t *hdr = (const int32_t *)(ws + A.L.hdr);
@@ -474,6 +476,7 @@ __global__ __launch_bounds__(TB) void k_core(TailArgs A) {
     __syncthreads();
     if (threadIdx.x == 0) stamp[7] = (int)(wall_clock64() - tc0);
 }
+__global__ __launch_bounds__(TB) void k_core(TailArgs A) { core_body(A); }
 
 // --------------------------------------------------------------------------------------
 // k_prim: the library's Prim over the mutual-reachability graph, start node 0, lowest
@@ -873,7 +876,7 @@ __device__ __forceinline__ uint32_t lvl_sweep_chunk(const LvlLds &S, const uint4
     return r;
 }
 
-__global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
+__device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
     const int f = A.order[blockIdx.x];
     uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
     int32_t *hdr = (int32_t *)(ws + A.L.hdr);
@@ -1217,6 +1220,7 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) {
         for (int i = 0; i < 5; ++i) hdr[18 + i] = (int)ph[i];
     }
 }
+__global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) { prim_lvl_body(A); }
 
 // One 1x5 (ROWS) or 5x1 pass of the separable grey CLOSE over a map in LDS: MAX = dilate, else erode; samples
 // outside the image are ignored (OpenCV's morphology border).  A thread produces four consecutive outputs
@@ -1845,7 +1849,7 @@ __device__ __forceinline__ void sort_carve(uint8_t *lds, uint8_t *glob, int n, S
     a.idx = carve<uint16_t>(q, n); a.seg = carve<uint16_t>(q, n); a.lpos = carve<uint16_t>(q, n); a.rpos = carve<uint16_t>(q, n);
 }
 
-__global__ __launch_bounds__(TB) void k_sort(TailArgs A) {
+__device__ __forceinline__ void sort_body(const TailArgs &A) {
     const int f = A.order[blockIdx.x];
     uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
     int32_t *hdr = (int32_t *)(ws + A.L.hdr);
@@ -1863,6 +1867,7 @@ __global__ __launch_bounds__(TB) void k_sort(TailArgs A) {
     for (int i = threadIdx.x; i < n; i += TB) ea[i] = mst[perm[i]];
     if (threadIdx.x == 0) hdr[8] = (int)(wall_clock64() - t0);
 }
+__global__ __launch_bounds__(TB) void k_sort(TailArgs A) { sort_body(A); }
 
 // test door (svc_debug_argsort_u32): the same routine on arbitrary keys
 __global__ __launch_bounds__(TB) void k_argsort_test(const uint32_t *keys, int n, uint16_t *out, uint8_t *scratch) {
@@ -2265,7 +2270,7 @@ __device__ __forceinline__ void tp_body(const TailArgs &A, int cap_clusters, uin
 #undef TP_ORDER
 #undef TP_W
 
-__global__ __launch_bounds__(TB) void k_tree_par(TailArgs A, int cap_clusters) {
+__device__ __forceinline__ void tree_par_body(const TailArgs &A, int cap_clusters) {
     const int f = A.order[blockIdx.x];
     uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
     int32_t *hdr = (int32_t *)(ws + A.L.hdr);
@@ -2278,12 +2283,14 @@ __global__ __launch_bounds__(TB) void k_tree_par(TailArgs A, int cap_clusters) {
     if (N <= TP_CAP) tp_body<false>(A, cap_clusters, ws, hdr, N, sm_tp, lds16, sh_nc, sh_nsel);
     else tp_body<true>(A, cap_clusters, ws, hdr, N, sm_tp, lds16, sh_nc, sh_nsel);
 }
+__global__ __launch_bounds__(TB) void k_tree_par(TailArgs A, int cap_clusters) { tree_par_body(A, cap_clusters); }
 
 // k_finish: zero everything outside the kept cluster, CLOSE 5x5, write the map back, centroid
-__global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
+__device__ __forceinline__ void finish_body(const TailArgs &A) {
     const int f = A.order[blockIdx.x];
     uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
     int32_t *hdr = (int32_t *)(ws + A.L.hdr);
+    if (hdr[22]) return;                                               // k_tail_back has finished this map already
     const int N = hdr[0];
     const int hw = A.h * A.w;
     uint8_t *map = A.maps + (size_t)f * hw;
@@ -2348,6 +2355,33 @@ __global__ __launch_bounds__(TB) void k_finish(TailArgs A) {
         }
         hdr[11] = (int)(wall_clock64() - t0);
     }
+}
+__global__ __launch_bounds__(TB) void k_finish(TailArgs A) { finish_body(A); }
+
+// --------------------------------------------------------------------------------------
+// The round's kernels fused at the launch level (same workgroup, same map, LDS re-carved between the stages): two
+// launches instead of six, i.e. four kernel boundaries (~4 us each on a stream) less per round.  Maps a stage cannot
+// take (more than 8 192 points, cluster tables full) are left to the stand-alone kernels launched behind.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TB) void k_tail_front(TailArgs A) {           // k_compact -> k_core -> k_prim_lvl
+    compact_body(A);
+    __syncthreads();
+    core_body(A);
+    __syncthreads();
+    prim_lvl_body(A);
+}
+
+__global__ __launch_bounds__(TB) void k_tail_back(TailArgs A, int cap_clusters) {   // k_sort -> k_tree_par -> k_finish
+    const int f = A.order[blockIdx.x];
+    int32_t *hdr = (int32_t *)(A.ws + (size_t)f * A.ws_stride + A.L.hdr);
+    sort_body(A);
+    __syncthreads();
+    tree_par_body(A, cap_clusters);
+    __syncthreads();
+    if (hdr[3] && !hdr[23]) return;                                        // hierarchy not done here: k_tree, then k_finish
+    finish_body(A);
+    __syncthreads();
+    if (threadIdx.x == 0) hdr[22] = 1;
 }
 
 // --------------------------------------------------------------------------------------
@@ -2592,6 +2626,8 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
         SVC_HIP(hipFuncSetAttribute((const void *)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_tree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_tree_par, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_tail_front, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_tail_back, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_sort, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_BYTES));
     }
     for (int r = 0; r <= maxd; ++r) {
@@ -2611,6 +2647,29 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
             k_map_resize<<<dim3(8, m), 256, 0, s>>>(full_maps, maps, rs_down, ord, full_h, full_w, height, width);
             SVC_CHECK_LAUNCH();
         }
+        int cap_cl = 0;
+        const size_t lds_tp = tp_lds_bytes(hw, params->hdbscan_min, &cap_cl);
+        const bool tree_fallback = !h->tree_par || hw > TP_CAP_BIG || hdb::max_clusters(std::min(hw, TP_CAP_BIG), params->hdbscan_min) > cap_cl;
+        if (params->clust_filt && h->tail_merge && h->prim_lvl && h->tree_par) {
+            // two fused launches per round (k_tail_front, k_tail_back) + the stand-alone kernels for what they leave
+            const size_t lds_front = std::max({(size_t)(hw + 15) / 16 * 16, lds_core, lvl_lds_bytes(height, width, h->tail_n_offsets)});
+            const size_t lds_back = std::max({(size_t)SORT_LDS_BYTES, lds_tp, lds_fin});
+            {
+                ProfScope ps(h, SVC_K_PRIM, s);
+                k_tail_front<<<m, TB, lds_front, s>>>(A);
+                SVC_CHECK_LAUNCH();
+                if (hw > 8 * TB) { k_prim_big<<<m, TB, lds_prim, s>>>(A, LVL_CAP); SVC_CHECK_LAUNCH(); }
+            }
+            ProfScope ps(h, SVC_K_FINISH, s);
+            k_tail_back<<<m, TB, lds_back, s>>>(A, cap_cl);
+            SVC_CHECK_LAUNCH();
+            if (tree_fallback) {
+                k_tree<<<m, 64, FIN_LDS_BYTES, s>>>(A);
+                SVC_CHECK_LAUNCH();
+                k_finish<<<m, TB, lds_fin, s>>>(A);
+                SVC_CHECK_LAUNCH();
+            }
+        } else {
         {
             ProfScope ps(h, SVC_K_COMPACT, s);
             k_compact<<<m, TB, (size_t)(hw + 15) / 16 * 16, s>>>(A);
@@ -2640,20 +2699,19 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
             if (params->clust_filt) {
                 k_sort<<<m, TB, SORT_LDS_BYTES, s>>>(A);
                 SVC_CHECK_LAUNCH();
-                int cap_cl = 0;
-                const size_t lds_tp = tp_lds_bytes(hw, params->hdbscan_min, &cap_cl);
                 if (h->tree_par) {
                     k_tree_par<<<m, TB, lds_tp, s>>>(A, cap_cl);
                     SVC_CHECK_LAUNCH();
                 }
                 // the serial builder: maps the parallel one does not hold in LDS (more points or clusters), or all (SVC_TREE_PAR=0)
-                if (!h->tree_par || hw > TP_CAP_BIG || hdb::max_clusters(std::min(hw, TP_CAP_BIG), params->hdbscan_min) > cap_cl) {
+                if (tree_fallback) {
                     k_tree<<<m, 64, FIN_LDS_BYTES, s>>>(A);
                     SVC_CHECK_LAUNCH();
                 }
             }
             k_finish<<<m, TB, lds_fin, s>>>(A);
             SVC_CHECK_LAUNCH();
+        }
         }
         if (factor > 1) {
             k_map_resize<<<dim3(16, m), 256, 0, s>>>(maps, full_maps, rs_up, ord, height, width, full_h, full_w);

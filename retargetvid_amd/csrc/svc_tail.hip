@@ -282,7 +282,7 @@ __device__ __forceinline__ void compact_body(const TailArgs &A) {
         hdr[2] = -1;
         hdr[3] = (A.clust_filt && total > A.mcs + 1) ? 1 : 0;
         hdr[23] = 0;                                                     // k_tree_par sets it when it has done the map's hierarchy
-        hdr[22] = 0;                                                     // k_tail_back sets it when it has finished the map (zeroing, CLOSE, centre)
+        hdr[30] = 0;                                                     // k_tail_back sets it when it has finished the map (zeroing, CLOSE, centre)
     }
 }
 __global__ __launch_bounds__(TB) void k_compact(TailArgs A) { compact_body(A); }
@@ -962,7 +962,7 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
         }
     }
     int cnt = 1, done = 0, nb = 0, parity = 0;
-    uint32_t m = 0, cur = 0;
+    uint32_t m = 0, cur = 0, swept = 0;
     bool need_rise = true;
     int n_rounds = 0, n_rises = 0;
     long long ph[5] = {0, 0, 0, 0, 0}, tp = wall_clock64();        // phase stamps (10 ns units): rise, extract, probe, accept + commit, mark
@@ -1024,6 +1024,7 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
                     if (c < NF64) for (int i = lane; i < LVL_NB / 32; i += 64) S.proc[c * (LVL_NB / 32) + i] = 0u;
                 }
                 nb = 0;
+                swept = 0;
                 __syncthreads();                                       // every wavefront is done with the old table
             }
             for (int g = wave; g < nnew; g += NW16) {
@@ -1051,12 +1052,17 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
             nb += nnew;
             done = cnt;
             const uint32_t ub0 = block_min_R();                        // (its barrier also publishes the new batches)
+            // swept: every pending block has a lower bound ABOVE it (the limit of the last sweep over all pending blocks)
+            const bool need_sweep = !(single && ub0 <= swept);
+            if (need_sweep) {
 #pragma unroll
-            for (int q = 0; q < LVL_PT; ++q)
-                if (qmask & (1u << q)) {
-                    const int c = q * NW16 + wave;
-                    R[q] = lvl_sweep_chunk<false>(S, S.btab, S.proc + c * (LVL_NB / 32), nb, single ? ub0 : min(ub0, LVL_NEAR), false, S.cbox[c], rcq[q], cjq[q], R[q]);
-                }
+                for (int q = 0; q < LVL_PT; ++q)
+                    if (qmask & (1u << q)) {
+                        const int c = q * NW16 + wave;
+                        R[q] = lvl_sweep_chunk<false>(S, S.btab, S.proc + c * (LVL_NB / 32), nb, single ? ub0 : min(ub0, LVL_NEAR), false, S.cbox[c], rcq[q], cjq[q], R[q]);
+                    }
+                swept = single ? ub0 : min(ub0, LVL_NEAR);
+            }
             if (ub0 > LVL_NEAR && !single) {
                 // a jump between blobs: the nearest pending batch of every chunk tightens the bound, then the rest
                 const uint32_t ub1 = block_min_R();
@@ -1073,8 +1079,9 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
                         const int c = q * NW16 + wave;
                         R[q] = lvl_sweep_chunk<false>(S, S.btab, S.proc + c * (LVL_NB / 32), nb, ub2, false, S.cbox[c], rcq[q], cjq[q], R[q]);
                     }
+                swept = max(swept, ub2);
             }
-            m = block_min_R();
+            m = need_sweep ? block_min_R() : ub0;                      // (no sweep: nothing changed since ub0)
 #pragma unroll
             for (int q = 0; q < LVL_PT; ++q) {
                 const int c = q * NW16 + wave;
@@ -2290,7 +2297,7 @@ __device__ __forceinline__ void finish_body(const TailArgs &A) {
     const int f = A.order[blockIdx.x];
     uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
     int32_t *hdr = (int32_t *)(ws + A.L.hdr);
-    if (hdr[22]) return;                                               // k_tail_back has finished this map already
+    if (hdr[30]) return;                                               // k_tail_back has finished this map already
     const int N = hdr[0];
     const int hw = A.h * A.w;
     uint8_t *map = A.maps + (size_t)f * hw;
@@ -2381,7 +2388,7 @@ __global__ __launch_bounds__(TB) void k_tail_back(TailArgs A, int cap_clusters) 
     if (hdr[3] && !hdr[23]) return;                                        // hierarchy not done here: k_tree, then k_finish
     finish_body(A);
     __syncthreads();
-    if (threadIdx.x == 0) hdr[22] = 1;
+    if (threadIdx.x == 0) hdr[30] = 1;
 }
 
 // --------------------------------------------------------------------------------------

@@ -54,6 +54,7 @@ def prim_levels(X, core, hw, cap=64, stats=None, nbmax=256):
     nch = (n + 63) // 64
     cbox = [(X[c * 64:c * 64 + 64, 0].min(), X[c * 64:c * 64 + 64, 0].max(), X[c * 64:c * 64 + 64, 1].min(),
              X[c * 64:c * 64 + 64, 1].max(), core[c * 64:c * 64 + 64].min()) for c in range(nch)]
+    state = {'swept': 0}    # every pending block has a lower bound above this (the limit of the last sweep over all of them)
     batches = []            # (start, len, rmin, rmax, cmin, cmax, coremin)
     processed = []          # per batch: set of chunks
     NBMAX = nbmax
@@ -77,7 +78,7 @@ def prim_levels(X, core, hw, cap=64, stats=None, nbmax=256):
                 for c in range(nch):
                     if c not in processed[b] and not intree[c * 64:c * 64 + 64].all():
                         relax_block(b, c)
-            batches.clear(); processed.clear()
+            batches.clear(); processed.clear(); state['swept'] = 0
             st['flushes'] = st.get('flushes', 0) + 1
         for s0 in new:
             t = np.array(seq[s0:min(len(seq), s0 + 64)])
@@ -102,11 +103,22 @@ def prim_levels(X, core, hw, cap=64, stats=None, nbmax=256):
                 for _, b in todo:
                     relax_block(b, c); processed[b].add(c)
 
+        single = len(new) == 1 and batches[-1][1] == 1
+        if single:                                    # one new node (the start, a jump beyond the ring table): relaxed against
+            b = len(batches) - 1                      # every chunk right away, so the bound below is tight
+            for c in range(nch):
+                if not intree[c * 64:c * 64 + 64].all():
+                    relax_block(b, c); processed[b].add(c)
         ub0 = R.min()
-        sweep(min(ub0, 64))
-        if ub0 > 64:                                  # a far jump: tighten the bound before the wide sweep
-            sweep(R.min(), nearest_only=True)
-            sweep(R.min())
+        if single:
+            if ub0 > state['swept']:                  # else: every pending block's lower bound is above ub0 already
+                sweep(ub0); state['swept'] = ub0
+        else:
+            sweep(min(ub0, 64)); state['swept'] = min(ub0, 64)
+            if ub0 > 64:                              # a far jump: tighten the bound before the wide sweep
+                sweep(R.min(), nearest_only=True)
+                ub2 = R.min()
+                sweep(ub2); state['swept'] = max(state['swept'], ub2)
         R[intree] = INF
         m = R.min()
         F[:] = R == m

@@ -227,6 +227,32 @@ __global__ __launch_bounds__(256) void k_shot_conv_lds(const ShotConv A) {
 // channels x 64 weights are fetched with whole-line loads (a wave's float4 load covers four complete 256-byte rows; the
 // direct form reads 32 rows 16 bytes at a time: 4x the L1 transactions), parked in registers while the previous slice is
 // multiplied, and written to LDS between two barriers.  NT = 2 (64-filter cells) shares the positions between two tiles.
+// operand fetch / park of k_shot_conv_lds2 as functions over register arrays passed by reference (as lambdas capturing the
+// arrays they kept part of them -- the weight registers -- in a private segment: 48 / 80 bytes of scratch per thread)
+template <int NT>
+__device__ __forceinline__ void shot_fetch(const ShotConv &A, int it, int nsl, int C, int d, int c4, int row0, const float *wbase,
+                                           const int (&pxy)[8], const int (&pfr)[8], float4 (&areg)[8], float4 (&breg)[2 * NT]) {
+    const int tap = it / nsl, sl = it - tap * nsl;
+    const int kt = tap / 9, kh = (tap - 9 * kt) / 3, kw = tap - 9 * kt - 3 * kh;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int x = (pxy[j] & 255) + kw - 1, y = ((pxy[j] >> 8) & 255) + kh - 1, t = (pxy[j] >> 16) + (kt - 1) * d;
+        const bool ok = (unsigned)t < (unsigned)A.T && (unsigned)y < (unsigned)A.H && (unsigned)x < (unsigned)A.W;
+        const size_t pos = ok ? ((size_t)(pfr[j] + (kt - 1) * d) * A.H + y) * A.W + x : 0;
+        const float4 v = *(const float4 *)(A.X + pos * C + sl * 64 + c4 * 4);
+        areg[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);          // SAME padding
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * NT; ++j) {
+        // (element-wise: a plain float4 copy from memory into the array is turned into a memcpy, which keeps the array
+        // in a private segment)
+        const float *wp = wbase + (size_t)(row0 + 16 * j) * A.kpad + tap * C + sl * 64 + c4 * 4;
+        typedef float shot_f4 __attribute__((ext_vector_type(4)));
+        const shot_f4 v = *(const shot_f4 *)wp;
+        breg[j] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void k_shot_conv_lds2(const ShotConv A) {
     extern __shared__ float sm_shot2[];                      // As [128][68] | Bs [NT * 32][68]
@@ -249,21 +275,7 @@ __global__ __launch_bounds__(256) void k_shot_conv_lds2(const ShotConv A) {
     }
     const float *wbase = A.Wt + ((size_t)br * A.Fpad + ng * 32 * NT) * A.kpad;
     float4 areg[8], breg[2 * NT];
-    auto fetch = [&](int it) {
-        const int tap = it / nsl, sl = it - tap * nsl;
-        const int kt = tap / 9, kh = (tap - 9 * kt) / 3, kw = tap - 9 * kt - 3 * kh;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int x = (pxy[j] & 255) + kw - 1, y = ((pxy[j] >> 8) & 255) + kh - 1, t = (pxy[j] >> 16) + (kt - 1) * d;
-            const bool ok = (unsigned)t < (unsigned)A.T && (unsigned)y < (unsigned)A.H && (unsigned)x < (unsigned)A.W;
-            const size_t pos = ok ? ((size_t)(pfr[j] + (kt - 1) * d) * A.H + y) * A.W + x : 0;
-            const float4 v = *(const float4 *)(A.X + pos * C + sl * 64 + c4 * 4);
-            areg[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);          // SAME padding
-        }
-#pragma unroll
-        for (int j = 0; j < 2 * NT; ++j)
-            breg[j] = *(const float4 *)(wbase + (size_t)(row0 + 16 * j) * A.kpad + tap * C + sl * 64 + c4 * 4);
-    };
+#define SHOT_FETCH(it_) shot_fetch<NT>(A, it_, nsl, C, d, c4, row0, wbase, pxy, pfr, areg, breg)
     auto park = [&]() {
 #pragma unroll
         for (int j = 0; j < 8; ++j) *(float4 *)(As + (row0 + 16 * j) * WS + c4 * 4) = areg[j];
@@ -276,12 +288,12 @@ __global__ __launch_bounds__(256) void k_shot_conv_lds2(const ShotConv A) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
     const int niter = 27 * nsl;
-    fetch(0);
+    SHOT_FETCH(0);
     for (int it = 0; it < niter; ++it) {
         __syncthreads();                                     // the previous slice's readers are done
         park();
         __syncthreads();
-        if (it + 1 < niter) fetch(it + 1);                   // in flight during this slice's MFMAs
+        if (it + 1 < niter) SHOT_FETCH(it + 1);              // in flight during this slice's MFMAs
         const float *ap = As + (wave * 32 + r) * WS + 4 * hh;
 #pragma unroll
         for (int st = 0; st < 8; ++st) {

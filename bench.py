@@ -458,7 +458,9 @@ def main():
                             compact_ms=tail_classes['compact'],
                             points_per_map=dict(min=int(npts.min()), mean=round(float(npts.mean()), 1), max=int(npts.max())),
                             us_per_frame=round(sum(tail_classes.values()) / B * 1e3, 2),
-                            note='class ms per un-pipelined step of %d maps (three tail rounds: the batch starts a shot); '
+                            note='class ms per un-pipelined step of %d maps (three tail rounds: the batch starts a shot).  Default: a '
+                                 'round is two fused launches -- prim = k_tail_front (compact + core + Prim), finish = k_tail_back '
+                                 '(sort + hierarchy + finish), compact / core then read 0; SVC_TAIL_MERGE=0: one launch per stage, '
                                  'finish = k_sort + k_tree_par + k_finish' % B)
         out = dict(metric='frames/sec end-to-end saliency+crop on 640x360', value=round(value, 2), unit='frames/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / max(args.steps, 1) * 1e3, 4),

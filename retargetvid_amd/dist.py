@@ -140,7 +140,8 @@ def crop_job(make_video, frame_counts, names, CP, ratios, out_dir=None, workers=
         res_all = crop_fn([make_video(i) for i in mine], CP, ratios, workers) if mine else []
         for i, res in zip(mine, res_all):
             for r in ratios:
-                b = np.asarray(res[r][0]['bbs'], np.int32).reshape(-1, 4)
+                vd = res[r][0]
+                b = np.asarray(vd['bbs_np'] if 'bbs_np' in vd else vd['bbs'], np.int32).reshape(-1, 4)
                 if b.shape[0] != frame_counts[i]:
                     raise ValueError('video %s: %d boxes for %d frames' % (names[i], b.shape[0], frame_counts[i]))
                 local[r][i] = b

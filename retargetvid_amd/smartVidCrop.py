@@ -171,8 +171,12 @@ def sc_compute_bb(vid_data, crop_params, verbose=False):
     m = y2 > fh - bb
     y2[m] = fh - bb
     y1[m] = y2[m] - fbb_h
-    out = np.stack([x1, y1, x2, y2], axis=1).tolist()
-    vid_data['bbs'] = out
+    boxes = np.stack([x1, y1, x2, y2], axis=1)
+    vid_data['bbs_np'] = boxes                         # int64 [fc, 4]: what the multi-video job gathers (dist.crop_job)
+    if isinstance(vid_data, _LazySmaps):
+        vid_data.pop('bbs', None)                      # the list-of-lists form (the reference's VD['bbs']) is made on first access
+    else:
+        vid_data['bbs'] = boxes.tolist()
     return vid_data
 
 
@@ -475,12 +479,16 @@ def blend_flags(fc_sel, segmentation_sel):
 
 class _LazySmaps(dict):
     """VD dict whose 'smaps' ([H,W,n] u8, the reference's layout) is materialised from the device
-    only when somebody asks for it."""
+    only when somebody asks for it, and whose 'bbs' list is made from the array 'bbs_np' on first access (0.4 ms of
+    Python per video and ratio that the multi-video job never needs)."""
 
     def __missing__(self, key):
         if key == 'smaps' and 'smaps_dev' in self:
             self['smaps'] = np.ascontiguousarray(self['smaps_dev'].permute(1, 2, 0).cpu().numpy())
             return self['smaps']
+        if key == 'bbs' and 'bbs_np' in self:          # one [x1,y1,x2,y2] list per frame, as the reference returns them
+            self['bbs'] = self['bbs_np'].tolist()
+            return self['bbs']
         raise KeyError(key)
 
 
@@ -580,6 +588,7 @@ def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn=''
     t = time.perf_counter()
     if CP['shift_time'] > 0:
         temporal.shift_time(VD['bbs'], CP['shift_time'])
+        VD['bbs_np'] = np.asarray(VD['bbs'], np.int64)
     sc_register_time(t, '_shift')
     if callback_status is not None and callback_session is not None:
         callback_status(callback_session, 'sc', 'SC RENDERING', 'smart-cropping rendering')
@@ -628,6 +637,7 @@ def smart_vid_crop_ratios(video_path, CP, ratios, engine=None, verbose=False, st
             VD = sc_compute_bb(VD, cp)
             if cp['shift_time'] > 0:
                 temporal.shift_time(VD['bbs'], cp['shift_time'])
+                VD['bbs_np'] = np.asarray(VD['bbs'], np.int64)
             res['params'] = ''.join(' %-18s : %s\n' % (k, str(v)) for k, v in cp.items())
             res['info'] = ' (%dx%d)->(%dx%d)->(%dx%d)->(%dx%d)\n' % (
                 VD['h_orig'], VD['w_orig'], VD['h_process'], VD['w_process'], VD['h_final'], VD['w_final'],

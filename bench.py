@@ -64,7 +64,7 @@ def parse_args(argv=None):
     ap.add_argument('--pipeline', type=int, default=4, help='batches in flight per GPU (engines / HIP streams)')
     ap.add_argument('--cpu-sample', type=int, default=160, help='frames of the CPU baseline sample (0 = skip)')
     ap.add_argument('--iso-steps', type=int, default=3, help='un-pipelined profiling steps per kernel class')
-    ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps each; the median is reported')
+    ap.add_argument('--repeats', type=int, default=15, help='timed regions of --steps steps each; the median is reported')
     return ap.parse_args(argv)
 
 

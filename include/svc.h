@@ -57,6 +57,9 @@ typedef struct SvcParams {
     int32_t resize_factor;        /* CP['resize_factor'] (integer, 1 = off): cluster on the map shrunk by this
                                      factor (INTER_LINEAR down, then up again) and take the centre of the
                                      INTER_NEAREST-shrunk map, smartVidCrop.py:1078-1084, :1158, :1184 */
+    int32_t com_km;               /* CP['com_km']: 1 = centre of mass (single-cluster K-means = centroid of the non-zero
+                                     pixels), 0 = position of the first maximum of the final map in raster order
+                                     (sc_find_center_of_mass with km=False, smartVidCrop.py:1165-1178) */
 } SvcParams;
 
 /* Per-call diagnostics written by svc_cluster_center when `stats` is non-NULL:
@@ -67,7 +70,7 @@ const char *svc_last_error(void);
 
 /* ABI revision of the loaded library (bumped whenever a struct layout or a signature changes); a binding
  * checks it once after dlopen.  2 = SvcParams starts with struct_size and carries resize_factor.
- * 3 = SVC_MAP_HELD is honoured by svc_cluster_center (a v2 library ignores the bit), svc_debug_cluster_state
+ * 3 = SvcParams ends with com_km; SVC_MAP_HELD is honoured by svc_cluster_center (a v2 library ignores the bit), svc_debug_cluster_state
  *     returns 32 header words, svc_debug_round_plan / svc_debug_argsort_u32 / svc_transnet_* exist. */
 #define SVC_ABI_VERSION 3
 int svc_abi_version(void);

@@ -107,11 +107,21 @@ def center_of_mass(sal_map, factor=1.0):
     return float(np.mean(cols.astype(np.float64))) * factor, float(np.mean(rows.astype(np.float64))) * factor
 
 
+def center_argmax(sal_map):
+    """sc_find_center_of_mass with km=False (smartVidCrop.py:1165-1178): the position of the first maximum in raster
+    order, on the map as it is (no resize, no factor)."""
+    y, x = np.unravel_index(int(np.argmax(sal_map)), sal_map.shape)
+    return int(x), int(y)
+
+
 def centers(smaps_hwn, CP):
     dx, dy = [], []
     for i in range(smaps_hwn.shape[2]):
         if np.sum(smaps_hwn[:, :, i]) > 0:
-            x, y = center_of_mass(smaps_hwn[:, :, i], CP['resize_factor'])
+            if not CP.get('com_km', True):
+                x, y = center_argmax(smaps_hwn[:, :, i])
+            else:
+                x, y = center_of_mass(smaps_hwn[:, :, i], CP['resize_factor'])
         else:
             x, y = None, None
         dx.append(x)

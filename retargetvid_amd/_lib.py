@@ -20,7 +20,7 @@ EXPORTS = ('svc_last_error', 'svc_abi_version', 'svc_create', 'svc_destroy', 'sv
 class SvcParams(ctypes.Structure):
     _fields_ = [('struct_size', ctypes.c_uint32), ('hdbscan_min', ctypes.c_int32), ('hdbscan_min_samples', ctypes.c_int32),
                 ('select_sum', ctypes.c_int32), ('op_close', ctypes.c_int32), ('clust_filt', ctypes.c_int32),
-                ('resize_factor', ctypes.c_int32)]
+                ('resize_factor', ctypes.c_int32), ('com_km', ctypes.c_int32)]
 
 
 def make_params(CP):
@@ -29,7 +29,8 @@ def make_params(CP):
     if float(factor) != int(factor) or (int(factor) != 1 and CP.get('resize_type', 1) != 1):
         raise NotImplementedError('resize_factor must be an integer and resize_type 1 (bilinear)')
     return SvcParams(ctypes.sizeof(SvcParams), int(CP['hdbscan_min']), int(CP['hdbscan_min_samples'] or 0),
-                     int(CP['select_sum']), int(bool(CP['op_close'])), int(bool(CP['clust_filt'])), int(factor))
+                     int(CP['select_sum']), int(bool(CP['op_close'])), int(bool(CP['clust_filt'])), int(factor),
+                     int(bool(CP.get('com_km', True))))
 
 
 class SvcError(RuntimeError):

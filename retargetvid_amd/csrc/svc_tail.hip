@@ -236,6 +236,31 @@ __global__ __launch_bounds__(256) void k_centre_nearest(const uint8_t *__restric
     }
 }
 
+// com_km = 0 (sc_find_center_of_mass with km=False, smartVidCrop.py:1165-1178): the position of the first maximum of the
+// final map in raster order; NaN for an all-zero map.  key = value << 16 | (65535 - index): its maximum is that pixel.
+__global__ __launch_bounds__(256) void k_centre_argmax(const uint8_t *__restrict__ maps, int h, int w, FDiv dW, double *__restrict__ xy) {
+    const int f = blockIdx.x, hw = h * w;
+    const uint8_t *m = maps + (size_t)f * hw;
+    __shared__ uint32_t red[4];
+    uint32_t best = 0;
+    for (int i = threadIdx.x; i < hw; i += 256) best = max(best, ((uint32_t)m[i] << 16) | (uint32_t)(65535 - i));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        best = max(max(red[0], red[1]), max(red[2], red[3]));
+        if (best >> 16) {
+            uint32_t c;
+            const uint32_t r = fdivmod(65535u - (best & 0xFFFFu), dW, c);
+            xy[2 * f] = (double)c;
+            xy[2 * f + 1] = (double)r;
+        } else {
+            xy[2 * f] = xy[2 * f + 1] = __longlong_as_double(0x7FF8000000000000LL);
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------------
 // k_compact: non-zero pixels in raster order
 // --------------------------------------------------------------------------------------
@@ -2725,7 +2750,10 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
             SVC_CHECK_LAUNCH();
         }
     }
-    if (params->resize_factor > 1) {       // centre of the nearest-neighbour shrunk final map (also when clust_filt is off)
+    if (!params->com_km) {                 // centre = arg-max pixel of the final full-size map (held maps keep what the caller has)
+        k_centre_argmax<<<n, 256, 0, s>>>(full_maps, full_h, full_w, make_fdiv(full_w), xy);
+        SVC_CHECK_LAUNCH();
+    } else if (params->resize_factor > 1) {       // centre of the nearest-neighbour shrunk final map (also when clust_filt is off)
         const int f2 = params->resize_factor;
         k_centre_nearest<<<n, 256, 0, s>>>(full_maps, full_h, full_w, (int)lrint((double)full_h * (1.0 / f2)),
                                            (int)lrint((double)full_w * (1.0 / f2)), f2, xy);

@@ -506,9 +506,6 @@ def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn=''
     if CP['exit_on_spread_sal'] or CP['exit_on_low_cvrg'] or CP['t_border'] != -1:
         raise NotImplementedError('mean-saliency / coverage gates and border detection are disabled in both '
                                   'published parameter sets and are not part of this path')
-    if not CP['com_km']:
-        raise NotImplementedError('com_km=False (centre = arg-max pixel, smartVidCrop.py:1165-1178) is not part of '
-                                  'either published parameter set and is not implemented')
     if save_vid and (final_vid_fn or demo_fn):
         raise NotImplementedError('video rendering is outside the saliency-to-crop path; pass save_vid=False')
     engine = engine or get_engine()

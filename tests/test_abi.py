@@ -26,9 +26,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layout_matches_header():
-    assert ctypes.sizeof(_lib.SvcParams) == 28
+    assert ctypes.sizeof(_lib.SvcParams) == 32
     assert [f[0] for f in _lib.SvcParams._fields_] == ['struct_size', 'hdbscan_min', 'hdbscan_min_samples', 'select_sum', 'op_close',
-                                                       'clust_filt', 'resize_factor']
+                                                       'clust_filt', 'resize_factor', 'com_km']
 
 
 def test_abi_version_matches_header():

@@ -73,7 +73,10 @@ def test_stale_binding_is_rejected_not_over_read(engine):
     m = torch.zeros((1, 140, 250), dtype=torch.uint8, device='cuda')
     xy = torch.empty((1, 2), dtype=torch.float64, device='cuda')
     vp = ctypes.c_void_p
-    for old in (Old5(26, 0, 2, 1, 1), Old6(26, 0, 2, 1, 1, 1)):
+    class V2(ctypes.Structure):                      # ABI 2: struct_size = 28 and no com_km
+        _fields_ = [('struct_size', ctypes.c_uint32)] + Old6._fields_
+
+    for old in (Old5(26, 0, 2, 1, 1), Old6(26, 0, 2, 1, 1, 1), V2(28, 26, 0, 2, 1, 1, 1)):
         fn = lib.svc_cluster_center
         saved = fn.argtypes
         fn.argtypes = saved[:6] + [vp] + saved[7:]

@@ -74,8 +74,6 @@ def test_pickle_door_and_error_conventions(engine, tmp_path):
         S.smart_vid_crop(dict(video, trans_inds=[0]), CP, save_vid=False, engine=engine)   # no scenes
     with pytest.raises(NotImplementedError):
         S.smart_vid_crop('clip.mp4', CP, save_vid=False, engine=engine)
-    with pytest.raises(NotImplementedError):
-        S.smart_vid_crop(video, dict(CP, com_km=False), save_vid=False, engine=engine)
 
 
 def test_best_settings_match_oracle(engine, synthetic_sd):
@@ -273,3 +271,18 @@ def test_streaming_tail_inside_the_ingest_gives_the_same_windows(engine):
             VD1, _ = S.smart_vid_crop(video, CP, save_vid=False, engine=engine, stream_batch=sb)
             assert torch.equal(VD0['smaps_dev'], VD1['smaps_dev'])
             assert VD0['dx'] == VD1['dx'] and VD0['dy'] == VD1['dy'] and VD0['bbs'] == VD1['bbs']
+
+
+def test_com_km_false_takes_the_argmax_pixel(engine, synthetic_sd):
+    """CP['com_km'] = False (sc_find_center_of_mass with km=False, smartVidCrop.py:1165-1178): the centre is the position
+    of the first maximum of the filtered map in raster order -- against the oracle pipeline, both parameter sets (the
+    best-settings set clusters on shrunk maps but takes the arg-max on the full-size map)."""
+    torch.set_num_threads(8)
+    video = _video(60, 15, [0, 25, 60])
+    for best in (False, True):
+        CP = dict(S.sc_init_crop_params(use_best_settings=best), com_km=False, out_ratio='1:3')
+        VD, _ = S.smart_vid_crop(video, CP, save_vid=False, engine=engine)
+        ref = P.smart_vid_crop(video, dict(P.init_crop_params(best), com_km=False, out_ratio='1:3'), synthetic_sd)
+        assert VD['true_inds'] == ref['true_inds']
+        assert all(float(a).is_integer() and float(b).is_integer() for a, b in zip(VD['dxnf'], VD['dynf']))
+        assert np.abs(np.array(VD['bbs']) - np.array(ref['bbs'])).max() <= 1

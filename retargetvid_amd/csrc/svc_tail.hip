@@ -803,24 +803,36 @@ __device__ __forceinline__ void lvl_walk(const LvlLds &S, int wave, int nk, uint
         const int kk = LVL_WORKERS * (ib + lane) + wave;
         const uint2 mine = S.ring[kk < nk ? kk : 0];
         const int n64 = min(64, nit - ib);
-#pragma unroll 2
-        for (int it = 0; it < n64; ++it) {
-            const uint32_t d2 = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, it);
-            const uint32_t delta = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, it);
-            const uint32_t cell = cell0 + delta;
-            const OccW ow = S.occ[cell >> 5];
-            const bool in = on && ((ow.bits >> (cell & 31u)) & 1u);
-            const uint32_t j = in ? ow.base + (uint32_t)__popc(ow.bits & ((1u << (cell & 31u)) - 1u)) : 0u;
-            const uint32_t cj = S.corei[j];
-            const uint32_t mr = max(max(d2, cj), ci);
-            if (MARK) {
-                if (in && mr == level) atomicOr(&S.F[j >> 5], 1u << (j & 31u));
-            } else {
-                const uint32_t fw = S.F[j >> 5];
-                if (in && mr < level) dmin = min(dmin, mr);
-                if (in && mr == level && !((fw >> (j & 31u)) & 1u)) {
-                    nmin = min(nmin, j);
-                    if (ib + it < 32) entmask |= 1u << (ib + it);
+        // four ring cells at a time: their occupancy reads go out together, then the core / F reads of the points found
+        for (int it0 = 0; it0 < n64; it0 += 4) {
+            uint32_t d2[4], cell[4], j[4], cj[4], fw[4];
+            OccW ow[4];
+            bool in[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = min(it0 + u, n64 - 1);
+                d2[u] = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, it);
+                cell[u] = (it0 + u < n64) ? cell0 + (uint32_t)__builtin_amdgcn_readlane((int)mine.y, it) : 0u;
+                ow[u] = S.occ[cell[u] >> 5];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                in[u] = on && (it0 + u < n64) && ((ow[u].bits >> (cell[u] & 31u)) & 1u);
+                j[u] = in[u] ? ow[u].base + (uint32_t)__popc(ow[u].bits & ((1u << (cell[u] & 31u)) - 1u)) : 0u;
+                cj[u] = S.corei[j[u]];
+                if (!MARK) fw[u] = S.F[j[u] >> 5];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t mr = max(max(d2[u], cj[u]), ci);
+                if (MARK) {
+                    if (in[u] && mr == level) atomicOr(&S.F[j[u] >> 5], 1u << (j[u] & 31u));
+                } else {
+                    if (in[u] && mr < level) dmin = min(dmin, mr);
+                    if (in[u] && mr == level && !((fw[u] >> (j[u] & 31u)) & 1u)) {
+                        nmin = min(nmin, j[u]);
+                        if (ib + it0 + u < 32) entmask |= 1u << (ib + it0 + u);
+                    }
                 }
             }
         }

@@ -493,3 +493,77 @@ def test_network_every_layer_every_frame_three_geometries(ck, golden_dir):
                     assert du.max() <= 1 and (du > 0).mean() < u8_frac, (ck, gname, i)
     finally:
         eng.close()
+
+
+def _fuzz_maps(rng, n, h, w):
+    """Random thresholded maps of many kinds: blobs of different sizes and counts, rings, stripes, noise at several
+    densities, outliers, value plateaus and gradients."""
+    ys, xs = np.mgrid[0:h, 0:w]
+    out = np.zeros((n, h, w), np.uint8)
+    for i in range(n):
+        kind = i % 6
+        m = np.zeros((h, w), np.float32)
+        if kind in (0, 1, 2):
+            for _ in range(rng.randint(1, 5)):
+                cy, cx = rng.uniform(0, h), rng.uniform(0, w)
+                ry, rx = rng.uniform(2, h / (3 if kind else 6)), rng.uniform(2, w / (4 if kind else 8))
+                d = ((ys - cy) / ry) ** 2 + ((xs - cx) / rx) ** 2
+                m = np.maximum(m, 255 * np.exp(-d * rng.uniform(0.5, 2.0)))
+        elif kind == 3:
+            cy, cx, r0 = rng.uniform(h * 0.3, h * 0.7), rng.uniform(w * 0.3, w * 0.7), rng.uniform(5, min(h, w) * 0.4)
+            d = np.sqrt((ys - cy) ** 2 + (xs - cx) ** 2)
+            m = 255 * np.exp(-((d - r0) / rng.uniform(1.0, 4.0)) ** 2)                       # a ring
+        elif kind == 4:
+            m = 255 * (np.sin(xs / rng.uniform(2, 9) + ys / rng.uniform(3, 15)) > rng.uniform(0.2, 0.95))   # stripes
+        else:
+            m = 255 * (rng.rand(h, w) < rng.choice([0.003, 0.02, 0.08, 0.3]))               # noise
+        m = m + rng.uniform(0, 40) * rng.rand(h, w)
+        m[rng.rand(h, w) < rng.choice([0.0, 0.001, 0.01])] = 255                              # outliers
+        u = np.clip(m, 0, 255).astype(np.uint8)
+        u[u < 120] = 0
+        out[i] = u
+    return out
+
+
+def test_new_tail_kernels_equal_the_round2_kernels_on_random_maps():
+    """k_prim_lvl + k_tree_par (round 3) against the one-node-per-step Prim and the serial union-find hierarchy of round 2
+    (SVC_PRIM_LVL=0, SVC_TREE_PAR=0; both verified against the oracle by the tests above) on 264 random maps of three
+    sizes and both parameter sets: Prim edge lists, labels, filtered maps and centres must be identical.  A wide net for
+    the rare paths (drops, rises, jumps, full batch tables, maps above 4 352 points) that costs seconds on the device."""
+    import os
+    saved = {k: os.environ.get(k) for k in ('SVC_PRIM_LVL', 'SVC_TREE_PAR', 'SVC_TAIL_MERGE')}
+    try:
+        os.environ.update(SVC_PRIM_LVL='0', SVC_TREE_PAR='0', SVC_TAIL_MERGE='0')
+        old = ops.Engine(seed=0)
+        for k in saved:
+            os.environ.pop(k, None)
+        new = ops.Engine(seed=0)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        rng = np.random.RandomState(31)
+        n_maps = 0
+        for (h, w, n) in ((140, 250, 48), (35, 62, 60), (187, 250, 24)):
+            maps = _fuzz_maps(rng, n, h, w)
+            flags = (rng.rand(n) < 0.2).astype(np.uint8)
+            flags[-1] = 0
+            for CP in (P.init_crop_params(), dict(P.init_crop_params(), hdbscan_min=5, hdbscan_min_samples=3, select_sum=1)):
+                a, b = torch.from_numpy(maps).cuda(), torch.from_numpy(maps).cuda()
+                xa, sa = old.cluster_center_(a, flags, CP, want_stats=True)
+                xb, sb = new.cluster_center_(b, flags, CP, want_stats=True)
+                assert torch.equal(a, b), (h, w)
+                assert torch.equal(sa, sb)
+                assert np.array_equal(xa.cpu().numpy(), xb.cpu().numpy(), equal_nan=True)
+                for i in range(0, n, 5):                                   # intermediate state of every fifth map
+                    s_old, s_new = old.cluster_state(i, h * w), new.cluster_state(i, h * w)
+                    assert np.array_equal(s_old['mst'], s_new['mst']), 'Prim sequence of map %d (%dx%d, N = %d)' % (i, h, w, s_old['n'])
+                    assert np.array_equal(s_old['labels'], s_new['labels']), 'labels of map %d' % i
+                n_maps += n
+        assert n_maps == 264
+    finally:
+        old.close()
+        new.close()

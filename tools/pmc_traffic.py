@@ -24,7 +24,7 @@ import json
 CLASS = [('k_dwpw', 'pw'), ('k_pw', 'pw'), ('k_irb', 'pw'), ('k_dw', 'dw'), ('k_front', 'stem'), ('k_stem', 'stem'), ('k_lanczos', 'lanczos'),
          ('k_cv_resize', 'resize'), ('k_smooth', 'smooth'), ('k_quant', 'smooth'),
          ('k_subsample', 'resample'), ('k_upsample', 'resample'), ('k_gauss', 'resample'), ('k_adapt', 'resample'),
-         ('k_prim_lvl', 'prim'), ('k_prim_pt', 'prim'), ('k_prim_big', 'prim'), ('k_prim', 'prim'), ('k_tree_par', 'finish'), ('k_sort', 'finish'), ('k_tree', 'finish'), ('k_finish', 'finish'), ('k_core', 'core'),
+         ('k_tail_front', 'prim'), ('k_tail_back', 'finish'), ('k_centre_argmax', 'tail_misc'), ('k_prim_lvl', 'prim'), ('k_prim_pt', 'prim'), ('k_prim_big', 'prim'), ('k_prim', 'prim'), ('k_tree_par', 'finish'), ('k_sort', 'finish'), ('k_tree', 'finish'), ('k_finish', 'finish'), ('k_core', 'core'),
          ('k_compact', 'compact'), ('k_threshold', 'threshold'),
          ('k_blend', 'tail_misc'), ('k_map_resize', 'tail_misc'), ('k_centre', 'tail_misc'), ('k_iou', 'tail_misc')]
 # classes whose global loads are 16 B per lane (float4): the gfx950 FETCH_SIZE correction (x2) applies

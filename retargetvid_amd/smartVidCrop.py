@@ -23,6 +23,7 @@ with fr, frame_count, w, h, frames [RGB uint8], trans_inds) or that dict itself.
 Failures raise exceptions; nothing blocks on input() (the reference does at :544-545).
 """
 import math
+import os
 import pickle
 import threading
 import time
@@ -523,7 +524,31 @@ def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn=''
                                   'package: pass the ingest_pickle dict (fr, frame_count, w, h, frames, '
                                   'trans_inds), a .pkl holding it, or install a reader with set_video_reader() '
                                   '(retargetvid_amd/ingest.py)')
-    VD = _LazySmaps(ingest_frames(video, CP, engine, verbose=verbose, shot_net=shot_net, stream_batch=stream_batch))
+    # the reference's feature cache (smartVidCrop.py:2244-2256, :2276-2280): with temp_path, the analysis of a NAMED video
+    # (a file path, or a dict with a 'name') -- selection, segmentation and the raw saliency maps -- is pickled to
+    # <temp_path>/<name>.pkl after the ingest and read back instead of it the next time (another target ratio, other
+    # tail parameters).  The reference builds the file name from an undefined local (it works only through a global of its
+    # __main__); here it is the video's own name.  Not combined with stream_batch (that ingest also runs the tail).
+    cache_fn = None
+    if temp_path is not None and not stream_batch:
+        name = video.get('name') if isinstance(video, dict) else None
+        if name is None and isinstance(video_path, str):
+            name = os.path.splitext(os.path.basename(video_path))[0]
+        if name:
+            cache_fn = os.path.join(temp_path, str(name) + '.pkl')
+    if cache_fn is not None and os.path.isfile(cache_fn):
+        with open(cache_fn, 'rb') as fp:
+            cached = pickle.load(fp)
+        VD = _LazySmaps({k: v for k, v in cached.items() if k != 'smaps_nhw'})
+        VD['smaps_dev'] = torch.from_numpy(cached['smaps_nhw']).to(engine.device)
+    else:
+        VD = _LazySmaps(ingest_frames(video, CP, engine, verbose=verbose, shot_net=shot_net, stream_batch=stream_batch))
+        if cache_fn is not None:
+            os.makedirs(temp_path, exist_ok=True)
+            out = {k: v for k, v in VD.items() if k not in ('smaps_dev', 'smaps')}
+            out['smaps_nhw'] = VD['smaps_dev'].cpu().numpy()
+            with open(cache_fn, 'wb') as fp:
+                pickle.dump(out, fp)
     if callback_status is not None and callback_session is not None:
         callback_status(callback_session, 'sc', 'SC PROCESSING', 'smart-cropping main process')
     VD['segm_backup'] = VD['segmentation'].copy()

@@ -286,3 +286,20 @@ def test_com_km_false_takes_the_argmax_pixel(engine, synthetic_sd):
         assert VD['true_inds'] == ref['true_inds']
         assert all(float(a).is_integer() and float(b).is_integer() for a, b in zip(VD['dxnf'], VD['dynf']))
         assert np.abs(np.array(VD['bbs']) - np.array(ref['bbs'])).max() <= 1
+
+
+def test_feature_cache_in_temp_path(engine, tmp_path):
+    """temp_path (smartVidCrop.py:2244-2256, :2276-2280): the ingest's result is pickled per named video and read back on the
+    next call -- other target ratio, same windows as a fresh run; the cached call does not touch the frames."""
+    video = dict(_video(60, 22, [0, 31, 60]), name='clip22')
+    CP = S.sc_init_crop_params()
+    CP['out_ratio'] = '1:3'
+    fresh13, _ = S.smart_vid_crop(video, CP, save_vid=False, engine=engine)
+    a, _ = S.smart_vid_crop(video, CP, save_vid=False, engine=engine, temp_path=str(tmp_path))
+    assert os.path.isfile(os.path.join(str(tmp_path), 'clip22.pkl')) and a['bbs'] == fresh13['bbs']
+    CP31 = dict(CP, out_ratio='3:1')
+    fresh31, _ = S.smart_vid_crop(video, CP31, save_vid=False, engine=engine)
+    no_frames = dict(video, frames=None)                       # the cached analysis is enough
+    b, _ = S.smart_vid_crop(no_frames, CP31, save_vid=False, engine=engine, temp_path=str(tmp_path))
+    assert b['bbs'] == fresh31['bbs'] and b['true_inds'] == fresh31['true_inds']
+    assert np.array_equal(b['smaps'], fresh31['smaps'])

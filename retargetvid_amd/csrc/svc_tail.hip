@@ -11,10 +11,13 @@
 //   k_threshold   sc_threshold                      smartVidCrop.py:1050-1059
 //   k_blend       cut-adjacent blend, u8 wrap        smartVidCrop.py:2369-2373
 //   k_compact     coo_matrix gather, raster order    smartVidCrop.py:1089-1091
-//   k_core        HDBSCAN core distances  \
-//   k_prim        Prim on mutual reachability } hdbscan generic path, call site smartVidCrop.py:1099
-//   k_finish      sort, hierarchy, EOM, labels /    + cluster weights / first arg-max / zeroing
-//                 (smartVidCrop.py:1107-1122), CLOSE 5x5 (:1126-1128), centroid (:1163-1219)
+//   k_core        HDBSCAN core distances                 \
+//   k_prim_lvl    Prim on mutual reachability (rounds)   |  hdbscan generic path, call site smartVidCrop.py:1099
+//   k_sort        numpy's argsort order of the edges      |  (k_prim_pt / k_prim_big, k_tree: the one-node-per-step Prim and the
+//   k_tree_par    hierarchy, EOM, labels                 /   serial union-find builder, for maps the parallel kernels do not take)
+//   k_finish      cluster weights / first arg-max / zeroing (smartVidCrop.py:1107-1122), CLOSE 5x5 (:1126-1128),
+//                 centroid (:1163-1219); k_centre_argmax: com_km = False (:1165-1178)
+//   k_tail_front / k_tail_back  the stages of a round fused into two launches
 //   k_iou         bb_intersection_over_union         smartVidCrop.py:927-944
 #include <math.h>
 
@@ -1298,61 +1301,12 @@ __device__ __forceinline__ void close_pass(const uint8_t *__restrict__ src, uint
 }
 
 // --------------------------------------------------------------------------------------
-// k_finish: stable LSD radix sort of the MST edges by weight, hierarchy + EOM
-// (hdb_tree.h, one lane; its arrays live in LDS when N <= TREE_LDS_CAP), labels, cluster
-// weights, zeroing, CLOSE 5x5, centroid.
+// k_tree (the serial builder, kept for maps k_tree_par does not take): hierarchy + EOM (hdb_tree.h on one wavefront; its
+// arrays live in LDS when N <= TREE_LDS_CAP), labels, cluster weights.  k_finish: zeroing, CLOSE 5x5, centroid.
 // --------------------------------------------------------------------------------------
 #define TREE_LDS_CAP 4352      // points: 28 B/point of hierarchy state in LDS
 #define TREE_LDS_CLUSTERS 512  // condensed clusters kept in LDS (57 B each)
 #define FIN_LDS_BYTES (TREE_LDS_CAP * 28 + TREE_LDS_CLUSTERS * 60)
-
-// one stable 6-bit counting pass over n edges: src -> dst
-__device__ void radix_pass(const hdb::Edge *__restrict__ src, hdb::Edge *__restrict__ dst, int n, int shift,
-                           int *hist /*64*/, int *run /*64*/, uint16_t *wcnt /*[NW16][64]*/) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 64) hist[tid] = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += TB) atomicAdd(&hist[(src[i].w >> shift) & 63], 1);
-    __syncthreads();
-    if (tid < 64) {                                  // exclusive scan of the 64 bins by wave 0
-        int v = hist[tid], inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-        run[tid] = inc - v;
-    }
-    __syncthreads();
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int base = 0; base < n; base += TB) {
-        const int i = base + tid;
-        const bool valid = i < n;
-        hdb::Edge e = valid ? src[i] : hdb::Edge{0, 0, 0};
-        const int d = valid ? (int)((e.w >> shift) & 63) : 64;
-        unsigned long long mask = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            const unsigned long long bal = __ballot((d >> b) & 1);
-            mask &= ((d >> b) & 1) ? bal : ~bal;
-        }
-        const int rank = __popcll(mask & lt), cnt = __popcll(mask);
-        wcnt[wave * 64 + lane] = 0;
-        __syncthreads();
-        if (valid && rank == 0) wcnt[wave * 64 + d] = (uint16_t)cnt;
-        __syncthreads();
-        int pre = 0;
-        if (valid) {
-            for (int wv = 0; wv < wave; ++wv) pre += wcnt[wv * 64 + d];
-            dst[run[d] + pre + rank] = e;
-        }
-        __syncthreads();
-        if (tid < 64) {
-            int tot = 0;
-#pragma unroll
-            for (int wv = 0; wv < NW16; ++wv) tot += wcnt[wv * 64 + tid];
-            run[tid] += tot;
-        }
-        __syncthreads();
-    }
-}
 
 struct TreeShared {
     int nsel, best, ok;

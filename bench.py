@@ -281,6 +281,8 @@ def main():
             t0 = time.perf_counter()
             sl.pipe.submit_frames(frames, flags)
             host_t['enqueue'] += time.perf_counter() - t0
+        for k, sl in enumerate(slots):                         # every stream's last call is enqueued before any is waited for
+            take(k, sl.pipe.flush())
         for k, sl in enumerate(slots):
             t0 = time.perf_counter()
             res = sl.pipe.finish()

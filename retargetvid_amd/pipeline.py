@@ -178,14 +178,20 @@ class StreamPipeline:
         xy = self._xy[slot].numpy()
         return [(g, float(xy[i, 0]), float(xy[i, 1])) for i, g in rows]
 
-    def finish(self):
-        """Runs out whatever is still carried (one call, in rounds) and returns every result not collected yet.  A
-        trailing blend flag without a successor (the stream's last map) is dropped, as in the reference's loop."""
+    def flush(self):
+        """Enqueues the call that runs out whatever is still carried (in rounds) without waiting for it; -> results
+        collected on the way (to make room for the call).  Several pipelines can be flushed before any is waited for."""
         out = []
         while len(self.calls) >= self.depth:
             out += self.collect()
         if any(s == RAW for s in self.states):
             self._call(0, None, flush=True)
+        return out
+
+    def finish(self):
+        """flush(), then every result not collected yet.  A trailing blend flag without a successor (the stream's last
+        map) is dropped, as in the reference's loop."""
+        out = self.flush()
         while self.calls:
             out += self.collect()
         self.base += len(self.states)

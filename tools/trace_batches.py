@@ -19,7 +19,7 @@ for q, ks in byq.items():
             batches.append(cur)
         if cur is not None:
             cur['k'].append((s, e, n))
-TAIL = ('k_threshold', 'k_compact', 'k_core', 'k_prim', 'k_sort', 'k_tree', 'k_finish', 'k_blend')
+TAIL = ('k_threshold', 'k_compact', 'k_core', 'k_prim', 'k_tail_front', 'k_tail_back', 'k_prim_lvl', 'k_tree_par', 'k_sort', 'k_tree', 'k_finish', 'k_blend')
 out = []
 for b in batches:
     net = [k for k in b['k'] if not k[2].startswith(TAIL)]

@@ -21,7 +21,7 @@ print('wall %.2f ms' % (wall / 1e6))
 for k in sorted(hist):
     print('  %d kernels in flight: %5.1f %%' % (k, 100.0 * hist[k] / wall))
 print('mean kernels in flight %.2f' % (sum(k * v for k, v in hist.items()) / wall))
-tail = ('k_prim', 'k_tree', 'k_core', 'k_finish', 'k_sort', 'k_compact', 'k_blend', 'k_threshold')
+tail = ('k_prim', 'k_tail_front', 'k_tail_back', 'k_prim_lvl', 'k_tree_par', 'k_tree', 'k_core', 'k_finish', 'k_sort', 'k_compact', 'k_blend', 'k_threshold')
 tt = sum(e - max(s, lo) for s, e, n in rows if e > lo and n.startswith(tail))
 nt = sum(e - max(s, lo) for s, e, n in rows if e > lo and not n.startswith(tail))
 print('summed kernel time: tail %.1f ms, network %.1f ms (per wall ms: %.2f, %.2f)' % (tt / 1e6, nt / 1e6, tt / wall, nt / wall))

@@ -745,7 +745,7 @@ static size_t lvl_lds_bytes(int h, int w, int n_ring) {
     auto up = [](size_t b) { return (b + 15) / 16 * 16; };
     return up((cells + 31) / 32 * sizeof(OccW)) + up(cap * 8) + up(cap * 4) + up((cap + 63) / 64 * 8) +
            up((size_t)n_ring * 8) + up(cap * 2) + up(64 * 4 * 4) + up(64 * 4 * 8) + up(2 * NW16 * 4) + up(16) +
-           up(LVL_NB * 16) + up((cap + 63) / 64 * (LVL_NB / 32) * 4) + up((cap + 63) / 64 * 16) + up((LVL_RING2 + 1) * 2) + 64;
+           up(LVL_NB * 16) + up((cap + 63) / 64 * (LVL_NB / 32) * 4) + up((LVL_RING2 + 1) * 2) + 64;
 }
 
 __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int j) {
@@ -777,7 +777,6 @@ struct LvlLds {
     int *ctl;               // outcome of a round for the wavefronts that do not work in it: accepted, dropped, level, last node
     uint4 *btab;            // [LVL_NB] batches of tree nodes: (start | len << 16, box, smallest core distance, -)
     uint32_t *proc;         // [chunks][LVL_NB / 32] batch already relaxed against the chunk
-    uint4 *cbox;            // [chunks] (box, smallest core distance, -, -) of every chunk of 64 points
     uint16_t *rcnt;         // [RING_R^2 + 1] ring offsets with d2 <= index
     int gw;                 // padded grid width
 };
@@ -944,7 +943,6 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
         S.ctl = carve<int>(p, 4);
         S.btab = carve<uint4>(p, LVL_NB);
         S.proc = carve<uint32_t>(p, (size_t)((cap + 63) / 64) * (LVL_NB / 32));
-        S.cbox = carve<uint4>(p, (cap + 63) / 64);
         S.rcnt = carve<uint16_t>(p, LVL_RING2 + 1);
         S.gw = gw;
     }
@@ -989,17 +987,8 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
     for (int q = 0; q < LVL_PT; ++q) {
         R[q] = LVL_RINF;
         const int c = q * NW16 + wave;
-        if (c < NF64) {
-            const int p = c * 64 + lane;
-            const uint32_t v = p < N ? S.rc[p] : 0u;
-            const uint32_t r = v & 255, cc = v >> 8;
-            const uint32_t big = p < N ? 0u : 255u;
-            const uint32_t rmin = wave_min_u32(r | big), rmax = 255u - wave_min_u32(p < N ? 255u - r : 255u);
-            const uint32_t cmin = wave_min_u32(cc | big), cmax = 255u - wave_min_u32(p < N ? 255u - cc : 255u);
-            const uint32_t kmin = wave_min_u32(p < N ? (S.corei[p] & ~LVL_TREE) : LVL_RINF);
-            if (lane == 0) S.cbox[c] = make_uint4(rmin | (rmax << 8) | (cmin << 16) | (cmax << 24), kmin, 0u, 0u);
+        if (c < NF64)
             for (int i = lane; i < LVL_NB / 32; i += 64) S.proc[c * (LVL_NB / 32) + i] = 0u;
-        }
     }
     int cnt = 1, done = 0, nb = 0, parity = 0;
     uint32_t m = 0, cur = 0, swept = 0;
@@ -1033,6 +1022,7 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
             // against a chunk) where the block's lower bound allows a value <= the bound; new level, new F
             ++n_rises;
             uint32_t cjq[LVL_PT], rcq[LVL_PT];
+            uint4 cbq[LVL_PT];
             uint32_t qmask = 0;
 #pragma unroll
             for (int q = 0; q < LVL_PT; ++q) {
@@ -1046,7 +1036,17 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
                         rcq[q] = (v & 255) | ((v >> 8) << 16);
                     }
                     if (cjq[q] & LVL_TREE) R[q] = LVL_RINF;
-                    if (__ballot(!(cjq[q] & LVL_TREE))) qmask |= 1u << q;
+                    if (__ballot(!(cjq[q] & LVL_TREE))) {
+                        qmask |= 1u << q;
+                        // the box and the smallest core distance of the chunk's points that are still OUTSIDE the tree: tighter lower
+                        // bounds than the whole chunk's (a jump between blobs otherwise relaxes the finished blob's blocks again)
+                        const bool live = !(cjq[q] & LVL_TREE);
+                        const uint32_t r_ = rcq[q] & 0xFFFFu, c_ = rcq[q] >> 16;
+                        const uint32_t rmin = wave_min_u32(live ? r_ : 255u), rmax = 255u - wave_min_u32(live ? 255u - r_ : 255u);
+                        const uint32_t cmin = wave_min_u32(live ? c_ : 255u), cmax = 255u - wave_min_u32(live ? 255u - c_ : 255u);
+                        const uint32_t kmin = wave_min_u32(live ? cjq[q] : LVL_RINF);
+                        cbq[q] = make_uint4(rmin | (rmax << 8) | (cmin << 16) | (cmax << 24), kmin, 0u, 0u);
+                    }
                 }
             }
             const int nnew = (cnt - done + 63) >> 6;
@@ -1056,7 +1056,7 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
                 for (int q = 0; q < LVL_PT; ++q)
                     if (qmask & (1u << q)) {
                         const int c = q * NW16 + wave;
-                        R[q] = lvl_sweep_chunk<false>(S, S.btab, S.proc + c * (LVL_NB / 32), nb, 0u, true, S.cbox[c], rcq[q], cjq[q], R[q]);
+                        R[q] = lvl_sweep_chunk<false>(S, S.btab, S.proc + c * (LVL_NB / 32), nb, 0u, true, cbq[q], rcq[q], cjq[q], R[q]);
                     }
 #pragma unroll
                 for (int q = 0; q < LVL_PT; ++q) {
@@ -1099,7 +1099,7 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
                 for (int q = 0; q < LVL_PT; ++q)
                     if (qmask & (1u << q)) {
                         const int c = q * NW16 + wave;
-                        R[q] = lvl_sweep_chunk<false>(S, S.btab, S.proc + c * (LVL_NB / 32), nb, single ? ub0 : min(ub0, LVL_NEAR), false, S.cbox[c], rcq[q], cjq[q], R[q]);
+                        R[q] = lvl_sweep_chunk<false>(S, S.btab, S.proc + c * (LVL_NB / 32), nb, single ? ub0 : min(ub0, LVL_NEAR), false, cbq[q], rcq[q], cjq[q], R[q]);
                     }
                 swept = single ? ub0 : min(ub0, LVL_NEAR);
             }
@@ -1110,14 +1110,14 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
                 for (int q = 0; q < LVL_PT; ++q)
                     if (qmask & (1u << q)) {
                         const int c = q * NW16 + wave;
-                        R[q] = lvl_sweep_chunk<true>(S, S.btab, S.proc + c * (LVL_NB / 32), nb, ub1, false, S.cbox[c], rcq[q], cjq[q], R[q]);
+                        R[q] = lvl_sweep_chunk<true>(S, S.btab, S.proc + c * (LVL_NB / 32), nb, ub1, false, cbq[q], rcq[q], cjq[q], R[q]);
                     }
                 const uint32_t ub2 = block_min_R();
 #pragma unroll
                 for (int q = 0; q < LVL_PT; ++q)
                     if (qmask & (1u << q)) {
                         const int c = q * NW16 + wave;
-                        R[q] = lvl_sweep_chunk<false>(S, S.btab, S.proc + c * (LVL_NB / 32), nb, ub2, false, S.cbox[c], rcq[q], cjq[q], R[q]);
+                        R[q] = lvl_sweep_chunk<false>(S, S.btab, S.proc + c * (LVL_NB / 32), nb, ub2, false, cbq[q], rcq[q], cjq[q], R[q]);
                     }
                 swept = max(swept, ub2);
             }

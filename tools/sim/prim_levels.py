@@ -86,8 +86,17 @@ def prim_levels(X, core, hw, cap=64, stats=None, nbmax=256):
             processed.append(set())
         done = len(seq)
 
+        dyn = {}
+        if os.environ.get('DYNBOX', '0') == '1':       # experiment: the box of a chunk's points that are still outside the tree
+            for c in range(nch):
+                sl = slice(c * 64, min(n, c * 64 + 64))
+                live = ~intree[sl]
+                if live.any():
+                    Xc = X[sl][live]
+                    dyn[c] = (Xc[:, 0].min(), Xc[:, 0].max(), Xc[:, 1].min(), Xc[:, 1].max(), core[sl][live].min())
+
         def lower(b, c):
-            r0, r1, c0, c1, cm = cbox[c]
+            r0, r1, c0, c1, cm = dyn.get(c, cbox[c])
             s0, ln, br0, br1, bc0, bc1, bm = batches[b]
             dr = max(0, br0 - r1, r0 - br1); dc = max(0, bc0 - c1, c0 - bc1)
             return max(dr * dr + dc * dc, bm, cm)

@@ -527,7 +527,7 @@ def _fuzz_maps(rng, n, h, w):
 
 def test_new_tail_kernels_equal_the_round2_kernels_on_random_maps():
     """k_prim_lvl + k_tree_par (round 3) against the one-node-per-step Prim and the serial union-find hierarchy of round 2
-    (SVC_PRIM_LVL=0, SVC_TREE_PAR=0; both verified against the oracle by the tests above) on 264 random maps of three
+    (SVC_PRIM_LVL=0, SVC_TREE_PAR=0; both verified against the oracle by the tests above) on 288 random maps of four
     sizes and both parameter sets: Prim edge lists, labels, filtered maps and centres must be identical.  A wide net for
     the rare paths (drops, rises, jumps, full batch tables, maps above 4 352 points) that costs seconds on the device."""
     import os
@@ -547,7 +547,7 @@ def test_new_tail_kernels_equal_the_round2_kernels_on_random_maps():
     try:
         rng = np.random.RandomState(31)
         n_maps = 0
-        for (h, w, n) in ((140, 250, 48), (35, 62, 60), (187, 250, 24)):
+        for (h, w, n) in ((140, 250, 48), (35, 62, 60), (187, 250, 24), (255, 255, 12)):    # 255 x 255: the largest map the tail takes
             maps = _fuzz_maps(rng, n, h, w)
             flags = (rng.rand(n) < 0.2).astype(np.uint8)
             flags[-1] = 0
@@ -563,7 +563,7 @@ def test_new_tail_kernels_equal_the_round2_kernels_on_random_maps():
                     assert np.array_equal(s_old['mst'], s_new['mst']), 'Prim sequence of map %d (%dx%d, N = %d)' % (i, h, w, s_old['n'])
                     assert np.array_equal(s_old['labels'], s_new['labels']), 'labels of map %d' % i
                 n_maps += n
-        assert n_maps == 264
+        assert n_maps == 288
     finally:
         old.close()
         new.close()

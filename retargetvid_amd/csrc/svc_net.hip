@@ -1726,6 +1726,230 @@ static int launch_pw(SvcHandle *h, hipStream_t s, const float *X, int ldx, const
     return launch_pw_ex(h, s, X, ldx, L.w.dev, L.cin, L.cin, L.b.dev, L.relu6, L.cout, R, ldr, Y, ldy, M, n, nullptr);
 }
 
+// --------------------------------------------------------------------------------------
+// k_cgb: a whole inverted-residual block of the 8x13 level (expand -> depthwise -> project, MobileNetV2.py:26-83) with the
+// 6x expanded tensor kept on chip, parallel over CHANNEL GROUPS (round 3 experiment, SVC_CGB=1).
+// At 8x13 a frame has 104 pixels: a layer is one wave of workgroups, and the un-fused block writes and re-reads 25 MB of
+// expansion per 32 frames through three launches.  Here a workgroup = (frame, group of 128 expanded channels):
+//   1. the frame's input [px][Cin] -> LDS (rows padded to 128 pixels);
+//   2. expand: wave w = pixel tile w (32 pixels), 4 channel tiles, K = Cin, weights straight from L2; ReLU6; the
+//      128 x 128 tile is parked in LDS over the wave's own input rows;
+//   3. depthwise 3x3 + ReLU6 over the 8x13 grid for the group's channels (LDS -> LDS);
+//   4. project partial: [128 px x 128 ch] x [128 ch x Cout] -> partial sums of the block's output, written per group;
+// k_cgb_sum adds the groups' partials in group order (deterministic), the bias and the residual.
+// --------------------------------------------------------------------------------------
+#ifndef CGB_SKIP
+#define CGB_SKIP 0          // timing experiments only: bit 1 expand loop, 2 depthwise, 4 project loop left out
+#endif
+#define CGB_GC 128          // expanded channels per group
+#define CGB_XS 164          // LDS row stride (floats) of the input / expansion rows: max(Cin, 128) + 4
+#define CGB_DS 132          // LDS row stride of the depthwise output rows
+struct CgbArgs {
+    const float *X; int Cin, Cexp, Cout, H, W, n;
+    const float *We, *be, *Wd, *bd, *Wp;
+    float *part;            // [groups][n][H*W][Cout]
+};
+
+template <int NCO>          // column tiles (of 32 output channels) per project pass
+__global__ __launch_bounds__(256) void k_cgb(const CgbArgs A) {
+    extern __shared__ float sm_cgb[];
+    float *XE = sm_cgb, *D = sm_cgb + 128 * CGB_XS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int g = blockIdx.x, f = blockIdx.y, npx = A.H * A.W, Cin = A.Cin;
+    const int ch0 = g * CGB_GC, nval = min(CGB_GC, A.Cexp - ch0), nct = nval >> 5;
+    // 1. input rows (pixels >= npx: zeros); a frame's rows are contiguous in memory: batches of eight float4 per thread, all
+    // loads of a batch issued before the first LDS store (one memory round trip per batch, not per element)
+    const float *xf = A.X + (size_t)f * npx * Cin;
+    const int c4n = Cin >> 2, nin = npx * c4n;
+    for (int i0 = tid; i0 < ((CGB_SKIP & 16) ? 256 : 128 * c4n); i0 += 256 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 256 * u;
+            v[u] = i < nin ? *(const float4 *)(xf + 4 * (size_t)i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 256 * u;
+            if (i < 128 * c4n) {
+                const int px = i / c4n, c4 = i - px * c4n;
+                *(float4 *)(XE + px * CGB_XS + 4 * c4) = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    // 2. expand: acc[ct] = W[ch0 + 32 ct + .][k] x X[32 wave + .][k]; a lane ends with 16 channels of pixel 32 wave + r
+    {
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        const float *xp = XE + (wave * 32 + r) * CGB_XS + 4 * hh;
+        const float *wp = A.We + (size_t)(ch0 + r) * Cin + 4 * hh;
+        const int nst = Cin >> 3;
+        float4 b = *(const float4 *)xp, a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = *(const float4 *)(wp + (size_t)min(t, nct - 1) * 32 * Cin);
+        for (int st = 0; st < ((CGB_SKIP & 1) ? 1 : nst); ++st) {
+            const float4 bc = b;
+            float4 ac[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ac[t] = a[t];
+            const int sn = min(st + 1, nst - 1);
+            b = *(const float4 *)(xp + 8 * sn);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[t] = *(const float4 *)(wp + (size_t)min(t, nct - 1) * 32 * Cin + 8 * sn);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t >= nct) continue;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].x, bc.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].y, bc.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].z, bc.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].w, bc.w, acc[t], 0, 0, 0);
+            }
+        }
+        // ReLU6(acc + bias) -> the wave's own rows of XE, now [px][128 channels of the group]
+        float *ep = XE + (wave * 32 + r) * CGB_XS;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t >= nct) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = t * 32 + 8 * q + 4 * hh;
+                const float4 bv = *(const float4 *)(A.be + ch0 + c);
+                float4 v = make_float4(acc[t][4 * q] + bv.x, acc[t][4 * q + 1] + bv.y, acc[t][4 * q + 2] + bv.z, acc[t][4 * q + 3] + bv.w);
+                v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
+                v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
+                *(float4 *)(ep + c) = v;
+            }
+        }
+    }
+    __syncthreads();
+    // 3. depthwise 3x3 pad 1 + ReLU6 (taps in the order ky, kx, out-of-image taps contribute nothing: as k_dw)
+    {
+        const int q = tid & 31, c = 4 * q;
+        if (c < nval) {
+            float4 w9[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) w9[t] = *(const float4 *)(A.Wd + (size_t)t * A.Cexp + ch0 + c);
+            const float4 bv = *(const float4 *)(A.bd + ch0 + c);
+            // every tap is read (from a clamped position) and an out-of-image tap's weight is zero: fmaf(x, 0, acc) = acc for
+            // the finite x >= 0 in here, so the sums are those of the skipping form, without branches around the LDS reads
+            for (int px = tid >> 5; px < ((CGB_SKIP & 2) ? 8 : npx); px += 8) {
+                const int oy = px / A.W, ox = px - oy * A.W;
+                float4 x[9];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int iy = min(max(oy - 1 + ky, 0), A.H - 1), ix = min(max(ox - 1 + kx, 0), A.W - 1);
+                        x[ky * 3 + kx] = *(const float4 *)(XE + (iy * A.W + ix) * CGB_XS + c);
+                    }
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const bool in = (unsigned)(oy - 1 + ky) < (unsigned)A.H && (unsigned)(ox - 1 + kx) < (unsigned)A.W;
+                        const float4 w = w9[ky * 3 + kx], xv = x[ky * 3 + kx];
+                        acc.x = fmaf(xv.x, in ? w.x : 0.f, acc.x); acc.y = fmaf(xv.y, in ? w.y : 0.f, acc.y);
+                        acc.z = fmaf(xv.z, in ? w.z : 0.f, acc.z); acc.w = fmaf(xv.w, in ? w.w : 0.f, acc.w);
+                    }
+                acc.x = fminf(fmaxf(acc.x + bv.x, 0.f), 6.f); acc.y = fminf(fmaxf(acc.y + bv.y, 0.f), 6.f);
+                acc.z = fminf(fmaxf(acc.z + bv.z, 0.f), 6.f); acc.w = fminf(fmaxf(acc.w + bv.w, 0.f), 6.f);
+                *(float4 *)(D + px * CGB_DS + c) = acc;
+            }
+        }
+        // rows of padding pixels feed MFMA columns that are never stored; keep them finite
+        for (int i = tid; i < (128 - npx) * (CGB_GC / 4); i += 256) {
+            const int px = npx + i / (CGB_GC / 4), c4 = i % (CGB_GC / 4);
+            *(float4 *)(D + px * CGB_DS + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    // 4. project partial over the group's channels, NCO column tiles at a time
+    {
+        const float *dp = D + (wave * 32 + r) * CGB_DS + 4 * hh;
+        const int nst = nval >> 3, px = wave * 32 + r;
+        float *yp = A.part + (((size_t)g * A.n + f) * npx + px) * A.Cout;
+        for (int co0 = 0; co0 < A.Cout; co0 += 32 * NCO) {
+            f32x16 acc[NCO];
+#pragma unroll
+            for (int t = 0; t < NCO; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+            const float *wp = A.Wp + (size_t)(co0 + r) * A.Cexp + ch0 + 4 * hh;
+            float4 b = *(const float4 *)dp, a[NCO];
+#pragma unroll
+            for (int t = 0; t < NCO; ++t) a[t] = *(const float4 *)(wp + (size_t)t * 32 * A.Cexp);
+            for (int st = 0; st < ((CGB_SKIP & 4) ? 1 : nst); ++st) {
+                const float4 bc = b;
+                float4 ac[NCO];
+#pragma unroll
+                for (int t = 0; t < NCO; ++t) ac[t] = a[t];
+                const int sn = min(st + 1, nst - 1);
+                b = *(const float4 *)(dp + 8 * sn);
+#pragma unroll
+                for (int t = 0; t < NCO; ++t) a[t] = *(const float4 *)(wp + (size_t)t * 32 * A.Cexp + 8 * sn);
+#pragma unroll
+                for (int t = 0; t < NCO; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].x, bc.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].y, bc.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].z, bc.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].w, bc.w, acc[t], 0, 0, 0);
+                }
+            }
+            if (px < ((CGB_SKIP & 8) ? 1 : npx)) {
+#pragma unroll
+                for (int t = 0; t < NCO; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *(float4 *)(yp + co0 + t * 32 + 8 * q + 4 * hh) =
+                            make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+            }
+        }
+    }
+}
+
+// out = bias + sum over the groups (in group order) [+ residual]
+__global__ __launch_bounds__(256) void k_cgb_sum(const float *__restrict__ part, int groups, size_t per_group, const float *__restrict__ bias,
+                                                 const float *__restrict__ R, float *__restrict__ Y, int Cout) {
+    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i4 * 4 >= per_group) return;
+    const int co = (int)((i4 * 4) % (size_t)Cout);
+    float4 v = *(const float4 *)(part + i4 * 4);
+    for (int g = 1; g < groups; ++g) {
+        const float4 p = *(const float4 *)(part + (size_t)g * per_group + i4 * 4);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    const float4 b = *(const float4 *)(bias + co);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    if (R) { const float4 rv = *(const float4 *)(R + i4 * 4); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+    *(float4 *)(Y + i4 * 4) = v;
+}
+
+static int launch_cgb(SvcHandle *h, hipStream_t s, const float *X, int n, int H, int W, int Cin, const SvcLayer &Le, const SvcLayer &Ld,
+                      const SvcLayer &Lp, const float *R, float *Y) {
+    ProfScope ps(h, SVC_K_PW, s);
+    const int Cexp = Le.cout, Cout = Lp.cout, npx = H * W, groups = (Cexp + CGB_GC - 1) / CGB_GC;
+    const size_t per_group = (size_t)n * npx * Cout;
+    int rc = h->cgb_part.ensure((size_t)groups * per_group * sizeof(float));
+    if (rc) return rc;
+    CgbArgs A;
+    A.X = X; A.Cin = Cin; A.Cexp = Cexp; A.Cout = Cout; A.H = H; A.W = W; A.n = n;
+    A.We = Le.w.dev; A.be = Le.b.dev; A.Wd = Ld.w.dev; A.bd = Ld.b.dev; A.Wp = Lp.w.dev;
+    A.part = (float *)h->cgb_part.p;
+    const size_t lds = (size_t)(128 * CGB_XS + 128 * CGB_DS) * sizeof(float);
+    if (h->lds_attr_done.insert((const void *)k_cgb<5>).second)
+        SVC_HIP(hipFuncSetAttribute((const void *)k_cgb<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    k_cgb<5><<<dim3((unsigned)groups, (unsigned)n), 256, lds, s>>>(A);
+    SVC_CHECK_LAUNCH();
+    k_cgb_sum<<<blocks256(per_group / 4), 256, 0, s>>>((const float *)h->cgb_part.p, groups, per_group, Lp.b.dev, R, Y, Cout);
+    SVC_CHECK_LAUNCH();
+    return SVC_OK;
+}
+
 static int launch_dw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer &L, float *Y, int n, int H, int W,
                      int stride) {
     ProfScope ps(h, SVC_K_DW, s);
@@ -2526,6 +2750,11 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
                 const bool with_stem = stem_fused && idx == 1;
                 RC(launch_irb(h, s, with_stem ? IN : x, n, H, W, inp, Le, Ld, Lp, dws, res ? x : nullptr, y,
                               with_stem ? &Lstem : nullptr));
+            } else if (h->cgb && t != 1 && dws == 1 && !tap && H * W <= 128 && inp % 8 == 0 && inp <= 160 && (inp * t) % 64 == 0 &&
+                       oup % 160 == 0) {
+                const SvcLayer &Le = next();
+                const SvcLayer &Ld = next();
+                RC(launch_cgb(h, s, x, n, H, W, inp, Le, Ld, next(), res ? x : nullptr, y));
             } else {
                 const float *dwin = x;
                 if (t != 1) {
@@ -2834,6 +3063,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->shot_form = atoi(env);
     env = getenv("SVC_PRIM_PT");
     if (env && atoi(env) > 0) h->prim_pt = atoi(env);
+    env = getenv("SVC_CGB");
+    if (env) h->cgb = atoi(env) != 0;
     env = getenv("SVC_TAIL_MERGE");
     if (env) h->tail_merge = atoi(env);
     env = getenv("SVC_TREE_PAR");
@@ -2972,6 +3203,7 @@ extern "C" int svc_destroy(SvcHandle *h) {
     h->tail_ws.release();
     h->tail_offsets.release();
     h->tail_ring_cnt.release();
+    h->cgb_part.release();
     for (auto &kv : h->tail_delta) kv.second.release();
     h->stem_wt.release();
     h->shot_blob.release();

@@ -110,6 +110,7 @@ def test_saliency_batch_and_chunk_independence(engine):
     {'SVC_STEM_FUSED': '1'},                                # features.0 inside the kernel of block 1 (MFMA im2col form)
     {'SVC_FRONT': '0'},                                     # LANCZOS, features.0 and features.1 as three kernels instead of k_front
     {'SVC_CHUNK': '5'},                                     # ragged chunks of the batch
+    {'SVC_CGB': '1'},                                       # 8x13-level blocks as k_cgb (expansion in LDS, channel groups; DESIGN 5, not adopted)
 ])
 def test_saliency_kernel_families_agree(engine, synthetic_sd, knobs):
     """Every kernel family that can serve a layer (selected by shape at run time, forced here through

@@ -3063,6 +3063,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->shot_form = atoi(env);
     env = getenv("SVC_PRIM_PT");
     if (env && atoi(env) > 0) h->prim_pt = atoi(env);
+    env = getenv("SVC_TAIL_PRIO");
+    if (env) h->tail_prio = atoi(env);
     env = getenv("SVC_CGB");
     if (env) h->cgb = atoi(env) != 0;
     env = getenv("SVC_TAIL_MERGE");

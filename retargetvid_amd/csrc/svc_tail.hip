@@ -84,6 +84,7 @@ struct TailArgs {
     int n_ring, n_ring1;    // all offsets within RING_R / the prefix within RING_R1
     const uint16_t *ring_cnt;   // [RING_R^2 + 1]: offsets with d2 <= index
     int prim_lvl;           // 1: k_prim_lvl for maps of up to LVL_CAP points (SVC_PRIM_LVL)
+    int tail_prio;          // 1: the fused tail kernels raise their wavefronts' issue priority (SVC_TAIL_PRIO)
     double *xy;
     int32_t *stats;
     FrameWS L;
@@ -2362,6 +2363,10 @@ __global__ __launch_bounds__(TB) void k_finish(TailArgs A) { finish_body(A); }
 // take (more than 8 192 points, cluster tables full) are left to the stand-alone kernels launched behind.
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TB) void k_tail_front(TailArgs A) {           // k_compact -> k_core -> k_prim_lvl
+    // The tail is a chain of dependent steps on one CU per map; in the pipeline its wavefronts share their SIMDs with the
+    // network passes of other streams, whose wavefronts always have an instruction ready.  Highest issue priority for
+    // the tail's few instructions costs the network nothing and keeps the chain from waiting behind it.
+    if (A.tail_prio) __builtin_amdgcn_s_setprio(3);
     compact_body(A);
     __syncthreads();
     core_body(A);
@@ -2372,6 +2377,7 @@ __global__ __launch_bounds__(TB) void k_tail_front(TailArgs A) {           // k_
 __global__ __launch_bounds__(TB) void k_tail_back(TailArgs A, int cap_clusters) {   // k_sort -> k_tree_par -> k_finish
     const int f = A.order[blockIdx.x];
     int32_t *hdr = (int32_t *)(A.ws + (size_t)f * A.ws_stride + A.L.hdr);
+    if (A.tail_prio) __builtin_amdgcn_s_setprio(3);
     sort_body(A);
     __syncthreads();
     tree_par_body(A, cap_clusters);
@@ -2608,7 +2614,7 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
     RC_TAIL(ensure_ring_delta(h, width, &ring_delta));
     A.ring = (const uint32_t *)h->tail_offsets.p; A.n_ring = h->tail_n_offsets; A.n_ring1 = h->tail_n_offsets1;
     A.ring_delta = ring_delta;
-    A.ring_cnt = (const uint16_t *)h->tail_ring_cnt.p; A.prim_lvl = h->prim_lvl;
+    A.ring_cnt = (const uint16_t *)h->tail_ring_cnt.p; A.prim_lvl = h->prim_lvl; A.tail_prio = h->tail_prio;
     A.xy = xy; A.stats = stats; A.L = L;
     const int hw = height * width;
     const size_t lds_core = (size_t)(hw + 15) / 16 * 16 + (size_t)h->tail_n_offsets * 4 + (size_t)h->tail_n_offsets1 * 4;

@@ -297,12 +297,43 @@ class _HostFeed:
         return self._tp
 
 
+def device_index(engine, idx, dev=None):
+    """Frame numbers -> int64 CUDA tensor WITHOUT a host-device synchronisation: torch.as_tensor(list, device=...) copies from
+    pageable memory, i.e. waits for everything the stream holds -- once per read batch that is the end of the host's run-ahead
+    (and, with several videos in flight, of their overlap).  An arithmetic progression is generated on the device; any
+    other list travels through a small ring of pinned slots (an event per slot: a slot is not refilled before its copy ran)."""
+    import torch
+    dev = dev or engine.device
+    n = len(idx)
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=dev)
+    step = int(idx[1]) - int(idx[0]) if n > 1 else 1
+    if step > 0 and all(int(idx[i + 1]) - int(idx[i]) == step for i in range(n - 1)):
+        return torch.arange(int(idx[0]), int(idx[0]) + step * n, step, dtype=torch.int64, device=dev)
+    ring = engine.__dict__.get('_idx_ring')
+    if ring is None or ring['cap'] < n or ring['dev'] != dev:
+        cap = max(4096, n)
+        ring = engine.__dict__['_idx_ring'] = dict(cap=cap, dev=dev, k=0, host=[torch.empty(cap, dtype=torch.int64).pin_memory() for _ in range(4)],
+                                                   ev=[None] * 4)
+    k = ring['k'] = (ring['k'] + 1) & 3
+    if ring['ev'][k] is not None:
+        ring['ev'][k].synchronize()
+    host = ring['host'][k]
+    host[:n] = torch.as_tensor(np.asarray(idx, dtype=np.int64))
+    out = host[:n].to(dev, non_blocking=True)
+    ev = ring['ev'][k] = ring['ev'][k] or torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    return out
+
+
 def _small_frames(engine, frames, idx, sal_h, sal_w, dev):
     """Frames idx at saliency size on the device, whatever the container (CUDA tensor, on-device generator, host array)."""
     import torch
     if torch.is_tensor(frames) and frames.is_cuda:
-        return engine.resize_frames(frames[torch.as_tensor(idx, device=frames.device)].to(dev).contiguous(), sal_h, sal_w)
+        return engine.resize_frames(frames[device_index(engine, idx, frames.device)].to(dev).contiguous(), sal_h, sal_w)
     if not torch.is_tensor(frames) and hasattr(frames, 'select'):             # an on-device generator (synth.LazyBlobVideo)
+        if getattr(frames, 'accepts_device_index', False):
+            return engine.resize_frames(frames.select(idx, index=device_index(engine, idx, dev)).to(dev).contiguous(), sal_h, sal_w)
         return engine.resize_frames(frames.select(idx).to(dev).contiguous(), sal_h, sal_w)
     host = frames if torch.is_tensor(frames) else np.asarray(frames)
     if (host.dtype not in (np.uint8, torch.uint8)) or host.ndim != 4 or host.shape[3] != 3:
@@ -682,6 +713,9 @@ def crop_videos(videos, CP, ratios=None, workers=3, state_dict=None, seed=0, str
     workers = max(1, min(int(workers), len(videos) or 1))
     dev = torch.device('cuda', torch.cuda.current_device())
     from . import ops as _ops
+    if state_dict is None:                                   # built once, not once per worker (33 of an engine's 43 ms)
+        from . import weights as _weights
+        state_dict = _weights.make_synthetic_state_dict(seed)
     engines = [_ops.Engine(state_dict, device=dev.index, seed=seed) for _ in range(workers)]
     out, errors = [None] * len(videos), []
 
@@ -697,11 +731,20 @@ def crop_videos(videos, CP, ratios=None, workers=3, state_dict=None, seed=0, str
         except BaseException as e:                       # surfaced in the caller's thread
             errors.append(e)
 
+    # a worker coming back from a launch or a wait must get the interpreter back quickly to keep its stream fed: the default
+    # 5 ms switch interval lets another worker's NumPy-free Python stretch (bookkeeping, SciPy set-up) hold it that long
+    import sys
+    si = sys.getswitchinterval()
+    if os.environ.get('SVC_SWITCH_INTERVAL_US'):
+        sys.setswitchinterval(float(os.environ['SVC_SWITCH_INTERVAL_US']) * 1e-6)
     threads = [threading.Thread(target=run, args=(k,)) for k in range(workers)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    try:
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        sys.setswitchinterval(si)
     for e in engines:
         e.close()
     if errors:

@@ -53,10 +53,19 @@ class LazyBlobVideo:
     def __len__(self):
         return self.n
 
-    def select(self, idx):
+    accepts_device_index = True        # select(idx, index=<CUDA int64 tensor>): smartVidCrop._small_frames passes its own
+
+    def select(self, idx, index=None):
+        """index: the frame numbers as a CUDA tensor, if the caller has them there already (no host-device copy here)."""
         import torch
         dev = self.device
-        t = torch.as_tensor(list(idx), dtype=torch.float32, device=dev).view(-1, 1, 1)
+        idx = list(idx)
+        if index is not None:
+            t = index.to(torch.float32).view(-1, 1, 1)
+        elif len(idx) > 1 and all(idx[i + 1] - idx[i] == idx[1] - idx[0] for i in range(len(idx) - 1)) and idx[1] > idx[0]:
+            t = torch.arange(idx[0], idx[0] + (idx[1] - idx[0]) * len(idx), idx[1] - idx[0], dtype=torch.float32, device=dev).view(-1, 1, 1)
+        else:
+            t = torch.as_tensor(idx, dtype=torch.float32, device=dev).view(-1, 1, 1)       # (synchronises: pageable copy)
         ys = torch.arange(self.h, dtype=torch.float32, device=dev).view(1, -1, 1)
         xs = torch.arange(self.w, dtype=torch.float32, device=dev).view(1, 1, -1)
         # deterministic low-amplitude texture (a hash of position and frame) instead of a host RNG stream
@@ -67,5 +76,6 @@ class LazyBlobVideo:
             x0 = torch.remainder(p['cx'][b] + p['vx'][b] * t, self.w)
             y0 = torch.remainder(p['cy'][b] + p['vy'][b] * t, self.h)
             g = p['amp'][b] * torch.exp(-((xs - x0) ** 2 + (ys - y0) ** 2) / (2 * p['sig'][b] ** 2))
-            img += g.unsqueeze(-1) * torch.as_tensor(p['col'][b], dtype=torch.float32, device=dev).view(1, 1, 1, 3)
+            for c in range(3):                                       # (scalars: no host-device copy of the colour)
+                img[..., c].add_(g, alpha=float(p['col'][b][c]))
         return img.clamp_(0, 255).to(torch.uint8).contiguous()

@@ -111,6 +111,7 @@ struct SvcHandle {
                                        // a call still in flight on the stream may be reading the one it was given)
     int tail_frames = 0, tail_h = 0, tail_w = 0;
     size_t tail_frame_stride = 0;      // bytes of per-frame tail workspace
+    std::vector<int> tail_slot_of;     // last call: map -> workspace slot (-1: held)
     DevBuf rs_maps;                    // resize_factor != 1: the shrunk maps
     std::map<std::tuple<int, int, int>, std::pair<DevBuf, DevBuf>> rs_tabs;   // (h, w, factor) -> INTER_LINEAR tables down / up
     uint8_t *depth_pinned = nullptr;   // pinned staging ring for the per-map round numbers

@@ -72,8 +72,9 @@ static FrameWS make_layout(int cap, int mc) {
 
 struct TailArgs {
     uint8_t *maps;          // [n][h][w]
-    uint8_t *ws;            // per-frame workspace
+    uint8_t *ws;            // workspace, one slot per map the call PROCESSES (held maps have none): slot = slot0 + blockIdx.x
     size_t ws_stride;
+    int slot0;              // position of the launch's first map in the call's list of processed maps (sorted by round)
     const uint16_t *order;  // the maps this launch works on (one workgroup each): the current round's slice of the list of all maps sorted by round
     int n, h, w;
     FDiv dW;                // division by w
@@ -285,7 +286,7 @@ __device__ __forceinline__ void compact_body(const TailArgs &A) {
     extern __shared__ uint8_t sm_compact[];                  // the map: read once with whole lines, scanned from LDS
     const int hw = A.h * A.w;
     const uint8_t *gmap = A.maps + (size_t)f * hw;
-    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
+    uint8_t *ws = A.ws + (size_t)(A.slot0 + (int)blockIdx.x) * A.ws_stride;
     uint32_t *pts = (uint32_t *)(ws + A.L.pts);
     int32_t *hdr = (int32_t *)(ws + A.L.hdr);
     uint8_t *map = sm_compact;
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(TB) void k_compact(TailArgs A) { compact_body(A); }
 // --------------------------------------------------------------------------------------
 __device__ __forceinline__ void core_body(const TailArgs &A) {
     const int f = A.order[blockIdx.x];
-    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
+    uint8_t *ws = A.ws + (size_t)(A.slot0 + (int)blockIdx.x) * A.ws_stride;
     const int32_t *hdr = (const int32_t *)(ws + A.L.hdr);
     if (!hdr[3]) return;
     const int N = hdr[0];
@@ -652,8 +653,7 @@ struct PrimFrame {
 };
 // common prologue of the legacy kernels: false = nothing to do for this map
 __device__ __forceinline__ bool prim_frame(const TailArgs &A, uint8_t *sm, PrimFrame &P, int n_min) {
-    const int f = A.order[blockIdx.x];
-    P.ws = A.ws + (size_t)f * A.ws_stride;
+    P.ws = A.ws + (size_t)(A.slot0 + (int)blockIdx.x) * A.ws_stride;
     const int32_t *hdr = (const int32_t *)(P.ws + A.L.hdr);
     if (!hdr[3]) return false;
     P.N = hdr[0];
@@ -917,8 +917,7 @@ __device__ __forceinline__ uint32_t lvl_sweep_chunk(const LvlLds &S, const uint4
 }
 
 __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
-    const int f = A.order[blockIdx.x];
-    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
+    uint8_t *ws = A.ws + (size_t)(A.slot0 + (int)blockIdx.x) * A.ws_stride;
     int32_t *hdr = (int32_t *)(ws + A.L.hdr);
     if (!hdr[3]) return;
     const int N = hdr[0];
@@ -1849,8 +1848,7 @@ __device__ __forceinline__ void sort_carve(uint8_t *lds, uint8_t *glob, int n, S
 }
 
 __device__ __forceinline__ void sort_body(const TailArgs &A) {
-    const int f = A.order[blockIdx.x];
-    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
+    uint8_t *ws = A.ws + (size_t)(A.slot0 + (int)blockIdx.x) * A.ws_stride;
     int32_t *hdr = (int32_t *)(ws + A.L.hdr);
     if (!hdr[3]) return;
     const int n = hdr[0] - 1;
@@ -1881,8 +1879,7 @@ __global__ __launch_bounds__(TB) void k_argsort_test(const uint32_t *keys, int n
 // serial union-find pass, so the map gets ONE wavefront (64 threads): the other SIMDs and wave slots of
 // the CU stay free for the network kernels of the next batch (which use no LDS).
 __global__ __launch_bounds__(64) void k_tree(TailArgs A) {
-    const int f = A.order[blockIdx.x];
-    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
+    uint8_t *ws = A.ws + (size_t)(A.slot0 + (int)blockIdx.x) * A.ws_stride;
     int32_t *hdr = (int32_t *)(ws + A.L.hdr);
     if (!hdr[3] || hdr[23]) return;
     const int N = hdr[0];
@@ -2270,8 +2267,7 @@ __device__ __forceinline__ void tp_body(const TailArgs &A, int cap_clusters, uin
 #undef TP_W
 
 __device__ __forceinline__ void tree_par_body(const TailArgs &A, int cap_clusters) {
-    const int f = A.order[blockIdx.x];
-    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
+    uint8_t *ws = A.ws + (size_t)(A.slot0 + (int)blockIdx.x) * A.ws_stride;
     int32_t *hdr = (int32_t *)(ws + A.L.hdr);
     if (!hdr[3]) return;
     const int N = hdr[0];
@@ -2287,7 +2283,7 @@ __global__ __launch_bounds__(TB) void k_tree_par(TailArgs A, int cap_clusters) {
 // k_finish: zero everything outside the kept cluster, CLOSE 5x5, write the map back, centroid
 __device__ __forceinline__ void finish_body(const TailArgs &A) {
     const int f = A.order[blockIdx.x];
-    uint8_t *ws = A.ws + (size_t)f * A.ws_stride;
+    uint8_t *ws = A.ws + (size_t)(A.slot0 + (int)blockIdx.x) * A.ws_stride;
     int32_t *hdr = (int32_t *)(ws + A.L.hdr);
     if (hdr[30]) return;                                               // k_tail_back has finished this map already
     const int N = hdr[0];
@@ -2375,8 +2371,7 @@ __global__ __launch_bounds__(TB) void k_tail_front(TailArgs A) {           // k_
 }
 
 __global__ __launch_bounds__(TB) void k_tail_back(TailArgs A, int cap_clusters) {   // k_sort -> k_tree_par -> k_finish
-    const int f = A.order[blockIdx.x];
-    int32_t *hdr = (int32_t *)(A.ws + (size_t)f * A.ws_stride + A.L.hdr);
+    int32_t *hdr = (int32_t *)(A.ws + (size_t)(A.slot0 + (int)blockIdx.x) * A.ws_stride + A.L.hdr);
     if (A.tail_prio) __builtin_amdgcn_s_setprio(3);
     sort_body(A);
     __syncthreads();
@@ -2525,7 +2520,27 @@ extern "C" int svc_debug_round_plan(const uint8_t *flags_host, int n, int32_t *r
     return any ? maxd + 1 : 0;
 }
 
+static int cluster_center_impl(SvcHandle *h, uint8_t *maps, int n, int height, int width,
+                                  const uint8_t *blend_flags_host, const SvcParams *params, double *xy,
+                                  int32_t *stats, void *stream);
+#include <chrono>
+#include <atomic>
+static std::atomic<long long> g_cc_ns{0}, g_cc_calls{0}, g_cc_max{0};
 extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height, int width,
+                                  const uint8_t *blend_flags_host, const SvcParams *params, double *xy,
+                                  int32_t *stats, void *stream) {
+    static const bool timing = getenv("SVC_HOST_TIMING") != nullptr;
+    if (!timing) return cluster_center_impl(h, maps, n, height, width, blend_flags_host, params, xy, stats, stream);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = cluster_center_impl(h, maps, n, height, width, blend_flags_host, params, xy, stats, stream);
+    const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    g_cc_ns += ns; const long long c = ++g_cc_calls;
+    if (ns > g_cc_max) g_cc_max = ns;
+    if (ns > 2000000) fprintf(stderr, "svc_cluster_center call %lld: %.1f ms (n=%d)\n", c, ns / 1e6, n);
+    if (c % 100 == 0) fprintf(stderr, "svc_cluster_center host time: %lld calls, mean %.1f us, max %.1f us\n", c, g_cc_ns / 1e3 / c, g_cc_max / 1e3);
+    return rc;
+}
+static int cluster_center_impl(SvcHandle *h, uint8_t *maps, int n, int height, int width,
                                   const uint8_t *blend_flags_host, const SvcParams *params, double *xy,
                                   int32_t *stats, void *stream) {
     if (!h || !params || n < 0 || (n > 0 && (!maps || !xy)) || height < 1 || width < 1) {     // n = 0: a no-op, null buffers allowed
@@ -2592,20 +2607,28 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
         for (int i = 0; i < n; ++i) if (depth[i] != HELD) order[fill[depth[i]]++] = (uint16_t)i;
     }
     for (size_t i = 0; i < blend0.size(); ++i) order[n + i] = blend0[i];
-    if ((rc = h->tail_ws.ensure((size_t)L.total * n + 8 * 4 * (size_t)DEPTH_SLOT))) return rc;
+    // workspace: the round lists (a ring of 8 slots, fixed size) and behind them one slot per map that takes part in a
+    // round (a streamed call spans up to twice as many maps as it processes: the held ones need none); grown in steps of
+    // 32 slots -- a re-allocation is a hipFree, i.e. a device-wide synchronisation, and used to happen whenever a call
+    // was one map longer than any before it
+    const size_t lists_bytes = 8 * 4 * (size_t)DEPTH_SLOT;
+    const int n_proc = round_start[maxd + 1];
+    if ((rc = h->tail_ws.ensure(lists_bytes + (size_t)L.total * std::max<size_t>(32, ((size_t)n_proc + 31) / 32 * 32)))) return rc;
     // the lists travel through a small ring of pinned host slots so that the upload is asynchronous (up to 8 calls may
     // be in flight on the stream before a slot is reused)
     if (!h->depth_pinned) SVC_HIP(hipHostMalloc((void **)&h->depth_pinned, 8 * 4 * (size_t)DEPTH_SLOT, hipHostMallocDefault));
     const int slot = h->depth_slot++ & 7;
     if (h->depth_ev[slot]) SVC_HIP(hipEventSynchronize(h->depth_ev[slot]));      // the upload that last used this slot has run
     else SVC_HIP(hipEventCreateWithFlags(&h->depth_ev[slot], hipEventDisableTiming));
-    uint16_t *order_dev = (uint16_t *)((uint8_t *)h->tail_ws.p + (size_t)L.total * n + (size_t)slot * 4 * DEPTH_SLOT);
+    uint16_t *order_dev = (uint16_t *)((uint8_t *)h->tail_ws.p + (size_t)slot * 4 * DEPTH_SLOT);
     memcpy(h->depth_pinned + (size_t)slot * 4 * DEPTH_SLOT, order.data(), (size_t)n * 4);
     SVC_HIP(hipMemcpyAsync(order_dev, h->depth_pinned + (size_t)slot * 4 * DEPTH_SLOT, (size_t)n * 4, hipMemcpyHostToDevice, s));
     SVC_HIP(hipEventRecord(h->depth_ev[slot], s));
     h->tail_frames = n; h->tail_h = height; h->tail_w = width; h->tail_frame_stride = L.total;
+    h->tail_slot_of.assign((size_t)n, -1);                       // (svc_debug_cluster_state: map -> workspace slot)
+    for (int i = 0; i < n_proc; ++i) h->tail_slot_of[order[i]] = i;
     TailArgs A;
-    A.maps = maps; A.ws = (uint8_t *)h->tail_ws.p; A.ws_stride = L.total; A.order = order_dev;
+    A.maps = maps; A.ws = (uint8_t *)h->tail_ws.p + lists_bytes; A.ws_stride = L.total; A.order = order_dev; A.slot0 = 0;
     A.n = n; A.h = height; A.w = width; A.dW = make_fdiv(width);
     A.mcs = params->hdbscan_min; A.min_samples = params->hdbscan_min_samples; A.select_sum = params->select_sum;
     A.op_close = params->op_close; A.clust_filt = params->clust_filt;
@@ -2637,7 +2660,7 @@ extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height
     for (int r = 0; r <= maxd; ++r) {
         const int m = round_start[r + 1] - round_start[r];   // maps of this round
         const uint16_t *ord = order_dev + round_start[r];
-        A.order = ord;
+        A.order = ord; A.slot0 = round_start[r];
         if (r == 0 && !blend0.empty()) {                     // blends from held (already final) predecessors
             k_blend<<<dim3(8, (unsigned)blend0.size()), 256, 0, s>>>(full_maps, order_dev + n, full_h * full_w);
             SVC_CHECK_LAUNCH();
@@ -2755,15 +2778,15 @@ extern "C" int svc_debug_argsort_u32(SvcHandle *h, const uint32_t *keys_host, in
 
 extern "C" int svc_debug_cluster_state(SvcHandle *h, int frame, int cap, uint32_t *pts_host, uint32_t *core_host,
                                        uint32_t *mst_host, int32_t *labels_host, int32_t *hdr_host) {
-    if (!h || !h->tail_ws.p || frame < 0 || frame >= h->tail_frames) {
-        svc_set_error("svc_debug_cluster_state: no such frame");
+    if (!h || !h->tail_ws.p || frame < 0 || frame >= h->tail_frames || h->tail_slot_of[frame] < 0) {
+        svc_set_error("svc_debug_cluster_state: no such frame (or a held map: the last call did not process it)");
         return SVC_E_INVALID;
     }
     SVC_HIP(hipSetDevice(h->device));
     SVC_HIP(hipDeviceSynchronize());
     const int fcap = h->tail_h * h->tail_w;
     FrameWS L = make_layout(fcap, 1);      // point-array offsets do not depend on the cluster capacity
-    const uint8_t *ws = (const uint8_t *)h->tail_ws.p + (size_t)frame * h->tail_frame_stride;
+    const uint8_t *ws = (const uint8_t *)h->tail_ws.p + 8 * 4 * (size_t)DEPTH_SLOT + (size_t)h->tail_slot_of[frame] * h->tail_frame_stride;
     int32_t hdr[32];
     SVC_HIP(hipMemcpy(hdr, ws + L.hdr, sizeof hdr, hipMemcpyDeviceToHost));
     const int N = hdr[0];

@@ -30,13 +30,18 @@ def main():
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'config3'))
     ap.add_argument('--workers', type=int, default=4, help='videos in flight per GPU (S.crop_videos)')
     ap.add_argument('--stream-batch', type=int, default=int(os.environ.get('STREAM_BATCH', 64)), help='maps per tail call inside the ingest (pipeline.StreamPipeline); 0 = one call per video')
+    ap.add_argument('--ranks-per-gpu', type=int, default=1, help='processes that share one GPU (launch nproc-per-node = GPUs x this)')
     ap.add_argument('--annotations', default=os.path.join(ROOT, 'tests', 'golden', 'retargetvid'))
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
-    torch.cuda.set_device(local)
+    rpg = max(1, args.ranks_per_gpu)
+    torch.cuda.set_device(local // rpg)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if rpg > 1:       # several ranks share a GPU (the host side of a video is Python: one interpreter lock per process); RCCL wants
+            torch.distributed.init_process_group('gloo')     # one rank per device, so the boxes are gathered over gloo here
+        else:
+            torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
     annots = E.load_annotations(args.annotations)
     vids = E.VID_INDS[:args.videos]
     counts = [len(annots[0]['1-3'][v]) for v in vids]
@@ -58,6 +63,11 @@ def main():
     crop_fn = lambda vs, cp, rs, w: S.crop_videos(vs, cp, rs, workers=w, stream_batch=args.stream_batch)
     allb, st = D.crop_job(make, counts, ['%03d' % v for v in vids], CP, ratios, out_dir=args.out, workers=args.workers,
                           run_name='synthetic_default', crop_fn=crop_fn)
+    dt_max = st['seconds_rank']
+    if world > 1:                                            # the job's compute time = the slowest rank's
+        t_ = torch.tensor([dt_max], dtype=torch.float64, device='cuda' if torch.distributed.get_backend() == 'nccl' else 'cpu')
+        torch.distributed.all_reduce(t_, op=torch.distributed.ReduceOp.MAX)
+        dt_max = float(t_.item())
     if rank == 0:
         score = None
         if args.videos == 200 and not args.max_frames:
@@ -66,7 +76,7 @@ def main():
         dt = st['seconds_rank']
         print(json.dumps(dict(config='RetargetVid-shaped synthetic set', stream_batch=args.stream_batch, videos=len(vids), world=world,
                               video_frames=sum(counts), saliency_frames_rank0=st['saliency_frames_rank'],
-                              seconds_rank0=round(dt, 2), video_frames_per_s_rank0=round(st['video_frames_rank'] / dt, 1),
+                              seconds_rank0=round(dt, 2), seconds_slowest_rank=round(dt_max, 2), video_frames_per_s_job=round(sum(counts) / dt_max, 1), video_frames_per_s_rank0=round(st['video_frames_rank'] / dt, 1),
                               saliency_frames_per_s_rank0=round(st['saliency_frames_rank'] / dt, 1), eval=score)))
     if world > 1:
         torch.distributed.barrier()

@@ -145,7 +145,7 @@ struct SvcHandle {
     int prim_pt = 2;                   // legacy Prim (k_prim_pt): smallest points-per-thread variant (SVC_PRIM_PT: 2, 4, 8, 16)
     bool cgb = false;                  // 8x13-level inverted-residual blocks as k_cgb (channel-group fused block; SVC_CGB=1: round-3 experiment)
     DevBuf cgb_part;                   // ... its per-group partial sums
-    int tail_prio = 1;                 // s_setprio 3 in k_tail_front / k_tail_back (SVC_TAIL_PRIO=0: default priority)
+    int tail_prio = 0;                 // SVC_TAIL_PRIO=1: s_setprio 3 in k_tail_front / k_tail_back (measured: no effect on the pipelined bench or config 3)
     int tail_merge = 1;                // a round's kernels as two fused launches, k_tail_front / k_tail_back (SVC_TAIL_MERGE=0: one launch per stage, for per-kernel profiles)
     int tree_par = 1;                  // data-parallel hierarchy k_tree_par for maps of up to 4352 points (SVC_TREE_PAR=0: the serial builder k_tree)
     int prim_lvl = 1;                  // level-bucketed Prim k_prim_lvl for maps of up to 8192 points (SVC_PRIM_LVL=0: one node per step)

@@ -2359,9 +2359,9 @@ __global__ __launch_bounds__(TB) void k_finish(TailArgs A) { finish_body(A); }
 // take (more than 8 192 points, cluster tables full) are left to the stand-alone kernels launched behind.
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TB) void k_tail_front(TailArgs A) {           // k_compact -> k_core -> k_prim_lvl
-    // The tail is a chain of dependent steps on one CU per map; in the pipeline its wavefronts share their SIMDs with the
-    // network passes of other streams, whose wavefronts always have an instruction ready.  Highest issue priority for
-    // the tail's few instructions costs the network nothing and keeps the chain from waiting behind it.
+    // SVC_TAIL_PRIO=1: highest issue priority for the tail's wavefronts (a chain of dependent steps that shares its SIMDs with
+    // other streams' network wavefronts in the pipeline).  Measured: no difference (1.2315 / 1.2354 ms per pipelined step,
+    // config 3 1.93 / 1.95 s) -- the chain waits for its own latencies, not for issue slots.  Off by default.
     if (A.tail_prio) __builtin_amdgcn_s_setprio(3);
     compact_body(A);
     __syncthreads();

@@ -843,25 +843,25 @@ __device__ __forceinline__ void lvl_walk(const LvlLds &S, int wave, int nk, uint
 }
 
 // One batch of <= 64 tree nodes (positions start .. start + len in tnode) against one chunk of 64 points (one per
-// lane): r = min(r, max(d2, core_j, core_t)).  The nodes are read once by the lanes and travel through scalar registers.
+// lane): r = min(r, max(d2, core_j, core_t)).  Every lane reads the node from LDS itself (one address for the whole
+// wavefront: a broadcast read on the LDS pipe, two nodes per ds_read_b128) -- the earlier form, nodes read once by the
+// lanes and handed round with v_readlane, spent 2 of its 6.5 VALU slots per node (+ the SGPR hazard nops) on that.
 __device__ __forceinline__ uint32_t lvl_relax_block(const LvlLds &S, int start, int len, uint32_t rcv, uint32_t cj, uint32_t r) {
-    const int lane = threadIdx.x & 63;
-    const uint2 mine = S.tnode[start + min(lane, len - 1)];
+    const uint2 *tn = S.tnode + start;
     if (len == 64) {
 #pragma unroll 16
         for (int j = 0; j < 64; ++j) {
-            const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, j);
-            const uint32_t ty = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, j);
-            const lvl_s2 d = __builtin_bit_cast(lvl_s2, rcv) - __builtin_bit_cast(lvl_s2, tx);
-            r = min(r, max(max((uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false), cj), ty));
+            const uint2 t = tn[j];
+            const lvl_s2 d = __builtin_bit_cast(lvl_s2, rcv) - __builtin_bit_cast(lvl_s2, t.x);
+            r = min(r, max(max((uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false), cj), t.y));
         }
         return r;
     }
+#pragma unroll 4
     for (int j = 0; j < len; ++j) {
-        const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, j);
-        const uint32_t ty = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, j);
-        const lvl_s2 d = __builtin_bit_cast(lvl_s2, rcv) - __builtin_bit_cast(lvl_s2, tx);
-        r = min(r, max(max((uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false), cj), ty));
+        const uint2 t = tn[j];
+        const lvl_s2 d = __builtin_bit_cast(lvl_s2, rcv) - __builtin_bit_cast(lvl_s2, t.x);
+        r = min(r, max(max((uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false), cj), t.y));
     }
     return r;
 }

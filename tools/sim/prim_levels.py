@@ -56,13 +56,14 @@ def prim_levels(X, core, hw, cap=64, stats=None, nbmax=256):
              X[c * 64:c * 64 + 64, 1].max(), core[c * 64:c * 64 + 64].min()) for c in range(nch)]
     state = {'swept': 0}    # every pending block has a lower bound above this (the limit of the last sweep over all of them)
     batches = []            # (start, len, rmin, rmax, cmin, cmax, coremin)
+    nodes = []              # the tree nodes as the batches see them: Prim order, or (SORTNEW=k) the nodes of a rise with >= k batches in index order
     processed = []          # per batch: set of chunks
     NBMAX = nbmax
 
     def relax_block(b, c):
         s0, ln = batches[b][0], batches[b][1]
         sl = slice(c * 64, min(n, c * 64 + 64))
-        for t in seq[s0:s0 + ln]:
+        for t in nodes[s0:s0 + ln]:
             d = (X[sl, 0] - X[t, 0]) ** 2 + (X[sl, 1] - X[t, 1]) ** 2
             R[sl] = np.minimum(R[sl], np.maximum(np.maximum(d, core[sl]), core[t]))
         R[intree] = INF                  # (the kernel: tree members carry an infinite core distance)
@@ -80,8 +81,13 @@ def prim_levels(X, core, hw, cap=64, stats=None, nbmax=256):
                         relax_block(b, c)
             batches.clear(); processed.clear(); state['swept'] = 0
             st['flushes'] = st.get('flushes', 0) + 1
+        seg = seq[done:]
+        sortnew = int(os.environ.get('SORTNEW', 0))
+        if sortnew and len(new) >= sortnew:
+            seg = sorted(seg)                    # index order = raster order: batches become compact strips, like the chunks
+        nodes[done:] = seg
         for s0 in new:
-            t = np.array(seq[s0:min(len(seq), s0 + 64)])
+            t = np.array(nodes[s0:min(len(seq), s0 + 64)])
             batches.append((s0, len(t), X[t, 0].min(), X[t, 0].max(), X[t, 1].min(), X[t, 1].max(), core[t].min()))
             processed.append(set())
         done = len(seq)

@@ -765,6 +765,22 @@ __device__ __forceinline__ uint32_t wave_prefix_min_u32(uint32_t v) {
     return v;
 }
 
+// wave-wide inclusive prefix sum (64 lanes) as six DPP-fused additions: a Hillis-Steele scan inside every row of 16
+// lanes (row_shr 1, 2, 4, 8; lanes without a source add 0), then the row totals are carried into the rows above
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add_u32(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v = dpp_add_u32<0x111, 0xF>(v);
+    v = dpp_add_u32<0x112, 0xF>(v);
+    v = dpp_add_u32<0x114, 0xF>(v);
+    v = dpp_add_u32<0x118, 0xF>(v);
+    v = dpp_add_u32<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_add_u32<0x143, 0xC>(v);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 struct LvlLds {
     OccW *occ;              // padded grid, 32 cells per word
     uint2 *tnode;           // tree nodes in the order they joined: (row | col << 16, core distance)
@@ -1144,7 +1160,10 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
         uint32_t mycand = LVL_NONE, m2 = LVL_NONE, entmask = 0;
         bool dropped = false;
         if (worker) {
-            // the first 64 members of F in index order (each worker for itself: no barrier)
+            // the first 64 members of F in index order (each worker for itself: no barrier).  A loop over the WORDS that hold
+            // members, all lanes placing one word's members at once: the members of a level are raster neighbours, i.e. few
+            // words with many bits each (the other way round -- lane = word, rank from a prefix sum of the populations, every
+            // lane writing its own bits -- took 2.7x as long: 88 against 32 us per map at ~780 points)
             uint32_t *cw = S.cand + wave * 64;
             for (int wb = 0; wb < NF64 && ncand < 64; wb += 64) {
                 const int k = wb + lane;
@@ -1311,22 +1330,6 @@ __device__ __forceinline__ void close_pass(const uint8_t *__restrict__ src, uint
 struct TreeShared {
     int nsel, best, ok;
 };
-
-// wave-wide inclusive prefix sum (64 lanes) as six DPP-fused additions: a Hillis-Steele scan inside every row of 16
-// lanes (row_shr 1, 2, 4, 8; lanes without a source add 0), then the row totals are carried into the rows above
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_add_u32(uint32_t v) {
-    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-    v = dpp_add_u32<0x111, 0xF>(v);
-    v = dpp_add_u32<0x112, 0xF>(v);
-    v = dpp_add_u32<0x114, 0xF>(v);
-    v = dpp_add_u32<0x118, 0xF>(v);
-    v = dpp_add_u32<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
-    v = dpp_add_u32<0x143, 0xC>(v);      // row_bcast:31 into rows 2 and 3
-    return v;
-}
 
 // hdb::build_batched<64> on one wavefront (see the comment there): lane j resolves edge j of the batch and
 // classifies its sides (big / fresh / linked to an earlier lane); six rounds of pointer jumping along the links

@@ -865,7 +865,7 @@ __device__ __forceinline__ void lvl_walk(const LvlLds &S, int wave, int nk, uint
 __device__ __forceinline__ uint32_t lvl_relax_block(const LvlLds &S, int start, int len, uint32_t rcv, uint32_t cj, uint32_t r) {
     const uint2 *tn = S.tnode + start;
     if (len == 64) {
-#pragma unroll 16
+#pragma unroll 4          // (8 and 16 cost the kernel its last registers: 2-3 spills)
         for (int j = 0; j < 64; ++j) {
             const uint2 t = tn[j];
             const lvl_s2 d = __builtin_bit_cast(lvl_s2, rcv) - __builtin_bit_cast(lvl_s2, t.x);

@@ -163,13 +163,14 @@ __global__ __launch_bounds__(256) void k_shot_conv_lds(const ShotConv A) {
         ok = (unsigned)tt < (unsigned)A.T && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W;
         return ok ? A.X + ((((size_t)(frame0 + tt)) * A.H + yy) * A.W + xx) * C + 4 * hh : A.X + 4 * hh;
     };
-    float4 wreg[8];
+    typedef float shot_f4 __attribute__((ext_vector_type(4)));
+    shot_f4 wreg[8];                                         // (an ext_vector type: a float4 struct array indexed under a run-time bound became a 144-byte private segment)
     auto fetch_w = [&](int tap) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             if (i < per_thread) {
                 const int idx = tid + 256 * i, row = idx / c4n, c4 = idx - row * c4n;
-                wreg[i] = *(const float4 *)(wbase + (size_t)row * A.kpad + tap * C + c4 * 4);
+                wreg[i] = *(const shot_f4 *)(wbase + (size_t)row * A.kpad + tap * C + c4 * 4);
             }
     };
     auto store_w = [&](float *dst) {
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void k_shot_conv_lds(const ShotConv A) {
         for (int i = 0; i < 8; ++i)
             if (i < per_thread) {
                 const int idx = tid + 256 * i, row = idx / c4n, c4 = idx - row * c4n;
-                *(float4 *)(dst + row * WS + c4 * 4) = wreg[i];
+                *(shot_f4 *)(dst + row * WS + c4 * 4) = wreg[i];
             }
     };
     fetch_w(0);

@@ -303,3 +303,21 @@ def test_feature_cache_in_temp_path(engine, tmp_path):
     b, _ = S.smart_vid_crop(no_frames, CP31, save_vid=False, engine=engine, temp_path=str(tmp_path))
     assert b['bbs'] == fresh31['bbs'] and b['true_inds'] == fresh31['true_inds']
     assert np.array_equal(b['smaps'], fresh31['smaps'])
+
+
+def test_frame_numbers_reach_the_device_without_a_synchronising_copy(engine):
+    """smartVidCrop.device_index: an arithmetic progression is generated on the device, any other list goes through the
+    pinned ring (more lists than the ring has slots, longer than a slot); CUDA-tensor frames selected with it are the
+    frames selected on the host; the lazily generated video gives the same frames with and without the device index."""
+    lists = [[0, 6, 12, 18], [5], [], [3, 4, 5, 6, 7], [0, 6, 12, 13, 14, 20], list(range(0, 9000, 2)) + [8999, 9001],
+             [7, 3, 11], [1, 2, 4, 8, 16], [10, 20, 30, 31], [0, 1, 3]]
+    for idx in lists:
+        got = S.device_index(engine, idx)
+        assert got.dtype == torch.int64 and got.is_cuda and got.cpu().tolist() == list(idx)
+    frames = torch.from_numpy(synth.blob_frames(24, 90, 160, seed=5)).cuda()
+    idx = [0, 6, 7, 8, 14, 23]
+    small = S._small_frames(engine, frames, idx, 45, 80, engine.device)
+    assert torch.equal(small, engine.resize_frames(frames[idx].contiguous(), 45, 80))
+    v = synth.LazyBlobVideo(40, 90, 160, seed=2)
+    assert torch.equal(v.select(idx), v.select(idx, index=S.device_index(engine, idx)))
+    assert torch.equal(v.select([2, 5, 8, 11]), v.select([2, 5, 8, 11], index=S.device_index(engine, [2, 5, 8, 11])))

@@ -1,5 +1,8 @@
 #!/bin/bash
-# k_cgb phase timing: the kernel's average duration with a phase left out (libraries built with -DCGB_SKIP=<bits> under retargetvid_amd/ab/)
+# k_cgb phase timing: the kernel's average duration with a phase left out.  Build the variants first (build container):
+#   cd retargetvid_amd/csrc && mkdir -p ../ab && for v in 7 15 23 31; do hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 \
+#     -ffp-contract=off -Wno-unused-function -Wno-pass-failed -DCGB_SKIP=$v -shared -o ../ab/skip$v.so svc_net.hip svc_tail.hip svc_shot.hip; done
+# CGB_SKIP bits: 1 expand loop, 2 depthwise, 4 project loop, 8 partial-sum stores, 16 input rows (results are wrong, the time is the point)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export SVC_CGB=1
 cd /tmp && export TMPDIR=/tmp

@@ -22,6 +22,8 @@
 #include <math.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 
 #include "hdb_tree.h"
 #include "svc_internal.h"
@@ -2526,8 +2528,8 @@ extern "C" int svc_debug_round_plan(const uint8_t *flags_host, int n, int32_t *r
 static int cluster_center_impl(SvcHandle *h, uint8_t *maps, int n, int height, int width,
                                   const uint8_t *blend_flags_host, const SvcParams *params, double *xy,
                                   int32_t *stats, void *stream);
-#include <chrono>
-#include <atomic>
+// SVC_HOST_TIMING=1: the call's host-side duration goes to stderr (every 100 calls; every call above 2 ms) -- a call is
+// supposed to enqueue and return; a workspace re-allocation or a full upload ring shows up here
 static std::atomic<long long> g_cc_ns{0}, g_cc_calls{0}, g_cc_max{0};
 extern "C" int svc_cluster_center(SvcHandle *h, uint8_t *maps, int n, int height, int width,
                                   const uint8_t *blend_flags_host, const SvcParams *params, double *xy,

@@ -1293,17 +1293,23 @@ __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) { prim_lvl_body(A);
 // One 1x5 (ROWS) or 5x1 pass of the separable grey CLOSE over a map in LDS: MAX = dilate, else erode; samples
 // outside the image are ignored (OpenCV's morphology border).  A thread produces four consecutive outputs
 // along the pass direction from one sliding window of eight samples (2 LDS reads per output instead of 5).
+// The pass runs over a WINDOW of the image (rows r0 .. r0+wh, columns c0 .. c0+ww; row stride w): samples outside the window
+// count as outside the image.  finish_body passes the kept cluster's bounding box widened by 4 pixels (clipped to the
+// image): everything further out is zero before and after the CLOSE, and inside the window the results are those of the
+// whole-image pass -- a dilated value is non-zero within 2 pixels of the box only, so an eroded value next to an inner
+// window edge already has the zeros of the window's own last two lines among its samples.
 template <bool MAX, bool ROWS>
-__device__ __forceinline__ void close_pass(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int h, int w) {
-    const int len = ROWS ? w : h, lines = ROWS ? h : w;      // length of a line along the pass, number of lines
+__device__ __forceinline__ void close_pass(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int r0, int c0, int wh, int ww) {
+    const int len = ROWS ? ww : wh, lines = ROWS ? wh : ww;  // length of a line along the pass, number of lines
     const int stride = ROWS ? 1 : w, lstride = ROWS ? w : 1;
     const int groups = (len + 3) >> 2;
     const int ident = MAX ? 0 : 255;
+    const int origin = r0 * w + c0;
     for (int it = threadIdx.x; it < lines * groups; it += TB) {
         // consecutive threads take consecutive positions ACROSS lines for the column pass (adjacent bytes in LDS)
         const int line = ROWS ? it / groups : it % lines, g = ROWS ? it - line * groups : it / lines;
         const int p0 = 4 * g;
-        const uint8_t *sp = src + line * lstride;
+        const uint8_t *sp = src + origin + line * lstride;
         int win[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -1316,7 +1322,7 @@ __device__ __forceinline__ void close_pass(const uint8_t *__restrict__ src, uint
             int v = win[j];
 #pragma unroll
             for (int d = 1; d < 5; ++d) v = MAX ? max(v, win[j + d]) : min(v, win[j + d]);
-            dst[line * lstride + (p0 + j) * stride] = (uint8_t)v;
+            dst[origin + line * lstride + (p0 + j) * stride] = (uint8_t)v;
         }
     }
 }
@@ -2296,7 +2302,9 @@ __device__ __forceinline__ void finish_body(const TailArgs &A) {
     uint8_t *map = A.maps + (size_t)f * hw;
     extern __shared__ uint8_t sm_fin[];
     __shared__ unsigned long long red[3 * NW16];
+    __shared__ uint32_t box[4];
     const int tid = threadIdx.x;
+    if (tid < 4) box[tid] = 255u;                          // (published by the barrier behind the map copy)
     const bool clustered = hdr[3] != 0;
     long long t0 = 0;
     if (tid == 0) t0 = wall_clock64();
@@ -2306,25 +2314,34 @@ __device__ __forceinline__ void finish_body(const TailArgs &A) {
     uint8_t *m1 = sm_fin + (hw + 15) / 16 * 16;      // [hw]
     copy_bytes(m0, map, hw);
     __syncthreads();
+    int wr0 = 0, wc0 = 0, wh = A.h, ww = A.w;                // the window the CLOSE and the centroid have to look at
     if (best >= 0) {
         const uint32_t *pts = (const uint32_t *)(ws + A.L.pts);
         const int32_t *labels = (const int32_t *)(ws + A.L.labels);
-        for (int p = tid; p < N; p += TB)
-            if (labels[p] != best) {
-                const uint32_t v = pts[p];
-                m0[(v & 255) * A.w + ((v >> 8) & 255)] = 0;
-            }
+        // bounding box of the kept cluster (the maxima as minima of 255 - r, 255 - c: one kind of reduction)
+        uint32_t rmin = 255, cmin = 255, rmaxc = 255, cmaxc = 255;
+        for (int p = tid; p < N; p += TB) {
+            const uint32_t v = pts[p], r = v & 255, c = (v >> 8) & 255;
+            if (labels[p] != best) m0[r * A.w + c] = 0;
+            else { rmin = min(rmin, r); cmin = min(cmin, c); rmaxc = min(rmaxc, 255u - r); cmaxc = min(cmaxc, 255u - c); }
+        }
+        const uint32_t a = wave_min_u32(rmin), b = wave_min_u32(cmin), c_ = wave_min_u32(rmaxc), d = wave_min_u32(cmaxc);
+        if ((tid & 63) == 0) { atomicMin(&box[0], a); atomicMin(&box[1], b); atomicMin(&box[2], c_); atomicMin(&box[3], d); }
         __syncthreads();
+        if (box[0] <= 255u - box[2]) {                       // (a kept cluster has points; an empty box keeps the whole image)
+            wr0 = max(0, (int)box[0] - 4); wc0 = max(0, (int)box[1] - 4);
+            wh = min(A.h, (int)(255u - box[2]) + 5) - wr0; ww = min(A.w, (int)(255u - box[3]) + 5) - wc0;
+        }
         if (A.op_close) {
             // grey CLOSE with a 5x5 rectangle = separable max (dilate) then separable min (erode);
             // out-of-image samples are ignored
-            close_pass<true, true>(m0, m1, A.h, A.w);      // dilate: rows then columns
+            close_pass<true, true>(m0, m1, A.w, wr0, wc0, wh, ww);      // dilate: rows then columns
             __syncthreads();
-            close_pass<true, false>(m1, m0, A.h, A.w);
+            close_pass<true, false>(m1, m0, A.w, wr0, wc0, wh, ww);
             __syncthreads();
-            close_pass<false, true>(m0, m1, A.h, A.w);     // erode
+            close_pass<false, true>(m0, m1, A.w, wr0, wc0, wh, ww);     // erode
             __syncthreads();
-            close_pass<false, false>(m1, m0, A.h, A.w);
+            close_pass<false, false>(m1, m0, A.w, wr0, wc0, wh, ww);
             __syncthreads();
         }
         copy_bytes(map, m0, hw);
@@ -2332,8 +2349,10 @@ __device__ __forceinline__ void finish_body(const TailArgs &A) {
     __syncthreads();
     // centroid of the non-zero pixels of the final map
     unsigned long long cnt = 0, sr = 0, sc = 0;
-    for (int i = tid; i < hw; i += TB)
-        if (m0[i]) { uint32_t c; const uint32_t r = fdivmod((uint32_t)i, A.dW, c); ++cnt; sr += r; sc += c; }
+    for (int i = tid; i < wh * ww; i += TB) {                // (outside the window the map is zero)
+        const int r = wr0 + i / ww, c = wc0 + i % ww;
+        if (m0[r * A.w + c]) { ++cnt; sr += (uint32_t)r; sc += (uint32_t)c; }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o); sr += __shfl_xor(sr, o); sc += __shfl_xor(sc, o); }
     if ((tid & 63) == 0) { red[tid >> 6] = cnt; red[NW16 + (tid >> 6)] = sr; red[2 * NW16 + (tid >> 6)] = sc; }

@@ -104,10 +104,26 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     }
     return v;
 }
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// wave-wide inclusive prefix sum (64 lanes) as six DPP-fused additions: a Hillis-Steele scan inside every row of 16
+// lanes (row_shr 1, 2, 4, 8; lanes without a source add 0), then the row totals are carried into the rows above
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add_u32(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v = dpp_add_u32<0x111, 0xF>(v);
+    v = dpp_add_u32<0x112, 0xF>(v);
+    v = dpp_add_u32<0x114, 0xF>(v);
+    v = dpp_add_u32<0x118, 0xF>(v);
+    v = dpp_add_u32<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_add_u32<0x143, 0xC>(v);      // row_bcast:31 into rows 2 and 3
     return v;
+}
+
+// sum over the wavefront, in every lane (six DPP additions and a read-lane: the butterfly of six ds_bpermute round trips it
+// replaces was most of a bisection step in k_core's phase 3)
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    return __builtin_amdgcn_readlane((int)wave_incl_scan_u32((uint32_t)v), 63);
 }
 
 template <typename T>
@@ -328,6 +344,40 @@ __global__ __launch_bounds__(TB) void k_compact(TailArgs A) { compact_body(A); }
 //  3. points with fewer than k neighbours within RING_R: wave-wide bisection on the count
 //     of points within distance t over all N points.
 // --------------------------------------------------------------------------------------
+// k_core phase 3, maps of up to 64 * NI points: the smallest t with #{d2 <= t} >= k + 1 (self included) for the point (r, c),
+// by bisection over the point's distances to all N points held in registers (NI per lane)
+template <int NI>
+__device__ __forceinline__ uint32_t core_kth_regs(const uint16_t *rcl, int N, int r, int c, int k, uint32_t lo, uint32_t hi) {
+    const int lane = threadIdx.x & 63;
+    uint32_t d[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int j = lane + 64 * i;
+        d[i] = 0xFFFFFFFFu;
+        if (j < N) {
+            const uint32_t u = rcl[j];
+            const int dr = (int)(u & 255) - r, dc = (int)(u >> 8) - c;
+            d[i] = (uint32_t)(dr * dr + dc * dc);
+        }
+    }
+    auto enough = [&](uint32_t t) -> bool {
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) cnt += d[i] <= t;
+        return wave_sum_i32(cnt) >= k + 1;
+    };
+    // the answer is usually within a few times the lower bound, the upper bound is the image diagonal: gallop first
+    for (uint32_t t = 2 * lo; t < hi; t *= 2) {
+        if (enough(t)) { hi = t; break; }
+        lo = t + 1;
+    }
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (enough(mid)) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
 __device__ __forceinline__ void core_body(const TailArgs &A) {
     const int f = A.order[blockIdx.x];
     uint8_t *ws = A.ws + (size_t)(A.slot0 + (int)blockIdx.x) * A.ws_stride;
@@ -461,27 +511,11 @@ __device__ __forceinline__ void core_body(const TailArgs &A) {
         const int r = v & 255, c = (v >> 8) & 255;
         uint32_t lo = RING_R * RING_R + 1, hi = maxd;         // smallest t with #{d2 <= t} >= k+1 (self included)
         if (in_lds && N <= 64 * 32) {
-            // all N distances of this point in registers (32 per lane), the bisection then touches no memory
-            uint32_t d[32];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int j = lane + 64 * i;
-                d[i] = 0xFFFFFFFFu;
-                if (j < N) {
-                    const uint32_t u = rcl[j];
-                    const int dr = (int)(u & 255) - r, dc = (int)(u >> 8) - c;
-                    d[i] = (uint32_t)(dr * dr + dc * dc);
-                }
-            }
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                int cnt = 0;
-#pragma unroll
-                for (int i = 0; i < 32; ++i) cnt += d[i] <= mid;
-                cnt = wave_sum_i32(cnt);
-                if (cnt >= k + 1) hi = mid; else lo = mid + 1;
-            }
-            if (lane == 0) core[p] = lo;
+            // all N distances of this point in registers (8, 16, 24 or 32 per lane), the bisection then touches no memory
+            const int ni = (N + 63) >> 6;
+            const uint32_t ans = ni <= 8 ? core_kth_regs<8>(rcl, N, r, c, k, lo, hi) : ni <= 16 ? core_kth_regs<16>(rcl, N, r, c, k, lo, hi)
+                               : ni <= 24 ? core_kth_regs<24>(rcl, N, r, c, k, lo, hi) : core_kth_regs<32>(rcl, N, r, c, k, lo, hi);
+            if (lane == 0) core[p] = ans;
             continue;
         }
         while (lo < hi) {
@@ -764,22 +798,6 @@ __device__ __forceinline__ uint32_t wave_prefix_min_u32(uint32_t v) {
     v = dpp_min_u32<0x118, 0xF>(v);
     v = dpp_min_u32<0x142, 0xA>(v);
     v = dpp_min_u32<0x143, 0xC>(v);
-    return v;
-}
-
-// wave-wide inclusive prefix sum (64 lanes) as six DPP-fused additions: a Hillis-Steele scan inside every row of 16
-// lanes (row_shr 1, 2, 4, 8; lanes without a source add 0), then the row totals are carried into the rows above
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_add_u32(uint32_t v) {
-    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-    v = dpp_add_u32<0x111, 0xF>(v);
-    v = dpp_add_u32<0x112, 0xF>(v);
-    v = dpp_add_u32<0x114, 0xF>(v);
-    v = dpp_add_u32<0x118, 0xF>(v);
-    v = dpp_add_u32<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
-    v = dpp_add_u32<0x143, 0xC>(v);      // row_bcast:31 into rows 2 and 3
     return v;
 }
 

@@ -29,6 +29,7 @@ for i in range(0, 32, 6):
     h = st['hdr']
     print('  map %2d: N=%5d clusters %3d  stamps (us, 100 MHz wall clock): k_sort %.1f | k_tree built %.1f hierarchy %.1f chosen %.1f | '
           'k_finish %.1f | k_prim %.1f' % (i, st['n'], h[4], h[8] / 100.0, h[13] / 100.0, h[9] / 100.0, h[10] / 100.0, h[11] / 100.0, h[12] / 100.0))
+    print('           k_core stamps (us): phase 1 (thread per point, inner ring) %.1f, phase 2 (wavefront per point) %.1f, end %.1f' % (h[5] / 100.0, h[6] / 100.0, h[7] / 100.0))
     if h[23]:
         print('           k_tree_par stamps (us): loaded %.1f nearest-greater %.1f clusters %.1f jumped %.1f tops %.1f | rows %.1f stabilities %.1f labels+kept %.1f' % tuple(
             x / 100.0 for x in list(h[25:30]) + [h[13], h[9], h[10]]))

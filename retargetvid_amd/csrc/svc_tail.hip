@@ -136,12 +136,7 @@ __device__ __forceinline__ T *carve(uint8_t *&p, size_t count) {
 // exclusive prefix sum of one int per thread over the 1024-thread block; total in *tot
 __device__ __forceinline__ int block_excl_scan(int v, int *lds16, int *tot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
+    const int inc = (int)wave_incl_scan_u32((uint32_t)v);      // (six DPP additions; was six ds_bpermute round trips)
     if (lane == 63) lds16[wave] = inc;
     __syncthreads();
     int base = 0, total = 0;
@@ -1226,7 +1221,7 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
                 }
                 if (lane >= ncand) sl = make_uint2(LVL_NONE, LVL_NONE);
                 const uint32_t pend = wave_prefix_min_u32(sl.y);
-                const uint32_t nextf = (uint32_t)__shfl_down((int)mycand, 1);
+                const uint32_t nextf = (uint32_t)__builtin_amdgcn_update_dpp((int)mycand, (int)mycand, 0x130, 0xF, 0xF, false);   // wave_shl:1 = the next lane's candidate
                 const bool stop = lane < ncand && (sl.x != LVL_NONE || (lane + 1 < ncand && pend < nextf));
                 const unsigned long long bal = __ballot(stop);
                 a = bal ? __builtin_ctzll(bal) + 1 : ncand;
@@ -1234,7 +1229,7 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
                 dropped = m2 != LVL_NONE;
             }
             // ---- commit: edges, tree membership, F
-            const uint32_t prevc = (uint32_t)__shfl_up((int)mycand, 1);
+            const uint32_t prevc = (uint32_t)__builtin_amdgcn_update_dpp((int)mycand, (int)mycand, 0x138, 0xF, 0xF, false);       // wave_shr:1 = the previous lane's
             if (wave == 0 && lane < a) {
                 const uint32_t from = lane == 0 ? cur : prevc;
                 mst[cnt - 1 + lane] = hdb::Edge{(uint16_t)from, (uint16_t)mycand, m};
@@ -2371,8 +2366,10 @@ __device__ __forceinline__ void finish_body(const TailArgs &A) {
         const int r = wr0 + i / ww, c = wc0 + i % ww;
         if (m0[r * A.w + c]) { ++cnt; sr += (uint32_t)r; sc += (uint32_t)c; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o); sr += __shfl_xor(sr, o); sc += __shfl_xor(sc, o); }
+    // (a thread sees at most hw / TB + 1 pixels: the wavefront's sums fit 32 bits)
+    cnt = (unsigned long long)(uint32_t)wave_sum_i32((int)cnt);
+    sr = (unsigned long long)(uint32_t)wave_sum_i32((int)sr);
+    sc = (unsigned long long)(uint32_t)wave_sum_i32((int)sc);
     if ((tid & 63) == 0) { red[tid >> 6] = cnt; red[NW16 + (tid >> 6)] = sr; red[2 * NW16 + (tid >> 6)] = sc; }
     __syncthreads();
     if (tid == 0) {

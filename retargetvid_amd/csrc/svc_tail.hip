@@ -285,8 +285,23 @@ __global__ __launch_bounds__(256) void k_centre_argmax(const uint8_t *__restrict
 // map <-> LDS copies, 8 bytes per lane when the map allows it (a 140x250 map does), bytes otherwise
 __device__ __forceinline__ void copy_bytes(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int n) {
     if ((((uintptr_t)src | (uintptr_t)dst) & 7) == 0) {
+        // eight loads of a thread in flight before the first store: written as one load and one store per iteration, a map
+        // (35 000 bytes, 4.3 words per thread) costs a memory round trip per word -- 5 x ~1.5 us at the head of k_compact,
+        // k_core and k_finish each
         const int n8 = n >> 3;
-        for (int i = threadIdx.x; i < n8; i += TB) ((uint2 *)dst)[i] = ((const uint2 *)src)[i];
+        for (int i0 = threadIdx.x; i0 < n8; i0 += 8 * TB) {
+            uint2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * TB;
+                v[u] = i < n8 ? ((const uint2 *)src)[i] : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * TB;
+                if (i < n8) ((uint2 *)dst)[i] = v[u];
+            }
+        }
         for (int i = (n8 << 3) + threadIdx.x; i < n; i += TB) dst[i] = src[i];
     } else {
         for (int i = threadIdx.x; i < n; i += TB) dst[i] = src[i];

@@ -141,6 +141,20 @@ def test_videos_in_flight_equal_sequential_runs(engine):
             assert a[r][0]['bbs'] == b[r][0]['bbs'] and a[r][0]['dx'] == b[r][0]['dx']
 
 
+def test_videos_in_flight_with_the_tail_inside_the_ingest(engine):
+    """S.crop_videos(stream_batch=): several videos in flight, each with its tail inside the ingest (16 maps per call) -- same
+    windows as sequential whole-video calls, for both parameter sets (the best-settings set reads the filtered maps back
+    for its focus stability)."""
+    for best in (False, True):
+        CP = S.sc_init_crop_params(use_best_settings=best)
+        vids = [_video(60 + 9 * k, 40 + k, [0, 21 + k, 60 + 9 * k]) for k in range(6)]
+        seq = [S.smart_vid_crop_ratios(v, CP, ('1:3', '3:1'), engine=engine) for v in vids]
+        par = S.crop_videos([(lambda v=v: v) for v in vids], CP, ('1:3', '3:1'), workers=3, stream_batch=16)
+        for a, b in zip(seq, par):
+            for r in ('1:3', '3:1'):
+                assert a[r][0]['bbs'] == b[r][0]['bbs'] and a[r][0]['dx'] == b[r][0]['dx']
+
+
 def test_evaluator_iou_within_1e4_of_the_oracle_on_ten_videos(engine, synthetic_sd, tmp_path):
     """north_star's second tolerance: the evaluator's IoU numbers (retargetvid_eval.py:133-283: per-frame IoU ->
     per-video mean -> per-annotator mean -> worst / best / mean) computed from the GPU path's crop windows and from

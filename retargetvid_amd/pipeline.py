@@ -45,20 +45,29 @@ class StreamPipeline:
     construction, or `stream`)."""
 
     def __init__(self, engine, CP, sal_h, sal_w, batch=32, ring_batches=8, max_span_batches=3, stream=None, depth=2,
-                 maps_out=None, timing=False):
+                 maps_out=None, timing=False, ring=None):
         """maps_out: uint8 CUDA [>= number of maps, h, w]: every filtered map is copied to maps_out[stream index] when
         it is final (VD['smaps']).  timing: HIP events around the network and tail phases of every submit_frames call
-        (phase_ms())."""
+        (phase_ms()).  ring: the caller's own map storage, uint8 CUDA [rows, h, w] holding the WHOLE stream (row = stream
+        index): nothing wraps, a finished map stays where it is (the multi-video scheduler, retargetvid_amd/scheduler.py:
+        a video's filtered maps are a slice of it), and a call may bring more than `batch` maps."""
         import torch
         self.eng, self.CP, self.h, self.w, self.batch = engine, CP, int(sal_h), int(sal_w), int(batch)
         self.dev = engine.device
         self.stream = stream if stream is not None else torch.cuda.current_stream(self.dev)
-        self.cap = int(ring_batches) * self.batch
         self.max_span = int(max_span_batches) * self.batch
-        assert self.cap >= self.max_span + self.batch
-        self.ring = torch.empty((self.cap, self.h, self.w), dtype=torch.uint8, device=self.dev)
+        self.external = ring is not None
+        if self.external:
+            assert ring.is_cuda and ring.dtype == torch.uint8 and tuple(ring.shape[1:]) == (self.h, self.w) and ring.is_contiguous()
+            self.ring, self.cap = ring, int(ring.shape[0])
+            xy_rows = self.max_span + 2 * self.batch + 64     # a call's span: what is carried + what it brings
+        else:
+            self.cap = int(ring_batches) * self.batch
+            assert self.cap >= self.max_span + self.batch
+            self.ring = torch.empty((self.cap, self.h, self.w), dtype=torch.uint8, device=self.dev)
+            xy_rows = self.cap
         self.depth = max(1, int(depth))
-        self._xy = [torch.empty((self.cap, 2), dtype=torch.float64).pin_memory() for _ in range(self.depth + 1)]
+        self._xy = [torch.empty((xy_rows, 2), dtype=torch.float64).pin_memory() for _ in range(self.depth + 1)]
         self._ev = [torch.cuda.Event() for _ in range(self.depth + 1)]
         self.maps_out = maps_out
         self.timing = bool(timing)
@@ -77,9 +86,13 @@ class StreamPipeline:
     # ---- feeding ------------------------------------------------------------------------------------------------
     def slot_for(self, n):
         """Ring rows for the next n maps (the caller may write raw saliency maps there itself: `out=` of ops.saliency)."""
-        assert 0 < n <= self.batch
         import torch
         end = self.base + len(self.states)
+        if self.external:
+            if n <= 0 or end + n > self.cap or n > 2 * self.batch + 64:
+                raise ValueError('StreamPipeline: %d maps do not fit the caller\'s map storage (row %d of %d)' % (n, end, self.cap))
+            return self.ring[end:end + n]
+        assert 0 < n <= self.batch
         if end + n > self.cap:                          # wrap: the open span moves to the front of the ring
             k = len(self.states)
             assert k + n <= self.cap
@@ -116,8 +129,14 @@ class StreamPipeline:
             dst.copy_(maps)
         return self._call(n, blend_next)
 
+    def submit_rows(self, n, blend_next):
+        """The caller has written n thresholded maps into slot_for(n) on this pipeline's stream itself."""
+        return self._call(int(n), blend_next)
+
     def _call(self, n_new, blend_next, flush=False, timed=False):
         import torch
+        if len(self.calls) >= self.depth:               # checked before any state changes: collect() and retry is safe
+            raise RuntimeError('StreamPipeline: collect() the oldest call before submitting another (depth %d)' % self.depth)
         if n_new:
             bn = [bool(v) for v in blend_next]
             assert len(bn) == n_new
@@ -130,8 +149,6 @@ class StreamPipeline:
             flush = True                                # chains too long to carry: this call runs them out in rounds
         flags, done = plan_call(self.states, self.bnext, flush)
         k = len(self.states)
-        if len(self.calls) >= self.depth:
-            raise RuntimeError('StreamPipeline: collect() the oldest call before submitting another (depth %d)' % self.depth)
         slot = self.n_calls % (self.depth + 1)
         with torch.cuda.stream(self.stream):
             xy = self.eng.cluster_center_(self.ring[self.base:self.base + k], flags, self.CP)
@@ -177,6 +194,22 @@ class StreamPipeline:
             self._phase[2] += 1
         xy = self._xy[slot].numpy()
         return [(g, float(xy[i, 0]), float(xy[i, 1])) for i, g in rows]
+
+    def collect_arrays(self):
+        """collect() without the per-map Python objects -> (stream indices int64 [m], centres float64 [m, 2]; NaN = none)."""
+        if not self.calls:
+            return np.empty(0, np.int64), np.empty((0, 2), np.float64)
+        slot, rows, timed = self.calls.pop(0)
+        self._ev[slot].synchronize()
+        if timed:
+            t = self._tev[slot]
+            self._phase[0] += t[0].elapsed_time(t[1])
+            self._phase[1] += t[1].elapsed_time(t[2])
+            self._phase[2] += 1
+        if not rows:
+            return np.empty(0, np.int64), np.empty((0, 2), np.float64)
+        r = np.asarray(rows, np.int64)
+        return r[:, 1], self._xy[slot].numpy()[r[:, 0]].copy()
 
     def flush(self):
         """Enqueues the call that runs out whatever is still carried (in rounds) without waiting for it; -> results

@@ -1,0 +1,323 @@
+"""Job-level scheduler: MANY videos through the saliency-to-crop path as ONE stream of frames per HIP stream.
+
+The reference's driver loop (smartVidCrop.py:2722-2790) crops one video after the other, and so did this package's
+crop_videos: a video of 105 selected frames is 32 + 32 + 32 + 9 frames for the network (the last piece 28 % full), every
+video pays its own shot-start tail rounds, and its host stages run between two videos' device work.  Here the selected
+frames of consecutive videos form one stream per lane (lane = engine + HIP stream):
+
+  * the network always gets full chunks of `chunk` frames, packed ACROSS video boundaries (a frame's map does not depend
+    on its neighbours in the chunk);
+  * the maps of a lane live in one device tensor in stream order; a video boundary is just a shot start: the cut-blend
+    flags of a video end with two zeros (smartVidCrop.py:2324-2327: `i < fc_sel - 2`), so nothing is blended across it,
+    and the all-zero map the reference's off-by-one gives the last selected frame of every read batch (:408-453) is a row
+    the network never writes;
+  * threshold, cluster filter, cut blend and centres follow every chunk on the lane's stream through
+    pipeline.StreamPipeline (ONE tail round per call, blend chains carried over to the next call), whatever the videos
+    in the chunk;
+  * when the last centre of a video has arrived its host stages (smartVidCrop.after_ingest: empty-centre fill,
+    interpolation, low-pass, LOESS, boxes -- native code behind temporal.py, which releases the interpreter lock) run on
+    a small thread pool while the feeder keeps the lanes busy.
+
+One feeder thread drives all lanes round-robin (a lane takes the next video from the common queue when it runs low), so
+the low-occupancy tail of one lane overlaps the full-chip network of the others, as bench.py's batches do.  Every video's
+result equals smartVidCrop.smart_vid_crop_ratios on that video alone (tests/test_gpu_scheduler.py).
+
+Host logic + torch plumbing only; device work goes through ops.Engine (the C ABI)."""
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import smartVidCrop as S
+
+
+class _Video:
+    __slots__ = ('idx', 'video', 'plan', 'lane', 'row0', 'xy', 'remaining', 'maps', 'pos', 'done')
+
+    def __init__(self, idx, video, plan):
+        self.idx, self.video, self.plan = idx, video, plan
+        self.xy = np.full((plan['n_sel'], 2), np.nan)
+        self.remaining = plan['n_sel']
+        self.pos = 0                       # next selected frame to take in
+        self.maps = None
+        self.done = False
+
+
+class _Lane:
+    """One engine + HIP stream + map storage; frames and maps of consecutive videos in stream order."""
+
+    def __init__(self, sched, engine, stream, k):
+        self.sched, self.eng, self.stream, self.k = sched, engine, stream, k
+        self.geom = None
+        self.cur = None                    # video being taken in
+        self.videos = {}                   # slot -> _Video with maps in this lane's storage
+        self.next_slot = 0
+        self.pipe = None
+        self.exhausted = False
+        self.cap = 0                       # no storage yet: the first video allocates it
+        self.frames_in = self.frames_done = self.rows_in = self.rows_called = 0
+
+    # ---- storage ----------------------------------------------------------------------------------------------------
+    def _alloc(self, sal_h, sal_w, min_rows):
+        import torch
+        from . import pipeline as _pl
+        sc = self.sched
+        rows = max(sc.lane_rows, min_rows)
+        self.geom = (sal_h, sal_w)
+        dev = self.eng.device
+        with torch.cuda.stream(self.stream):
+            self.small = torch.empty((rows, sal_h, sal_w, 3), dtype=torch.uint8, device=dev)     # network input frames, in order
+            self.maps = torch.zeros((rows, sal_h, sal_w), dtype=torch.uint8, device=dev)         # stream rows (zero rows stay zero)
+            self.tmp = torch.empty((sc.chunk, sal_h, sal_w), dtype=torch.uint8, device=dev)
+        self.cap = rows
+        self.row_of_frame = np.empty(rows, np.int64)
+        self.flags = np.zeros(rows, np.uint8)
+        self.vid_of_row = np.empty(rows, np.int32)
+        self.local_of_row = np.empty(rows, np.int32)
+        self.frames_in = self.frames_done = self.rows_in = self.rows_called = 0
+        self.pipe = _pl.StreamPipeline(self.eng, sc.CP, sal_h, sal_w, batch=sc.chunk, stream=self.stream, depth=sc.depth,
+                                       ring=self.maps)
+
+    # ---- intake -----------------------------------------------------------------------------------------------------
+    def _start_video(self, v):
+        """Room for the whole video in this lane's storage (a video never straddles two storages: its blend chains and
+        its filtered maps stay in one)."""
+        plan = v.plan
+        geom = (plan['sal_h'], plan['sal_w'])
+        if self.geom != geom or self.rows_in + plan['n_sel'] > self.cap:
+            self.drain()
+            self._alloc(geom[0], geom[1], plan['n_sel'])
+        v.lane, v.row0 = self, self.rows_in
+        v.maps = self.maps[v.row0:v.row0 + plan['n_sel']]
+        slot = self.next_slot
+        self.next_slot += 1
+        self.videos[slot] = v
+        n = plan['n_sel']
+        r0 = self.rows_in
+        self.flags[r0:r0 + n] = plan['flags'] if plan['flags'] is not None else 0
+        self.vid_of_row[r0:r0 + n] = slot
+        self.local_of_row[r0:r0 + n] = np.arange(n, dtype=np.int32)
+        self.cur = v
+
+    def _take_piece(self):
+        """The next piece of the current video: down-scaled frames behind the lane's frames, their rows behind its rows."""
+        import torch
+        v, plan, sc = self.cur, self.cur.plan, self.sched
+        frames = v.video['frames']
+        n = plan['n_sel']
+        per = max(sc.chunk, min(sc.piece_frames, sc.piece_bytes // max(1, plan['h'] * plan['w'] * 3)))
+        m = min(per, n - v.pos)
+        loc = np.arange(v.pos, v.pos + m)
+        net = loc[~plan['zero_map'][v.pos:v.pos + m]]
+        if len(net):
+            idx = [plan['true_inds'][j] for j in net]
+            with torch.cuda.stream(self.stream):
+                small = S._small_frames(self.eng, frames, idx, plan['sal_h'], plan['sal_w'], self.eng.device)
+                self.small[self.frames_in:self.frames_in + len(net)].copy_(small)
+            self.row_of_frame[self.frames_in:self.frames_in + len(net)] = v.row0 + net
+            self.frames_in += len(net)
+        self.rows_in += m
+        v.pos += m
+        if v.pos >= n:
+            self.cur = None
+
+    def _fill(self):
+        """Frames for at least one full chunk, as long as the job has any."""
+        sc = self.sched
+        while self.frames_in - self.frames_done < sc.chunk:
+            if self.cur is None:
+                v = sc._next_video(self)
+                if v is None:
+                    self.exhausted = True
+                    return
+                self._start_video(v)
+            self._take_piece()
+
+    # ---- one chunk --------------------------------------------------------------------------------------------------
+    def step(self):
+        """Takes in what is needed and enqueues one network chunk + its tail call.  -> False when the lane has nothing left."""
+        import torch
+        sc = self.sched
+        if not self.exhausted:
+            self._fill()
+        if self.pipe is None:
+            return False
+        k = min(sc.chunk, self.frames_in - self.frames_done)
+        if k == 0 and self.rows_in == self.rows_called:
+            return False
+        if len(self.pipe.calls) >= self.pipe.depth:
+            sc._dispatch(self, *self.pipe.collect_arrays())
+        f0 = self.frames_done
+        # rows of this call: up to (not including) the row of the next frame the network has not seen
+        R = int(self.row_of_frame[f0 + k]) if f0 + k < self.frames_in else self.rows_in
+        n_rows = R - self.rows_called
+        dst = self.pipe.slot_for(n_rows)
+        with torch.cuda.stream(self.stream):
+            if k:
+                rows = self.row_of_frame[f0:f0 + k]
+                r0 = int(rows[0])
+                if int(rows[-1]) - r0 + 1 == k:                       # no zero row inside: the network writes in place
+                    self.eng.saliency(self.small[f0:f0 + k], out=self.maps[r0:r0 + k])
+                else:
+                    self.eng.saliency(self.small[f0:f0 + k], out=self.tmp[:k])
+                    brk = np.flatnonzero(np.diff(rows) != 1) + 1
+                    a = 0
+                    for b in list(brk) + [k]:                         # runs of consecutive rows
+                        ra = int(rows[a])
+                        self.maps[ra:ra + (b - a)].copy_(self.tmp[a:b])
+                        a = int(b)
+            self.eng.threshold_(dst, sc.CP['t_threshold'])
+        self.pipe.submit_rows(n_rows, self.flags[self.rows_called:R])
+        self.frames_done += k
+        self.rows_called = R
+        sc.n_chunks += 1
+        sc.n_net_frames += k
+        return True
+
+    def flush(self):
+        """Enqueues the call that runs out what is still carried, without waiting for it."""
+        p = self.pipe
+        if p is not None:
+            while len(p.calls) >= p.depth:
+                self.sched._dispatch(self, *p.collect_arrays())
+            p.flush()
+
+    def finish(self):
+        if self.pipe is not None:
+            self.flush()
+            while self.pipe.calls:
+                self.sched._dispatch(self, *self.pipe.collect_arrays())
+            self.pipe.finish()
+
+    def drain(self):
+        """Runs out everything this lane holds (its storage is about to be replaced)."""
+        if self.pipe is None:
+            return
+        while self.frames_in > self.frames_done or self.rows_in > self.rows_called:
+            ex, self.exhausted = self.exhausted, True         # no intake while draining
+            self.step()
+            self.exhausted = ex
+        self.finish()
+        self.pipe = None
+        self.geom = None
+
+
+class JobScheduler:
+    """crop_videos' engine room.  ``videos``: sequence of ingest_pickle dicts or zero-argument callables producing them."""
+
+    def __init__(self, CP, ratios=None, lanes=4, chunk=32, state_dict=None, seed=0, engines=None, shot_net=None,
+                 host_threads=3, depth=2, lane_rows=8192, piece_frames=256, piece_bytes=256 << 20):
+        import torch
+        from . import ops as _ops
+        if CP['exit_on_spread_sal'] or CP['exit_on_low_cvrg'] or CP['t_border'] != -1:
+            raise NotImplementedError('mean-saliency / coverage gates and border detection are disabled in both '
+                                      'published parameter sets and are not part of this path')
+        self.CP = CP
+        self.ratios = tuple(ratios) if ratios else (CP['out_ratio'],)
+        self.chunk, self.depth, self.lane_rows = int(chunk), int(depth), int(lane_rows)
+        self.piece_frames, self.piece_bytes = int(piece_frames), int(piece_bytes)
+        self.shot_net = shot_net
+        self.dev = torch.device('cuda', torch.cuda.current_device())
+        self.own_engines = engines is None
+        if engines is None:
+            if state_dict is None:                               # built once, not once per lane
+                from . import weights as _weights
+                state_dict = _weights.make_synthetic_state_dict(seed)
+            engines = [_ops.Engine(state_dict, device=self.dev.index, seed=seed) for _ in range(max(1, int(lanes)))]
+        self.engines = list(engines)
+        self.streams = [torch.cuda.Stream(device=self.dev) for _ in self.engines]
+        self.pool = ThreadPoolExecutor(max_workers=max(1, int(host_threads)))
+        self.lock = threading.Lock()
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+        if self.own_engines:
+            for e in self.engines:
+                e.close()
+        self.engines = []
+
+    # ---- the job ------------------------------------------------------------------------------------------------------
+    def run(self, videos):
+        """-> list, in input order, of {ratio: (VD, smart_crop_results)}; each entry equals smart_vid_crop_ratios on that
+        video alone.  stats of the run in self.stats."""
+        import torch
+        self.videos = list(videos)
+        self.out = [None] * len(self.videos)
+        self.next_idx = 0
+        self.futures = []
+        self.n_chunks = self.n_net_frames = 0
+        t0 = time.perf_counter()
+        lanes = [_Lane(self, e, s, k) for k, (e, s) in enumerate(zip(self.engines, self.streams))]
+        if not self.CP['clust_filt']:
+            raise NotImplementedError('JobScheduler runs the cluster filter inside the stream (clust_filt=True, as in both '
+                                      'published parameter sets); use crop_videos(..., packed=False) otherwise')
+        with torch.cuda.device(self.dev):
+            live = list(lanes)
+            while live:
+                live = [ln for ln in live if ln.step()]
+            for ln in lanes:                                  # every lane's last call is enqueued before any is waited for
+                ln.flush()
+            for ln in lanes:
+                ln.finish()
+        t1 = time.perf_counter()
+        err = None
+        for f in self.futures:
+            try:
+                f.result()
+            except BaseException as e:                        # surfaced in the caller's thread
+                err = err or e
+        if err is not None:
+            raise err
+        t2 = time.perf_counter()
+        missing = [i for i, o in enumerate(self.out) if o is None]
+        if missing:
+            raise RuntimeError('JobScheduler: videos %r were never completed' % (missing[:8],))
+        self.stats = dict(videos=len(self.videos), chunks=self.n_chunks, network_frames=self.n_net_frames,
+                          mean_chunk_fill=self.n_net_frames / max(1, self.n_chunks) / self.chunk,
+                          seconds_device_side=t1 - t0, seconds_host_stage_drain=t2 - t1, lanes=len(lanes))
+        return self.out
+
+    # ---- feeder-side helpers ------------------------------------------------------------------------------------------
+    def _next_video(self, lane):
+        import torch
+        if self.next_idx >= len(self.videos):
+            return None
+        i = self.next_idx
+        self.next_idx += 1
+        with torch.cuda.stream(lane.stream):
+            v = self.videos[i]() if callable(self.videos[i]) else self.videos[i]
+            plan = S.plan_video(v, self.CP, engine=lane.eng, shot_net=self.shot_net)
+        return _Video(i, v, plan)
+
+    def _dispatch(self, lane, gids, xy):
+        """Centres of finished maps -> their videos; a video whose last centre arrived goes to the host-stage pool."""
+        if len(gids) == 0:
+            return
+        slots = lane.vid_of_row[gids]
+        loc = lane.local_of_row[gids]
+        for slot in np.unique(slots):
+            m = slots == slot
+            v = lane.videos[int(slot)]
+            v.xy[loc[m]] = xy[m]
+            v.remaining -= int(m.sum())
+            if v.remaining == 0 and not v.done:
+                v.done = True
+                del lane.videos[int(slot)]
+                self.futures.append(self.pool.submit(self._finish_video, v))
+
+    def _finish_video(self, v):
+        """Host stages of one video (pool thread)."""
+        S.sc_init_time()
+        VD = S._LazySmaps(S._ingest_dict(v.plan, v.maps, xy_stream=v.xy))
+        out = {}
+        base = None
+        for ratio in self.ratios:
+            cp = dict(self.CP, out_ratio=ratio)
+            if base is None:
+                base = S.after_ingest(VD, cp, v.lane.eng)
+                out[ratio] = base
+            else:
+                out[ratio] = S.other_ratio(base, cp)
+        self.out[v.idx] = out
+        v.video = None                     # the frames are not needed any more

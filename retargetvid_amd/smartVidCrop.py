@@ -344,6 +344,68 @@ def _small_frames(engine, frames, idx, sal_h, sal_w, dev):
     return feed.downscale(host, idx, sal_h, sal_w)
 
 
+def plan_video(video, crop_params, engine=None, shot_net=None):
+    """The ingest's host bookkeeping for one video dict (smartVidCrop.py:621-718, :740-758; the video path :379-399,
+    :452-456): frame selection, the selected-frame view of the shots, the cut-blend flags and which selected frames keep
+    an all-zero map (the last one of every read batch: the reference's off-by-one).  Shot detection runs here when the
+    dict has no ``trans_inds`` (device work on the current stream).  Shared by ingest_frames (one video at a time) and the
+    multi-video scheduler (retargetvid_amd/scheduler.py)."""
+    fr, frame_count, w, h = video['fr'], int(video['frame_count']), int(video['w']), int(video['h'])
+    frames = video['frames']              # ndarray / CUDA tensor [n,h,w,3] u8 RGB, or an object with __len__ and .select(idx)
+    n_frames = len(frames)
+    dsr = float(max(w, h)) / crop_params['max_input_d']
+    sal_h, sal_w = int(h / dsr), int(w / dsr)
+    trans_probs = None
+    if video.get('trans_inds') is None:
+        if shot_net is None:
+            raise ValueError('the video dict has no trans_inds: pass shot_net= (a transnetv1_handler.ShotTransNet) to run shot '
+                             'detection inside the ingest, as the reference\'s video path does')
+        shots = detect_shots(frames, fr, crop_params, net=shot_net, engine=engine, trans_threshold=TRANS_THRESHOLD)
+        trans_probs = shots['trans_probs']
+        true_inds, map2orig, batches = _select_frames_video(n_frames, frame_count, trans_probs, TRANS_THRESHOLD,
+                                                            crop_params['skip'], crop_params['read_batch'])
+        seg = np.array(shots['segmentation'], dtype=np.int32)
+    else:
+        trans_inds = [int(v) for v in video['trans_inds']]
+        true_inds, map2orig, batches = _select_frames(n_frames, frame_count, trans_inds, crop_params['skip'],
+                                                      crop_params['read_batch'])
+        scenes = []
+        for i in range(len(trans_inds)):
+            if frame_count - trans_inds[i] < 2:
+                break
+            if i + 1 < len(trans_inds):
+                scenes.append([trans_inds[i], trans_inds[i + 1] - 1])
+        if not scenes:
+            raise ValueError('trans_inds %r yields no scenes; pass at least [0, frame_count]' % (trans_inds,))
+        seg = np.array(scenes, dtype=np.int32)
+    seg_sel = np.array([[map2orig[v] for v in row] for row in seg], dtype=np.int32)
+    n_sel = len(true_inds)
+    # the reference's sanity checks (:799-825), as exceptions
+    if n_frames > frame_count or len(map2orig) != n_frames or seg[-1][-1] != n_frames - 1 or \
+            seg_sel[-1][-1] != n_sel - 1 or map2orig[-1] != n_sel - 1:
+        raise ValueError('inconsistent frame / segment bookkeeping (frame_count=%d, frames=%d, segmentation end=%d)'
+                         % (frame_count, n_frames, int(seg[-1][-1])))
+    zero_map = np.zeros(n_sel, bool)
+    for first, cnt in batches:
+        if cnt:
+            zero_map[first + cnt - 1] = True
+    return dict(fr=fr, frame_count=frame_count, w=w, h=h, n_frames=n_frames, sal_h=sal_h, sal_w=sal_w, true_inds=true_inds,
+                map2orig=map2orig, batches=batches, seg=seg, seg_sel=seg_sel, n_sel=n_sel, trans_probs=trans_probs,
+                zero_map=zero_map, flags=blend_flags(n_sel, seg_sel) if crop_params['clust_filt'] else None)
+
+
+def _ingest_dict(plan, smaps, xy_stream=None):
+    """The dict the ingest hands on (the reference's vid_data after ingest_pickle, smartVidCrop.py:826-836)."""
+    vd = dict(smaps_dev=smaps, segmentation=plan['seg'], segmentation_sel=plan['seg_sel'], true_inds=plan['true_inds'],
+              inds_to_orig=plan['map2orig'], fr=plan['fr'], fc=plan['n_frames'], fc_sel=plan['n_sel'], h_orig=plan['h'],
+              w_orig=plan['w'], h_process=plan['sal_h'], w_process=plan['sal_w'])
+    if plan['trans_probs'] is not None:
+        vd['trans_probs'] = plan['trans_probs']
+    if xy_stream is not None:
+        vd['xy_stream'] = xy_stream
+    return vd
+
+
 def ingest_frames(video, crop_params, engine=None, verbose=False, shot_net=None, stream_batch=0):
     """Counterpart of ingest_pickle (smartVidCrop.py:560-836) for an in-memory video dict -- and, when the dict carries no
     ``trans_inds`` and a shot network is given (``shot_net``: transnetv1_handler.ShotTransNet), of the video path
@@ -361,38 +423,11 @@ def ingest_frames(video, crop_params, engine=None, verbose=False, shot_net=None,
     import torch
     engine = engine or get_engine()
     t = time.perf_counter()
-    fr, frame_count, w, h = video['fr'], int(video['frame_count']), int(video['w']), int(video['h'])
-    frames = video['frames']              # ndarray / CUDA tensor [n,h,w,3] u8 RGB, or an object with __len__ and .select(idx)
-    n_frames = len(frames)
-    dsr = float(max(w, h)) / crop_params['max_input_d']
-    sal_h, sal_w = int(h / dsr), int(w / dsr)
-    trans_probs = None
-    if video.get('trans_inds') is None:
-        if shot_net is None:
-            raise ValueError('the video dict has no trans_inds: pass shot_net= (a transnetv1_handler.ShotTransNet) to run shot '
-                             'detection inside the ingest, as the reference\'s video path does')
-        shots = detect_shots(frames, fr, crop_params, net=shot_net, engine=engine, trans_threshold=TRANS_THRESHOLD)
-        trans_probs = shots['trans_probs']
-        true_inds, map2orig, batches = _select_frames_video(n_frames, frame_count, trans_probs, TRANS_THRESHOLD,
-                                                            crop_params['skip'], crop_params['read_batch'])
-    else:
-        trans_inds = [int(v) for v in video['trans_inds']]
-        true_inds, map2orig, batches = _select_frames(n_frames, frame_count, trans_inds, crop_params['skip'],
-                                                      crop_params['read_batch'])
+    plan = plan_video(video, crop_params, engine=engine, shot_net=shot_net)
+    frames = video['frames']
+    true_inds, batches, seg_sel = plan['true_inds'], plan['batches'], plan['seg_sel']
+    sal_h, sal_w = plan['sal_h'], plan['sal_w']
     sc_register_time(t, '_read_shot_det')
-    if trans_probs is not None:
-        seg = np.array(shots['segmentation'], dtype=np.int32)
-    else:
-        scenes = []
-        for i in range(len(trans_inds)):
-            if frame_count - trans_inds[i] < 2:
-                break
-            if i + 1 < len(trans_inds):
-                scenes.append([trans_inds[i], trans_inds[i + 1] - 1])
-        if not scenes:
-            raise ValueError('trans_inds %r yields no scenes; pass at least [0, frame_count]' % (trans_inds,))
-        seg = np.array(scenes, dtype=np.int32)
-    seg_sel = np.array([[map2orig[v] for v in row] for row in seg], dtype=np.int32)
     t = time.perf_counter()
     n_sel = len(true_inds)
     dev = engine.device
@@ -400,7 +435,7 @@ def ingest_frames(video, crop_params, engine=None, verbose=False, shot_net=None,
     pipe, xy_stream, flags_all = None, None, None
     if stream_batch and crop_params['clust_filt']:
         from . import pipeline as _pl
-        flags_all = blend_flags(n_sel, seg_sel)
+        flags_all = plan['flags']
         cache = engine.__dict__.setdefault('_pipes', {})        # ring + pinned buffers are re-used from video to video
         key = (sal_h, sal_w, int(stream_batch), torch.cuda.current_stream(dev).cuda_stream)
         pipe = cache.get(key)
@@ -443,21 +478,7 @@ def ingest_frames(video, crop_params, engine=None, verbose=False, shot_net=None,
             xy_stream[g] = (x, y)
     torch.cuda.current_stream(dev).synchronize()      # the caller's stream only: other videos may be in flight on theirs
     sc_register_time(t, '_read_sal_det')
-    if trans_probs is not None:
-        vid_data_extra = dict(trans_probs=trans_probs)
-    else:
-        vid_data_extra = {}
-    if xy_stream is not None:
-        vid_data_extra['xy_stream'] = xy_stream
-    vid_data = dict(vid_data_extra, smaps_dev=smaps, segmentation=seg, segmentation_sel=seg_sel, true_inds=true_inds,
-                    inds_to_orig=map2orig, fr=fr, fc=n_frames, fc_sel=n_sel, h_orig=h, w_orig=w,
-                    h_process=sal_h, w_process=sal_w)
-    # the reference's sanity checks (:799-825), as exceptions
-    if vid_data['fc'] > frame_count or len(map2orig) != n_frames or seg[-1][-1] != n_frames - 1 or \
-            seg_sel[-1][-1] != n_sel - 1 or map2orig[-1] != n_sel - 1:
-        raise ValueError('inconsistent frame / segment bookkeeping (frame_count=%d, frames=%d, segmentation end=%d)'
-                         % (frame_count, n_frames, int(seg[-1][-1])))
-    return vid_data
+    return _ingest_dict(plan, smaps, xy_stream)
 
 
 def detect_shots(frames, fr, crop_params=None, net=None, engine=None, trans_threshold=0.1):
@@ -582,6 +603,19 @@ def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn=''
                 pickle.dump(out, fp)
     if callback_status is not None and callback_session is not None:
         callback_status(callback_session, 'sc', 'SC PROCESSING', 'smart-cropping main process')
+    VD, results = after_ingest(VD, CP, engine, verbose=verbose)
+    if callback_status is not None and callback_session is not None:
+        callback_status(callback_session, 'sc', 'SC RENDERING', 'smart-cropping rendering')
+    return VD, results
+
+
+def after_ingest(VD, CP, engine, verbose=False):
+    """Everything of smart_vid_crop behind the ingest (smartVidCrop.py:2293-2614 without the rendering): destination
+    size, threshold + cluster filter + centres on the device (skipped when the ingest or the multi-video scheduler has
+    run them already: VD['xy_stream']), then the host stages -- empty-centre fill, focus stability, interpolation,
+    low-pass, LOESS, boxes.  One function for the one-video call and for retargetvid_amd/scheduler.py, so that both give
+    the same windows by construction.  -> (VD, smart_crop_results)."""
+    results = {}
     VD['segm_backup'] = VD['segmentation'].copy()
 
     t = time.perf_counter()
@@ -643,8 +677,6 @@ def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn=''
         temporal.shift_time(VD['bbs'], CP['shift_time'])
         VD['bbs_np'] = np.asarray(VD['bbs'], np.int64)
     sc_register_time(t, '_shift')
-    if callback_status is not None and callback_session is not None:
-        callback_status(callback_session, 'sc', 'SC RENDERING', 'smart-cropping rendering')
 
     results['result'] = 'smart cropped'
     results['info'] = ' (%dx%d)->(%dx%d)->(%dx%d)->(%dx%d)\n' % (
@@ -668,39 +700,51 @@ def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn=''
 smartVidCrop = smart_vid_crop      # BASELINE.json's spelling of the entry point
 
 
+def other_ratio(base, cp):
+    """(VD, results) of ANOTHER target ratio from those of a finished run of the same video: nothing before
+    sc_calc_dest_size depends on out_ratio, so only destination size and boxes are recomputed."""
+    import copy
+    VD = _LazySmaps({k: (copy.copy(v) if isinstance(v, list) else v) for k, v in base[0].items()})
+    res = dict(base[1])
+    VD = sc_calc_dest_size(VD, cp)
+    VD['dxs'], VD['dys'] = list(base[0]['dxs_smooth']), list(base[0]['dys_smooth'])   # smoothing does not depend on the ratio
+    VD = sc_compute_bb(VD, cp)
+    if cp['shift_time'] > 0:
+        temporal.shift_time(VD['bbs'], cp['shift_time'])
+        VD['bbs_np'] = np.asarray(VD['bbs'], np.int64)
+    res['params'] = ''.join(' %-18s : %s\n' % (k, str(v)) for k, v in cp.items())
+    res['info'] = ' (%dx%d)->(%dx%d)->(%dx%d)->(%dx%d)\n' % (
+        VD['h_orig'], VD['w_orig'], VD['h_process'], VD['w_process'], VD['h_final'], VD['w_final'],
+        VD['fbb_h'], VD['fbb_w'])
+    return VD, res
+
+
 def smart_vid_crop_ratios(video_path, CP, ratios, engine=None, verbose=False, stream_batch=0):
     """Several target aspect ratios for one video with the saliency / clustering work done once
     (the reference's driver re-runs the whole pipeline per ratio, smartVidCrop.py:2722-2775, or
     re-uses its pickled feature cache :2244-2256).  -> {ratio: (VD, smart_crop_results)}; results
     are identical to calling smart_vid_crop once per ratio, because nothing before
     sc_calc_dest_size depends on out_ratio."""
-    import copy
     out = {}
     base = None
     for ratio in ratios:
         cp = dict(CP, out_ratio=ratio)
         if base is None:
-            VD, res = smart_vid_crop(video_path, cp, save_vid=False, engine=engine, verbose=verbose, stream_batch=stream_batch)
-            base = (VD, res)
+            base = smart_vid_crop(video_path, cp, save_vid=False, engine=engine, verbose=verbose, stream_batch=stream_batch)
+            out[ratio] = base
         else:
-            VD = _LazySmaps({k: (copy.copy(v) if isinstance(v, list) else v) for k, v in base[0].items()})
-            res = dict(base[1])
-            VD = sc_calc_dest_size(VD, cp)
-            VD['dxs'], VD['dys'] = list(base[0]['dxs_smooth']), list(base[0]['dys_smooth'])   # smoothing does not depend on the ratio
-            VD = sc_compute_bb(VD, cp)
-            if cp['shift_time'] > 0:
-                temporal.shift_time(VD['bbs'], cp['shift_time'])
-                VD['bbs_np'] = np.asarray(VD['bbs'], np.int64)
-            res['params'] = ''.join(' %-18s : %s\n' % (k, str(v)) for k, v in cp.items())
-            res['info'] = ' (%dx%d)->(%dx%d)->(%dx%d)->(%dx%d)\n' % (
-                VD['h_orig'], VD['w_orig'], VD['h_process'], VD['w_process'], VD['h_final'], VD['w_final'],
-                VD['fbb_h'], VD['fbb_w'])
-        out[ratio] = (VD, res)
+            out[ratio] = other_ratio(base, cp)
     return out
 
 
-def crop_videos(videos, CP, ratios=None, workers=3, state_dict=None, seed=0, stream_batch=0):
-    """Many videos on one GPU with ``workers`` of them in flight: every worker thread owns an engine
+def crop_videos(videos, CP, ratios=None, workers=4, state_dict=None, seed=0, stream_batch=0, packed=None, shot_net=None,
+                stats=None):
+    """Many videos on one GPU.  Default (``packed``, whenever the cluster filter is on): the job-level scheduler of
+    retargetvid_amd/scheduler.py -- ``workers`` lanes (engine + HIP stream), the selected frames of consecutive videos
+    packed into full network chunks across video boundaries, one tail round per chunk, host stages on a thread pool;
+    ``stats`` (a dict) receives the run's counters.  packed=False: the round-3 form described next.
+
+    ``workers`` videos in flight, one per worker thread: every worker thread owns an engine
     (weights + workspace) and a HIP stream and runs smart_vid_crop_ratios on its share, so the
     low-occupancy clustering tail and the host-side temporal stages of one video overlap the network of
     the next ones (what bench.py does with its batches).  ``videos``: a sequence of ingest_pickle dicts or
@@ -710,6 +754,18 @@ def crop_videos(videos, CP, ratios=None, workers=3, state_dict=None, seed=0, str
     import torch
     ratios = tuple(ratios) if ratios else (CP['out_ratio'],)
     videos = list(videos)
+    if packed is None:
+        packed = bool(CP['clust_filt'])
+    if packed:
+        from . import scheduler as _sched
+        js = _sched.JobScheduler(CP, ratios, lanes=max(1, int(workers)), state_dict=state_dict, seed=seed, shot_net=shot_net)
+        try:
+            out = js.run(videos)
+            if stats is not None:
+                stats.update(js.stats)
+        finally:
+            js.close()
+        return out
     workers = max(1, min(int(workers), len(videos) or 1))
     dev = torch.device('cuda', torch.cuda.current_device())
     from . import ops as _ops

@@ -131,14 +131,17 @@ def test_multi_ratio_run_equals_separate_calls_and_lazy_frames(engine):
 
 
 def test_videos_in_flight_equal_sequential_runs(engine):
-    """S.crop_videos (worker threads, one engine + stream each) returns exactly what sequential calls return."""
+    """S.crop_videos returns exactly what sequential calls return: the job-level scheduler (the default: frames of
+    consecutive videos packed into full network chunks, retargetvid_amd/scheduler.py) and the round-3 form (worker
+    threads, one video + engine + stream each)."""
     CP = S.sc_init_crop_params()
     vids = [_video(40 + 7 * k, 30 + k, [0, 17 + k, 40 + 7 * k]) for k in range(5)]
     seq = [S.smart_vid_crop_ratios(v, CP, ('1:3', '3:1'), engine=engine) for v in vids]
-    par = S.crop_videos([(lambda v=v: v) for v in vids], CP, ('1:3', '3:1'), workers=3)
-    for a, b in zip(seq, par):
-        for r in ('1:3', '3:1'):
-            assert a[r][0]['bbs'] == b[r][0]['bbs'] and a[r][0]['dx'] == b[r][0]['dx']
+    for packed in (True, False):
+        par = S.crop_videos([(lambda v=v: v) for v in vids], CP, ('1:3', '3:1'), workers=3, packed=packed)
+        for a, b in zip(seq, par):
+            for r in ('1:3', '3:1'):
+                assert a[r][0]['bbs'] == b[r][0]['bbs'] and a[r][0]['dx'] == b[r][0]['dx']
 
 
 def test_videos_in_flight_with_the_tail_inside_the_ingest(engine):
@@ -149,7 +152,7 @@ def test_videos_in_flight_with_the_tail_inside_the_ingest(engine):
         CP = S.sc_init_crop_params(use_best_settings=best)
         vids = [_video(60 + 9 * k, 40 + k, [0, 21 + k, 60 + 9 * k]) for k in range(6)]
         seq = [S.smart_vid_crop_ratios(v, CP, ('1:3', '3:1'), engine=engine) for v in vids]
-        par = S.crop_videos([(lambda v=v: v) for v in vids], CP, ('1:3', '3:1'), workers=3, stream_batch=16)
+        par = S.crop_videos([(lambda v=v: v) for v in vids], CP, ('1:3', '3:1'), workers=3, stream_batch=16, packed=False)
         for a, b in zip(seq, par):
             for r in ('1:3', '3:1'):
                 assert a[r][0]['bbs'] == b[r][0]['bbs'] and a[r][0]['dx'] == b[r][0]['dx']

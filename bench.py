@@ -40,6 +40,11 @@ Rank 0 prints ONE JSON line.  `roofline` describes the kernel class that takes t
                            traffic_source; not re-measured by this run)
 `cpu_baseline` is the oracle (CPU restatement of the same path) timed on this node's host cores on a bounded
 sample of the same workload.
+`config.config3` (BENCH_CONFIG3=0 skips it) is BASELINE.json's configs[2] run ONCE MORE OUTSIDE the timed region through the
+product's job code: the 200-video RetargetVid-shaped synthetic set (real frame counts, 1:3 and 3:1), videos sharded over the
+ranks (dist.crop_job), every rank's share through the job-level scheduler (retargetvid_amd/scheduler.py: frames of
+consecutive videos packed into full 32-frame chunks), boxes all_gathered, scored by the evaluator counterpart.  The frames
+the job selects are generated before its clock starts and lie in HBM, like this benchmark's own batch.
 """
 import argparse
 import json
@@ -168,6 +173,78 @@ def cpu_baseline(sd, frames_u8, CP, flags):
     return n / dt, dt
 
 
+def config3_job(world, rank, dist_on, dev, sd, lanes, rccl_init_s):
+    """BASELINE configs[2] through the product's job code, timed between barriers (slowest rank).  -> dict for rank 0."""
+    from retargetvid_amd import evaluate as E, scheduler
+    folder = os.path.join(ROOT, 'tests', 'golden', 'retargetvid')
+    fcs = E.frame_counts(folder)
+    vids = list(E.VID_INDS)
+    counts = [fcs[v] for v in vids]
+    CP = S.sc_init_crop_params()
+    ratios = ('1:3', '3:1')
+
+    def cuts_of(i):
+        return synth.retargetvid_cuts(vids[i], counts[i])[:-1]
+
+    t0 = time.perf_counter()
+    resident, n_sel_mine = {}, 0
+    for i in svc_dist.shard_videos(counts, world)[rank]:          # this rank's videos: the frames the job will select, resident in HBM
+        sel = S._select_frames(counts[i], counts[i], cuts_of(i) + [counts[i]], CP['skip'], CP['read_batch'])[0]
+        resident[i] = synth.ResidentBlobVideo(counts[i], sel, seed=vids[i], device=dev)
+        n_sel_mine += len(sel)
+    torch.cuda.synchronize()
+    gen_s = time.perf_counter() - t0
+
+    def make(i):
+        return dict(fr=30.0, frame_count=counts[i], w=640, h=360, frames=resident[i], trans_inds=cuts_of(i) + [counts[i]])
+
+    t0 = time.perf_counter()
+    js = scheduler.JobScheduler(CP, ratios, lanes=lanes, state_dict=sd)
+    torch.cuda.synchronize()
+    create_s = time.perf_counter() - t0
+    runs, stats, allb = [], [], None
+
+    def barrier():
+        if dist_on:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for rep in range(3):
+        barrier()
+        t0 = time.perf_counter()
+        allb, st = svc_dist.crop_job(make, counts, ['%03d' % v for v in vids], CP, ratios, out_dir=None,
+                                     crop_fn=lambda vs, cp, rs, w: js.run(vs))
+        barrier()
+        runs.append(time.perf_counter() - t0)
+        stats.append(dict(js.stats))
+    js.close()
+    n_sel = torch.tensor([n_sel_mine], dtype=torch.int64, device=dev)
+    if dist_on:
+        torch.distributed.all_reduce(n_sel)
+    if rank != 0:
+        return None
+    annots = E.load_annotations(folder)
+    boxes = {ar: {vids[i]: allb[r][i] for i in range(len(vids))} for ar, r in (('1-3', '1:3'), ('3-1', '3:1'))}
+    gt, mt, index = E.pair_boxes(annots, boxes)
+    scores = E.aggregate(np.asarray(ops.iou_boxes(gt, mt), np.float64), index)
+    best = min(runs[1:])
+    k = runs.index(best)
+    n_sel = int(n_sel.item())
+    return dict(workload='200-video RetargetVid-shaped synthetic set (real frame counts, 0-3 cuts per video), targets 1:3 and 3:1, '
+                         'selected frames resident in HBM; dist.crop_job -> scheduler.JobScheduler -> all_gather of the boxes',
+                videos=len(vids), video_frames=int(sum(counts)), saliency_frames=n_sel, n_gpus=world, lanes_per_gpu=lanes,
+                seconds=round(best, 4), seconds_all_runs=[round(r, 4) for r in runs],
+                seconds_note='job wall clock between barriers (slowest rank), scheduler already created; the first run also pays '
+                             'one-time allocations; `seconds` = the better of runs 2 and 3',
+                video_frames_per_s=round(sum(counts) / best, 1), saliency_frames_per_s=round(n_sel / best, 1),
+                per_rank_fixed_costs_s=dict(scheduler_create=round(create_s, 4), rccl_init=(None if rccl_init_s is None else round(rccl_init_s, 4)),
+                                            generate_resident_frames=round(gen_s, 3)),
+                scheduler_rank0={kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in stats[k].items()},
+                windows_crc32=synth.windows_crc32(allb, ratios, len(vids)),
+                eval_percent={ar: [round(x, 3) for x in sc] for ar, sc in scores.items()},
+                eval_note='synthetic pixels against the human annotations: the scores only show that the job is deterministic')
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -181,10 +258,14 @@ def main():
     # BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, barrier, MAX all-reduce, box gather) with any
     # world size, including 1 under torch.distributed.run -- a way to exercise it on a single-GPU box
     dist_on = world > 1 or os.environ.get('BENCH_FORCE_DIST', '0') == '1'
+    rccl_init_s = None
     if dist_on:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local)
+        t_init = time.perf_counter()
         torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+        torch.distributed.barrier()                     # the communicator is built by the first collective
+        rccl_init_s = time.perf_counter() - t_init
     else:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', torch.cuda.current_device())
@@ -211,7 +292,8 @@ def main():
         (retargetvid_amd/pipeline.py: one tail round per call, chains carried over to the stream's next calls)."""
         def __init__(self):
             self.eng = ops.Engine(sd)
-            self.stream = torch.cuda.Stream(device=dev)
+            self.stream = lane_pool[len(slots_made)]        # the process's lane streams (scheduler.lane_streams): config 3 below re-uses them
+            slots_made.append(self)
             self.xy_host = torch.empty((B, 2), dtype=torch.float64).pin_memory()
             self.maps = torch.empty((B, 140, 250), dtype=torch.uint8, device=dev)
             self.net_done = torch.cuda.Event(enable_timing=True)
@@ -245,6 +327,8 @@ def main():
             host_t['boxes'] += time.perf_counter() - t1
             return b
 
+    from retargetvid_amd import scheduler as _sched
+    lane_pool, slots_made = _sched.lane_streams(dev, P), []
     slots = [Slot() for _ in range(P)]
     torch.cuda.synchronize()
     STREAMED = os.environ.get('BENCH_CARRY', '1') != '0' and P > 1      # BENCH_CARRY=0: the plain call (rounds inside the call)
@@ -316,6 +400,19 @@ def main():
         torch.cuda.synchronize()
 
     boxes = run(max(args.warmup, P))
+    # the timed path against the plain call on one batch (cheap; the full statement is tests/test_gpu_pipeline.py): the
+    # streaming scheduler must give the centres of the call that runs every blend chain out in rounds
+    if STREAMED:
+        slots[0].enqueue()
+        slots[0].finish()
+        xy_plain = slots[0].xy_host.numpy().copy()
+        slots[0].pipe.reset()
+        slots[0].pipe.submit_frames(frames, flags)
+        xy_stream = np.full((B, 2), np.nan)
+        for g, x, y in slots[0].pipe.finish():
+            xy_stream[g] = (x, y)
+        if not np.array_equal(xy_plain, xy_stream, equal_nan=True):
+            raise SystemExit('bench.py: the streaming schedule and the plain call disagree on the centres of one batch')
     # 1. un-pipelined pass (one batch in flight, slot 0 only): per kernel class, iso_steps profiled steps -> launch
     #    durations that overlap nothing; also the latency of one batch and the step time with one batch in flight
     eng = slots[0].eng
@@ -332,9 +429,8 @@ def main():
             slots[0].enqueue()
             slots[0].finish()
         raw, pair, cnt = eng.profile_read_raw()
-        ms = max(0.0, raw - 0.75 * pair * cnt)                    # the library's own correction (svc_profile_read); both ingredients are reported
-        per_class[k] = (ms / iso, cnt / iso)                      # ms per step, launches per step
-        raw_class[k] = (raw / iso, pair)
+        per_class[k] = (raw / iso, cnt / iso)                     # ms per step (the raw event-pair durations), launches per step
+        raw_class[k] = (max(0.0, raw - 0.75 * pair * cnt) / iso, pair)       # minus 3/4 of an empty event pair per launch: secondary key
     eng.profile_enable(None)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -394,6 +490,9 @@ def main():
         torch.distributed.all_gather(tl, torch.tensor([dt_local], dtype=torch.float64, device=dev))
         rank_fps = [B * args.steps / float(t.item()) for t in tl]
 
+    c3 = None
+    if os.environ.get('BENCH_CONFIG3', '1') != '0' and not plain:
+        c3 = config3_job(world, rank, dist_on, dev, sd, int(os.environ.get('BENCH_CONFIG3_LANES', 8)), rccl_init_s)
     if rank == 0:
         front_fused = eng.front_fused()
         work = layer_work(B, front_fused=front_fused)
@@ -412,8 +511,11 @@ def main():
                     measured='HIP events around every launch of the class in %d un-pipelined steps (one batch in flight) '
                              'before the timed region' % iso,
                     launches_per_step=round(iso_n, 2), class_ms_per_step=round(iso_ms, 4),
-                    class_ms_per_step_raw_events=round(raw_class[dominant][0], 4), empty_event_pair_ms=round(raw_class[dominant][1], 5),
-                    event_correction='class_ms_per_step = raw - 0.75 x empty pair x launches (calibrated against rocprofv3 kernel durations)',
+                    class_ms_per_step_event_corrected=round(raw_class[dominant][0], 4), empty_event_pair_ms=round(raw_class[dominant][1], 5),
+                    frac_event_corrected=round(rate(raw_class[dominant][0]) / peak, 5) if raw_class[dominant][0] > 0 else None,
+                    event_correction='frac / achieved / class_ms_per_step are the RAW event-pair durations (they include the events\' own '
+                                     'cost, so they read a few percent below a profiler\'s kernel durations); *_event_corrected takes 0.75 x '
+                                     'an empty event pair off every launch',
                     avg_launch_ms=round(iso_ms / max(iso_n, 1), 5),
                     algorithmic_per_step=unit_work, algorithmic_unit='FLOP' if dominant == 'pw' else 'B',
                     frac_wall=round(rate(dt / steps * 1e3) / peak, 5))
@@ -429,7 +531,7 @@ def main():
                         hbm_note='un-fused layer-wise fp32 traffic of the class (in + out + weights) / class time')
         roof['traffic'] = None
         try:
-            src = os.path.join('profiles', 'r03_pmc_traffic.json')
+            src = os.path.join('profiles', 'r04_pmc_traffic.json' if os.path.isfile(os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')) else 'r03_pmc_traffic.json')
             with open(os.path.join(ROOT, src)) as fp:
                 c = json.load(fp)['classes'][dominant]
             roof.update(traffic=c['hbm_bytes_per_launch'], traffic_per_step=c.get('hbm_bytes_per_step'),
@@ -468,6 +570,9 @@ def main():
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / max(args.steps, 1) * 1e3, 4),
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload='Single 640x360 video, batch=32 frames, UNISAL saliency + crop on 1 MI355X',
+                               workload_id=('r02-1to3blobs-sigma20-60' if not BENCH_BLOBS else
+                                            'r03-%dblobs-sigma%g-%g' % (BENCH_BLOBS['n_blobs'], BENCH_BLOBS['sigma'][0], BENCH_BLOBS['sigma'][1])),
+                               config3=c3,
                                batch_per_gpu=B, frame='640x360x3 u8', saliency_map='140x250 u8', network_input='256x416',
                                weights='synthetic seed 0 (weights.make_synthetic_state_dict)',
                                video_frames_per_s=round(value * CP['skip'], 1), batches_in_flight=P,

@@ -71,8 +71,9 @@ const char *svc_last_error(void);
 /* ABI revision of the loaded library (bumped whenever a struct layout or a signature changes); a binding
  * checks it once after dlopen.  2 = SvcParams starts with struct_size and carries resize_factor.
  * 3 = SvcParams ends with com_km; SVC_MAP_HELD is honoured by svc_cluster_center (a v2 library ignores the bit), svc_debug_cluster_state
- *     returns 32 header words, svc_debug_round_plan / svc_debug_argsort_u32 / svc_transnet_* exist. */
-#define SVC_ABI_VERSION 3
+ *     returns 32 header words, svc_debug_round_plan / svc_debug_argsort_u32 / svc_transnet_* exist.
+ * 4 = the host stages svc_host_* (SvcTemporalParams) exist. */
+#define SVC_ABI_VERSION 4
 int svc_abi_version(void);
 
 /* weights_blob_host: the packed, BN-folded static SALICON slice of a UNISAL
@@ -116,6 +117,51 @@ int svc_debug_round_plan(const uint8_t *flags_host, int n, int32_t *round_out, i
 
 /* a[n][4], b[n][4] int32 boxes (x1,y1,x2,y2) -> out[n] float64 IoU, inclusive +1 pixel convention. */
 int svc_iou_i32(const int32_t *a, const int32_t *b, size_t n, double *out, void *stream);
+
+/* ---- host stages between the per-frame centres and the crop windows (csrc/svc_host.cpp) ----
+ * north_star keeps them on the host; they are native so that a multi-video job runs them off the interpreter lock.
+ * No GPU, no handle, no stream: every pointer is HOST memory, float64 unless stated.  Reference: smartVidCrop.py
+ *   svc_host_fill_empty_centres  sc_handle_empty_centers :1221-1300.  NaN = no centre; filled in place; returns the
+ *                                number of centres still empty (> 0 only when a run copies from an empty neighbour)
+ *   svc_host_interp_segment      interp_handler :1528-1548 for the two series of one shot: n samples at the increasing times
+ *                                sampled_t -> n_out values at times 0 .. n_out-1 (constant for n < 3, interp1d 'linear' for
+ *                                n <= 6, 'quadratic' beyond, both extrapolating)
+ *   svc_host_lowpass             sc_butter_lowpass_filter :1599-1627: scipy.signal.filtfilt(b, a, x) with b, a =
+ *                                scipy.signal.butter(order, cutoff / (fr / 2)) and zi = scipy.signal.lfilter_zi(b, a)
+ *                                (taps = order + 1 coefficients; zi has taps - 1), or, for n <= 3 * taps, the reference's
+ *                                5-point moving average over x[2 : n-2]
+ *   svc_host_loess               pyloess.Loess(arange(n), y).estimate(j, window, degree) for every j
+ *                                (3rd_party_libs/loess/pyloess.py:13-95); NaN where the reference divides 0 / 0
+ *   svc_host_savgol              scipy.signal.savgol_filter(y, window, degree), mode 'interp' (:1643)
+ *   svc_host_temporal            sc_interpolate + sc_smoothing (:1550-1597, :1648-1734) of one video: centres of the n_sel
+ *                                selected frames (true_inds = their frame numbers) + the shots seg[n_seg][2] (first, last
+ *                                decoded frame) / seg_sel[n_seg][2] (first, last selected frame) -> interpolated (xi, yi)
+ *                                and smoothed (xs, ys) centres, fc values each.  Returns the number of values produced.
+ *   svc_host_boxes               sc_compute_bb :979-1048: smoothed centres (saliency-map pixels) -> boxes[fc][4] int64
+ *                                (x1, y1, x2, y2), centres[fc][2] (may be NULL) = the truncated full-resolution centres the
+ *                                reference writes back to dxs / dys, fbb_wh[2] (may be NULL) = box width, height;
+ *                                borders_tblr (may be NULL = 0) = border_t, border_b, border_l, border_r */
+typedef struct SvcTemporalParams {
+    uint32_t struct_size;       /* = sizeof(SvcTemporalParams) as the caller compiled it */
+    int32_t lp_filt;            /* CP['lp_filt'] */
+    int32_t lp_taps;            /* CP['lp_order'] + 1 = length of lp_b / lp_a */
+    int32_t loess_filt;         /* CP['loess_filt']: 1 = LOESS, 0 = Savitzky-Golay */
+    int32_t loess_degree;       /* CP['loess_degree'] */
+    int32_t reserved;
+    double loess_w_secs;        /* CP['loess_w_secs'] */
+    double fr;                  /* frames per second of the video */
+} SvcTemporalParams;
+int svc_host_fill_empty_centres(double *cx, double *cy, int n_sel, const int32_t *seg_sel, int n_seg);
+int svc_host_interp_segment(const double *sampled_t, const double *d1, const double *d2, int n, int n_out, double *out1, double *out2);
+int svc_host_lowpass(const double *b, const double *a, const double *zi, int taps, const double *x, int n, double *out);
+int svc_host_loess(const double *y, int n, int window, int degree, double *out);
+int svc_host_savgol(const double *y, int n, int window, int degree, double *out);
+int svc_host_temporal(const SvcTemporalParams *p, const double *lp_b, const double *lp_a, const double *lp_zi,
+                      const double *cx, const double *cy, int n_sel, const int32_t *true_inds,
+                      const int32_t *seg, const int32_t *seg_sel, int n_seg, int fc,
+                      double *xi, double *yi, double *xs, double *ys);
+int svc_host_boxes(const double *xs, const double *ys, int fc, int w_orig, int h_orig, int w_process, int h_process,
+                   int w_final, int h_final, const int32_t *borders_tblr, int64_t *boxes, int64_t *centres, int32_t *fbb_wh);
 
 /* Measurement door (bench.py): record HIP events around every launch of one kernel class on
  * the stream it is launched on.  kernel_class = one of SVC_K_*, or -1 to switch recording off.

@@ -9,18 +9,26 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SVC_LIB') or os.path.join(_HERE, 'libsvc_hip.so')      # SVC_LIB: another build of the same ABI (A/B runs)
 
-ABI_VERSION = 3          # include/svc.h SVC_ABI_VERSION this binding was written against
+ABI_VERSION = 4          # include/svc.h SVC_ABI_VERSION this binding was written against
 
 EXPORTS = ('svc_last_error', 'svc_abi_version', 'svc_create', 'svc_destroy', 'svc_resize_frames_u8', 'svc_saliency_u8',
            'svc_threshold_u8', 'svc_cluster_center', 'svc_iou_i32', 'svc_debug_cluster_state', 'svc_debug_tap', 'svc_front_fused', 'svc_debug_round_plan', 'svc_transnet_load', 'svc_transnet_predict',
            'svc_debug_argsort_u32',
-           'svc_profile_enable', 'svc_profile_read', 'svc_profile_read_raw')
+           'svc_profile_enable', 'svc_profile_read', 'svc_profile_read_raw',
+           'svc_host_fill_empty_centres', 'svc_host_interp_segment', 'svc_host_lowpass', 'svc_host_loess', 'svc_host_savgol',
+           'svc_host_temporal', 'svc_host_boxes')
 
 
 class SvcParams(ctypes.Structure):
     _fields_ = [('struct_size', ctypes.c_uint32), ('hdbscan_min', ctypes.c_int32), ('hdbscan_min_samples', ctypes.c_int32),
                 ('select_sum', ctypes.c_int32), ('op_close', ctypes.c_int32), ('clust_filt', ctypes.c_int32),
                 ('resize_factor', ctypes.c_int32), ('com_km', ctypes.c_int32)]
+
+
+class SvcTemporalParams(ctypes.Structure):
+    _fields_ = [('struct_size', ctypes.c_uint32), ('lp_filt', ctypes.c_int32), ('lp_taps', ctypes.c_int32),
+                ('loess_filt', ctypes.c_int32), ('loess_degree', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('loess_w_secs', ctypes.c_double), ('fr', ctypes.c_double)]
 
 
 def make_params(CP):
@@ -74,6 +82,14 @@ def load():
     lib.svc_profile_enable.argtypes = [vp, i32]
     lib.svc_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     lib.svc_profile_read_raw.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
+    lib.svc_host_fill_empty_centres.argtypes = [vp, vp, i32, vp, i32]
+    lib.svc_host_interp_segment.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+    lib.svc_host_lowpass.argtypes = [vp, vp, vp, i32, vp, i32, vp]
+    lib.svc_host_loess.argtypes = [vp, i32, i32, i32, vp]
+    lib.svc_host_savgol.argtypes = [vp, i32, i32, i32, vp]
+    lib.svc_host_temporal.argtypes = [ctypes.POINTER(SvcTemporalParams), vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    lib.svc_host_boxes.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     for name in EXPORTS:
         if name not in ('svc_last_error', 'svc_abi_version'):
             getattr(lib, name).restype = i32

@@ -80,7 +80,9 @@ def read_boxes(path, frame_count):
         b = np.loadtxt(path, dtype=np.int32, delimiter=',', ndmin=2)
     except Exception:
         return None
-    return b if b.shape == (frame_count, 4) else None
+    if b.shape != (frame_count, 4) or (b[:, 0] > b[:, 2]).any() or (b[:, 1] > b[:, 3]).any() or (b < 0).any():
+        return None                                            # not crop windows (x1 <= x2, y1 <= y2, inside the frame): computed again
+    return b
 
 
 def crop_job(make_video, frame_counts, names, CP, ratios, out_dir=None, workers=4, crop_fn=None, run_name='run',
@@ -110,19 +112,23 @@ def crop_job(make_video, frame_counts, names, CP, ratios, out_dir=None, workers=
     n_all = len(frame_counts)
     kept = {}                                              # video -> {ratio: boxes read back from an earlier run}
     if not replace_existing and out_dir is not None:
-        done = []
+        done, scan_err = [], None
         if rank == 0:
-            for i in range(n_all):
-                got = {}
-                for r in ratios:
-                    txt, info = result_paths(out_dir, run_name, names[i], r)
-                    b = read_boxes(txt, frame_counts[i]) if (os.path.isfile(txt) and os.path.isfile(info)) else None
-                    if b is None:
-                        break
-                    got[r] = b
-                if len(got) == len(ratios):
-                    kept[i] = got
-            done = sorted(kept)
+            try:                                               # a failure of the scan (an unreadable out_dir, a bad name) must not
+                for i in range(n_all):                         # leave the other ranks waiting in the broadcast below
+                    got = {}
+                    for r in ratios:
+                        txt, info = result_paths(out_dir, run_name, names[i], r)
+                        b = read_boxes(txt, frame_counts[i]) if (os.path.isfile(txt) and os.path.isfile(info)) else None
+                        if b is None:
+                            break
+                        got[r] = b
+                    if len(got) == len(ratios):
+                        kept[i] = got
+                done = sorted(kept)
+            except Exception as e:
+                scan_err = e
+        _agree_on_failure(scan_err)
         if world > 1:
             box = [done]
             dist.broadcast_object_list(box, src=0)

@@ -57,6 +57,25 @@ def load_annotations(folder):
     return annots
 
 
+def frame_counts(folder):
+    """{vid: number of frames} from the first annotator's 1-3 files alone (retargetvid_eval.py:99-101), without parsing
+    the 2 400 annotation files."""
+    name = 'annotator_1'
+    d, z = os.path.join(folder, name), os.path.join(folder, name + '.zip')
+    out = {}
+    if os.path.isdir(d):
+        for v in VID_INDS:
+            with open(os.path.join(d, '%03d_1-3.txt' % v)) as fp:
+                out[v] = sum(1 for l in fp if l.strip())
+    elif os.path.isfile(z):
+        with zipfile.ZipFile(z) as zf:
+            for v in VID_INDS:
+                out[v] = sum(1 for l in zf.read('%s/%03d_1-3.txt' % (name, v)).decode().splitlines() if l.strip())
+    else:
+        raise FileNotFoundError('%s: neither directory nor zip found' % d)
+    return out
+
+
 def list_runs(results):
     """results: a directory of run sub-directories, or a zip whose top-level entries are runs."""
     if os.path.isdir(results):

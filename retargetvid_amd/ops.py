@@ -42,6 +42,8 @@ class Engine:
         if state_dict is None:
             state_dict = _weights.make_synthetic_state_dict(seed)
         blob = _weights.pack_blob(_weights.fold_state_dict(state_dict))
+        import zlib
+        self.weights_id = zlib.crc32(blob) & 0xffffffff        # identifies the checkpoint (smartVidCrop's feature cache keys on it)
         self._h = ctypes.c_void_p()
         buf = ctypes.create_string_buffer(blob, len(blob))
         _lib.check(self.lib.svc_create(buf, len(blob), self.device.index, ctypes.byref(self._h)))

@@ -32,6 +32,20 @@ import numpy as np
 from . import smartVidCrop as S
 
 
+_LANE_STREAMS = {}          # device index -> HIP streams of the lanes, created once per process
+
+
+def lane_streams(dev, n):
+    """The lanes' HIP streams, kept for the life of the process: a scheduler made per job must not walk through the
+    runtime's hardware queues (GPU_MAX_HW_QUEUES) -- measured: the job whose streams were the 13th..16th of the process ran
+    10 x slower than its neighbours (tools/time_scheduler.py --fresh 1)."""
+    import torch
+    pool = _LANE_STREAMS.setdefault(dev.index, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
+
+
 class _Video:
     __slots__ = ('idx', 'video', 'plan', 'lane', 'row0', 'xy', 'remaining', 'maps', 'pos', 'done')
 
@@ -127,12 +141,16 @@ class _Lane:
         sc = self.sched
         while self.frames_in - self.frames_done < sc.chunk:
             if self.cur is None:
+                t = time.perf_counter()
                 v = sc._next_video(self)
+                sc.host_s['plan'] += time.perf_counter() - t
                 if v is None:
                     self.exhausted = True
                     return
                 self._start_video(v)
+            t = time.perf_counter()
             self._take_piece()
+            sc.host_s['intake'] += time.perf_counter() - t
 
     # ---- one chunk --------------------------------------------------------------------------------------------------
     def step(self):
@@ -147,7 +165,11 @@ class _Lane:
         if k == 0 and self.rows_in == self.rows_called:
             return False
         if len(self.pipe.calls) >= self.pipe.depth:
-            sc._dispatch(self, *self.pipe.collect_arrays())
+            t = time.perf_counter()
+            res = self.pipe.collect_arrays()
+            sc.host_s['wait'] += time.perf_counter() - t
+            sc._dispatch(self, *res)
+        t = time.perf_counter()
         f0 = self.frames_done
         # rows of this call: up to (not including) the row of the next frame the network has not seen
         R = int(self.row_of_frame[f0 + k]) if f0 + k < self.frames_in else self.rows_in
@@ -168,7 +190,11 @@ class _Lane:
                         self.maps[ra:ra + (b - a)].copy_(self.tmp[a:b])
                         a = int(b)
             self.eng.threshold_(dst, sc.CP['t_threshold'])
+        t1 = time.perf_counter()
         self.pipe.submit_rows(n_rows, self.flags[self.rows_called:R])
+        t2 = time.perf_counter()
+        sc.host_s['enqueue_net'] += t1 - t
+        sc.host_s['enqueue_tail'] += t2 - t1
         self.frames_done += k
         self.rows_called = R
         sc.n_chunks += 1
@@ -226,7 +252,7 @@ class JobScheduler:
                 state_dict = _weights.make_synthetic_state_dict(seed)
             engines = [_ops.Engine(state_dict, device=self.dev.index, seed=seed) for _ in range(max(1, int(lanes)))]
         self.engines = list(engines)
-        self.streams = [torch.cuda.Stream(device=self.dev) for _ in self.engines]
+        self.streams = lane_streams(self.dev, len(self.engines))
         self.pool = ThreadPoolExecutor(max_workers=max(1, int(host_threads)))
         self.lock = threading.Lock()
 
@@ -247,6 +273,7 @@ class JobScheduler:
         self.next_idx = 0
         self.futures = []
         self.n_chunks = self.n_net_frames = 0
+        self.host_s = dict(plan=0.0, intake=0.0, enqueue_net=0.0, enqueue_tail=0.0, wait=0.0, dispatch=0.0)
         t0 = time.perf_counter()
         lanes = [_Lane(self, e, s, k) for k, (e, s) in enumerate(zip(self.engines, self.streams))]
         if not self.CP['clust_filt']:
@@ -275,7 +302,8 @@ class JobScheduler:
             raise RuntimeError('JobScheduler: videos %r were never completed' % (missing[:8],))
         self.stats = dict(videos=len(self.videos), chunks=self.n_chunks, network_frames=self.n_net_frames,
                           mean_chunk_fill=self.n_net_frames / max(1, self.n_chunks) / self.chunk,
-                          seconds_device_side=t1 - t0, seconds_host_stage_drain=t2 - t1, lanes=len(lanes))
+                          seconds_device_side=t1 - t0, seconds_host_stage_drain=t2 - t1, lanes=len(lanes),
+                          feeder_seconds={k: round(v, 4) for k, v in self.host_s.items()})
         return self.out
 
     # ---- feeder-side helpers ------------------------------------------------------------------------------------------
@@ -294,6 +322,7 @@ class JobScheduler:
         """Centres of finished maps -> their videos; a video whose last centre arrived goes to the host-stage pool."""
         if len(gids) == 0:
             return
+        t = time.perf_counter()
         slots = lane.vid_of_row[gids]
         loc = lane.local_of_row[gids]
         for slot in np.unique(slots):
@@ -305,6 +334,7 @@ class JobScheduler:
                 v.done = True
                 del lane.videos[int(slot)]
                 self.futures.append(self.pool.submit(self._finish_video, v))
+        self.host_s['dispatch'] += time.perf_counter() - t
 
     def _finish_video(self, v):
         """Host stages of one video (pool thread)."""

@@ -137,45 +137,19 @@ def sc_calc_dest_size(vid_data, crop_params, verbose=False):
 
 
 def sc_compute_bb(vid_data, crop_params, verbose=False):
-    """smartVidCrop.py:979-1048: centres (saliency-map pixels) -> [x1,y1,x2,y2] per frame."""
-    fw, fh = vid_data['w_orig'], vid_data['h_orig']
-    scale_h = float(vid_data['h_process']) / float(fh)
-    scale_w = float(vid_data['w_process']) / float(fw)
-    bt, bb, bl, br = (vid_data.get(k, 0) for k in ('border_t', 'border_b', 'border_l', 'border_r'))
+    """smartVidCrop.py:979-1048: centres (saliency-map pixels) -> [x1,y1,x2,y2] per frame (native: svc_host_boxes)."""
     fc = vid_data['fc']
-    # full-resolution integer centres, int() = truncation toward zero (:995-999); vectorised, same float64 arithmetic
-    xs = np.trunc(np.asarray(vid_data['dxs'][:fc], np.float64) / scale_w).astype(np.int64)
-    ys = np.trunc(np.asarray(vid_data['dys'][:fc], np.float64) / scale_h).astype(np.int64)
-    vid_data['dxs'][:fc] = xs.tolist()
-    vid_data['dys'][:fc] = ys.tolist()
-    bb_w, bb_h = vid_data['w_final'], vid_data['h_final']
-    fbb_w, fbb_h = bb_w, bb_h
-    if bb_h == fh:
-        fbb_h = bb_h - bt - bb
-        fbb_w = int((float(fbb_h) / float(bb_h)) * bb_w)
-    if bb_w == fw:
-        fbb_w = bb_w - bl - br
-        fbb_h = int((float(fbb_w) / float(bb_w)) * bb_h)
+    borders = tuple(vid_data.get(k, 0) for k in ('border_t', 'border_b', 'border_l', 'border_r'))
+    boxes, ctr, fbb_w, fbb_h = temporal.boxes(vid_data['dxs'][:fc], vid_data['dys'][:fc], vid_data['w_orig'], vid_data['h_orig'],
+                                              vid_data['w_process'], vid_data['h_process'], vid_data['w_final'],
+                                              vid_data['h_final'], borders)
+    # full-resolution integer centres, int() = truncation toward zero (:995-999)
+    vid_data['dxs'][:fc] = ctr[:, 0].tolist()
+    vid_data['dys'][:fc] = ctr[:, 1].tolist()
     vid_data['fbb_w'], vid_data['fbb_h'] = fbb_w, fbb_h
-    hw1 = int(fbb_w / 2.0)
-    hw2 = fbb_w - hw1
-    hh1 = int(fbb_h / 2.0)
-    hh2 = fbb_h - hh1
-    x1, x2, y1, y2 = xs - hw1, xs + hw2, ys - hh1, ys + hh2
-    m = x1 < bl                                    # the four clamps in the reference's order (:1027-1044)
-    x1[m], x2[m] = bl, bl + fbb_w
-    m = x2 > fw - br
-    x2[m] = fw - br
-    x1[m] = x2[m] - fbb_w
-    m = y1 < bt
-    y1[m], y2[m] = bt, bt + fbb_h
-    m = y2 > fh - bb
-    y2[m] = fh - bb
-    y1[m] = y2[m] - fbb_h
-    boxes = np.stack([x1, y1, x2, y2], axis=1)
     vid_data['bbs_np'] = boxes                         # int64 [fc, 4]: what the multi-video job gathers (dist.crop_job)
     if isinstance(vid_data, _LazySmaps):
-        vid_data.pop('bbs', None)                      # the list-of-lists form (the reference's VD['bbs']) is made on first access
+        dict.pop(vid_data, 'bbs', None)                # the list-of-lists form (the reference's VD['bbs']) is made on first access
     else:
         vid_data['bbs'] = boxes.tolist()
     return vid_data
@@ -533,16 +507,51 @@ def blend_flags(fc_sel, segmentation_sel):
 class _LazySmaps(dict):
     """VD dict whose 'smaps' ([H,W,n] u8, the reference's layout) is materialised from the device
     only when somebody asks for it, and whose 'bbs' list is made from the array 'bbs_np' on first access (0.4 ms of
-    Python per video and ratio that the multi-video job never needs)."""
+    Python per video and ratio that the multi-video job never needs).  The lazy keys answer `in`, get(), keys(), items(),
+    iteration, dict(VD) and pickling like keys that are present: a caller of the reference gets a plain dict with both."""
+    _LAZY = {'smaps': 'smaps_dev', 'bbs': 'bbs_np'}
 
     def __missing__(self, key):
-        if key == 'smaps' and 'smaps_dev' in self:
-            self['smaps'] = np.ascontiguousarray(self['smaps_dev'].permute(1, 2, 0).cpu().numpy())
-            return self['smaps']
-        if key == 'bbs' and 'bbs_np' in self:          # one [x1,y1,x2,y2] list per frame, as the reference returns them
-            self['bbs'] = self['bbs_np'].tolist()
-            return self['bbs']
+        if key == 'smaps' and dict.__contains__(self, 'smaps_dev'):
+            self['smaps'] = np.ascontiguousarray(dict.__getitem__(self, 'smaps_dev').permute(1, 2, 0).cpu().numpy())
+            return dict.__getitem__(self, 'smaps')
+        if key == 'bbs' and dict.__contains__(self, 'bbs_np'):          # one [x1,y1,x2,y2] list per frame, as the reference returns them
+            self['bbs'] = dict.__getitem__(self, 'bbs_np').tolist()
+            return dict.__getitem__(self, 'bbs')
         raise KeyError(key)
+
+    def _materialise(self):
+        for k, src in self._LAZY.items():
+            if not dict.__contains__(self, k) and dict.__contains__(self, src):
+                self[k]
+        return self
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or (key in self._LAZY and dict.__contains__(self, self._LAZY[key]))
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        return dict.keys(self._materialise())
+
+    def items(self):
+        return dict.items(self._materialise())
+
+    def values(self):
+        return dict.values(self._materialise())
+
+    def __iter__(self):
+        return dict.__iter__(self._materialise())
+
+    def __len__(self):
+        return dict.__len__(self._materialise())
+
+    def copy(self):
+        return _LazySmaps(dict.copy(self))
+
+    def __reduce__(self):
+        return (dict, (dict(dict.items(self._materialise())),))
 
 
 def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn='', frames_dir='',
@@ -588,17 +597,29 @@ def smart_vid_crop(video_path, CP=None, demo_fn='', final_vid_fn='', plots_fn=''
             name = os.path.splitext(os.path.basename(video_path))[0]
         if name:
             cache_fn = os.path.join(temp_path, str(name) + '.pkl')
+    # what the cached analysis depends on besides the video: a file written under other values is ignored and replaced (the
+    # reference keys its cache by the name alone, :2244-2256, and would silently re-use it)
+    cache_key = None
+    if cache_fn is not None:
+        cache_key = dict(skip=CP['skip'], read_batch=CP['read_batch'], max_input_d=CP['max_input_d'],
+                         frame_count=int(video['frame_count']), shots='net' if video.get('trans_inds') is None else
+                         [int(v) for v in video['trans_inds']], weights=getattr(engine, 'weights_id', None))
+    cached = None
     if cache_fn is not None and os.path.isfile(cache_fn):
         with open(cache_fn, 'rb') as fp:
             cached = pickle.load(fp)
-        VD = _LazySmaps({k: v for k, v in cached.items() if k != 'smaps_nhw'})
+        if cached.get('cache_key') != cache_key:
+            cached = None
+    if cached is not None:
+        VD = _LazySmaps({k: v for k, v in cached.items() if k not in ('smaps_nhw', 'cache_key')})
         VD['smaps_dev'] = torch.from_numpy(cached['smaps_nhw']).to(engine.device)
     else:
         VD = _LazySmaps(ingest_frames(video, CP, engine, verbose=verbose, shot_net=shot_net, stream_batch=stream_batch))
         if cache_fn is not None:
             os.makedirs(temp_path, exist_ok=True)
-            out = {k: v for k, v in VD.items() if k not in ('smaps_dev', 'smaps')}
+            out = {k: v for k, v in dict.items(VD) if k not in ('smaps_dev', 'smaps')}     # (dict.items: nothing lazy is materialised)
             out['smaps_nhw'] = VD['smaps_dev'].cpu().numpy()
+            out['cache_key'] = cache_key
             with open(cache_fn, 'wb') as fp:
                 pickle.dump(out, fp)
     if callback_status is not None and callback_session is not None:
@@ -643,14 +664,15 @@ def after_ingest(VD, CP, engine, verbose=False):
     sc_register_time(t, '_clustering')
 
     t = time.perf_counter()
-    VD['dx'] = [None if math.isnan(v) else float(v) for v in xy[:, 0]]
-    VD['dy'] = [None if math.isnan(v) else float(v) for v in xy[:, 1]]
+    xy = np.asarray(xy, np.float64).reshape(-1, 2)
     sc_register_time(t, '_center_of_mass')
 
     t = time.perf_counter()
-    VD['dx'], VD['dy'] = temporal.handle_empty_centers(VD['dx'], VD['dy'], VD['segmentation_sel'])
-    if any(v is None for v in VD['dx']):
-        raise ValueError('no saliency centre found in any selected frame')
+    if np.isnan(xy[:, 0]).any():                       # (native: svc_host_fill_empty_centres)
+        xy, still_empty = temporal.fill_empty_centres(xy, VD['segmentation_sel'])
+        if still_empty:
+            raise ValueError('no saliency centre found in any selected frame')
+    VD['dx'], VD['dy'] = xy[:, 0].tolist(), xy[:, 1].tolist()
     sc_register_time(t, '_center_empty_handle')
     VD['jumps'] = [255] * len(VD['dx'])
     VD['jumps_inds'] = []
@@ -659,14 +681,16 @@ def after_ingest(VD, CP, engine, verbose=False):
     if CP['focus_stability']:            # best settings: hold the focus across short low-saliency jumps (host)
         VD['dx'], VD['dy'], VD['jumps'], VD['jumps_inds'] = temporal.focus_stability(
             VD['dx'], VD['dy'], VD['smaps'], VD['fr'], CP)
+        xy = np.stack([VD['dx'], VD['dy']], 1).astype(np.float64)
     sc_register_time(t, '_focus_stability')
 
-    t = time.perf_counter()
-    VD['dxi'], VD['dyi'] = temporal.interpolate(VD['dx'], VD['dy'], VD['segmentation'], VD['segmentation_sel'],
-                                                VD['true_inds'])
+    t = time.perf_counter()                            # interpolation + low-pass + LOESS / Savitzky-Golay: one native call
+    xi, yi, xs, ys = temporal.centres_to_series(xy, VD['true_inds'], VD['segmentation'], VD['segmentation_sel'], VD['fc'],
+                                                VD['fr'], CP)
+    VD['dxi'], VD['dyi'] = xi.tolist(), yi.tolist()
     sc_register_time(t, '_interpolation')
     t = time.perf_counter()
-    VD['dxs'], VD['dys'] = temporal.smoothing(VD['dxi'], VD['dyi'], VD['segmentation'], VD['fr'], CP)
+    VD['dxs'], VD['dys'] = xs.tolist(), ys.tolist()
     VD['dxs_smooth'], VD['dys_smooth'] = list(VD['dxs']), list(VD['dys'])    # sc_compute_bb overwrites dxs / dys (:995-999)
     sc_register_time(t, '_smooth')
     t = time.perf_counter()
@@ -704,7 +728,7 @@ def other_ratio(base, cp):
     """(VD, results) of ANOTHER target ratio from those of a finished run of the same video: nothing before
     sc_calc_dest_size depends on out_ratio, so only destination size and boxes are recomputed."""
     import copy
-    VD = _LazySmaps({k: (copy.copy(v) if isinstance(v, list) else v) for k, v in base[0].items()})
+    VD = _LazySmaps({k: (copy.copy(v) if isinstance(v, list) else v) for k, v in dict.items(base[0]) if k != 'bbs'})
     res = dict(base[1])
     VD = sc_calc_dest_size(VD, cp)
     VD['dxs'], VD['dys'] = list(base[0]['dxs_smooth']), list(base[0]['dys_smooth'])   # smoothing does not depend on the ratio

@@ -79,3 +79,48 @@ class LazyBlobVideo:
             for c in range(3):                                       # (scalars: no host-device copy of the colour)
                 img[..., c].add_(g, alpha=float(p['col'][b][c]))
         return img.clamp_(0, 255).to(torch.uint8).contiguous()
+
+
+class ResidentBlobVideo:
+    """The frames of a LazyBlobVideo that a run will ask for, generated ONCE and kept in HBM (uint8 [k,h,w,3]); select(idx)
+    gathers them.  bench.py's convention -- inputs resident in HBM when the timed region starts -- for a whole job: the
+    200-video set needs 20 964 frames = 14.5 GB, where generating them on the fly costs the GPU ~40 element-wise passes
+    over every frame inside the run.  Asking for a frame that was not generated raises."""
+
+    accepts_device_index = False
+
+    def __init__(self, n, indices, h=360, w=640, seed=0, device='cuda', piece=64):
+        import torch
+        self.n, self.h, self.w = n, h, w
+        src = LazyBlobVideo(n, h, w, seed=seed, device=device)
+        idx = [int(i) for i in indices]
+        self.row = {f: r for r, f in enumerate(idx)}
+        self.frames = torch.cat([src.select(idx[s:s + piece]) for s in range(0, len(idx), piece)]) if idx else \
+            torch.empty((0, h, w, 3), dtype=torch.uint8, device=device)
+
+    def __len__(self):
+        return self.n
+
+    def select(self, idx, index=None):
+        rows = [self.row[int(i)] for i in idx]
+        if rows and rows == list(range(rows[0], rows[0] + len(rows))):
+            return self.frames[rows[0]:rows[0] + len(rows)]               # a run of consecutive rows: a view, no gather
+        import torch
+        return self.frames[torch.as_tensor(rows, dtype=torch.int64).pin_memory().to(self.frames.device, non_blocking=True)]
+
+
+def retargetvid_cuts(vid, n):
+    """The synthetic shot starts of video `vid` (n frames) in the RetargetVid-shaped job of bench.py's config 3,
+    tools/run_config3.py and the tests: 0-3 cuts at seeded positions.  -> trans_inds (smartVidCrop.py:560-573)."""
+    rng = np.random.RandomState(vid)
+    return sorted(set([0] + [int(c) for c in rng.randint(20, max(21, n - 20), rng.randint(0, 4))])) + [n]
+
+
+def windows_crc32(boxes_by_ratio, ratios, n_videos):
+    """One checksum over the crop windows of a job: int32 boxes of every video, ratio-major."""
+    import zlib
+    c = 0
+    for r in ratios:
+        for i in range(n_videos):
+            c = zlib.crc32(np.ascontiguousarray(boxes_by_ratio[r][i], np.int32).tobytes(), c)
+    return c & 0xffffffff

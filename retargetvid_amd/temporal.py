@@ -1,10 +1,12 @@
 """Host-side temporal stages between per-frame centres and crop boxes.
 
-These stay on the host by design (BASELINE.json north_star: "TransNetV1 shot detection
-and LOESS smoothing stay on host").  Same results as the reference functions, written
-for speed where the reference is a Python loop (LOESS is evaluated for all frames of a
-shot at once with batched 3x3 pseudo-inverses instead of one ``Loess.estimate`` call per
-frame).
+These stay on the host by design (BASELINE.json north_star: "TransNetV1 shot detection and LOESS smoothing stay on
+host").  Since round 4 the arithmetic is native (csrc/svc_host.cpp behind the svc_host_* entries of include/svc.h; ctypes
+releases the interpreter lock for the duration of a call, which is what lets retargetvid_amd/scheduler.py run the host
+stages of finished videos on a thread pool next to the feeder): one call per video for interpolation + low-pass + LOESS /
+Savitzky-Golay (`centres_to_series`), one per target ratio for the boxes.  The functions below keep the signatures of the
+reference's per-stage functions for callers and tests.  The Butterworth DESIGN (scipy.signal.butter / lfilter_zi) stays
+SciPy's, cached per (order, cutoff): a handful of coefficients handed to the native filter.
 
 Reference (smartVidCrop.py unless noted):
   handle_empty_centers   sc_handle_empty_centers            :1221-1300
@@ -15,126 +17,92 @@ Reference (smartVidCrop.py unless noted):
   focus_stability        sc_check_for_extra_cuts + focus hold :1337-1455, :2425-2473
   shift_time             sc_shift_time                      :1740-1746
 """
+import ctypes
 import functools
 
 import numpy as np
-from scipy import interpolate as _interp, signal as _signal
+
+from . import _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+def centres_array(dx, dy):
+    """Two lists with None for a missing centre -> float64 [n, 2] with NaN."""
+    return np.array([[np.nan if a is None else a, np.nan if b is None else b] for a, b in zip(dx, dy)], np.float64).reshape(-1, 2)
+
+
+def fill_empty_centres(xy, segmentation_sel):
+    """xy float64 [n, 2] (NaN = no centre) -> filled copy, number of centres still empty."""
+    lib = _lib.load()
+    cx, cy = _f64(xy[:, 0]).copy(), _f64(xy[:, 1]).copy()
+    seg_sel = _i32(segmentation_sel).reshape(-1, 2)
+    rc = lib.svc_host_fill_empty_centres(_p(cx), _p(cy), len(cx), _p(seg_sel), len(seg_sel))
+    if rc < 0:
+        raise IndexError(lib.svc_last_error().decode(errors='replace'))       # the reference's list index error
+    return np.stack([cx, cy], 1), rc
 
 
 def handle_empty_centers(dx, dy, segmentation_sel):
     """Fill runs of missing centres (None) from the nearest shot-consistent neighbour."""
-    dx, dy = list(dx), list(dy)
-    missing = np.array([v is None for v in dx], bool)
-    if not missing.any():
-        return dx, dy
-    starts = np.array([int(s[0]) for s in segmentation_sel])
-    ends = np.array([int(s[1]) for s in segmentation_sel])
-    edges = np.flatnonzero(np.diff(np.concatenate([[0], missing.view(np.int8), [0]])))
-    for lo, hi in zip(edges[0::2], edges[1::2] - 1):
-        d_start = int(np.min(np.abs(starts - lo)))
-        d_end = int(np.min(np.abs(ends - hi)))
-        src = hi + 1 if d_start < d_end else lo - 1        # a negative index wraps, as in the reference
-        for j in range(lo, hi + 1):
-            dx[j], dy[j] = dx[src], dy[src]
-    return dx, dy
-
-
-def _interp_segment(d, sampled_t, true_t):
-    n = len(d)
-    if n < 3:
-        return [float(d[0])] * len(true_t)
-    f = _interp.interp1d(sampled_t, d, fill_value='extrapolate', kind='linear' if n <= 6 else 'quadratic')
-    return list(f(true_t))
+    if not any(v is None for v in dx):
+        return list(dx), list(dy)
+    xy, _ = fill_empty_centres(centres_array(dx, dy), segmentation_sel)
+    back = lambda col: [None if v != v else float(v) for v in col]
+    return back(xy[:, 0]), back(xy[:, 1])
 
 
 def interpolate(dx, dy, segmentation, segmentation_sel, true_inds):
     """Per shot: selected-frame centres -> one centre per decoded frame."""
+    lib = _lib.load()
+    dx, dy, ti = _f64(dx), _f64(dy), np.asarray(true_inds)
     dxi, dyi = [], []
     for seg, sel in zip(segmentation, segmentation_sel):
         si, ei = int(seg[0]), int(seg[1]) + 1
         sis, eis = int(sel[0]), int(sel[1]) + 1
-        st = np.asarray(true_inds[sis:eis])
-        st = list(st - st.min())
-        tt = np.arange(0, ei - si)
-        dxi += _interp_segment(dx[sis:eis], st, tt)
-        dyi += _interp_segment(dy[sis:eis], st, tt)
+        st = _f64(ti[sis:eis] - ti[sis:eis].min())
+        o1, o2 = np.empty(ei - si), np.empty(ei - si)
+        _lib.check(lib.svc_host_interp_segment(_p(st), _p(dx[sis:eis]), _p(dy[sis:eis]), eis - sis, ei - si, _p(o1), _p(o2)))
+        dxi += o1.tolist()
+        dyi += o2.tolist()
     return dxi, dyi
 
 
 @functools.lru_cache(maxsize=64)
 def _butter_design(order, wn):
-    return _signal.butter(order, wn, btype='lowpass', analog=False)      # the design is ~10x the cost of filtering a shot
+    """(b, a, zi) of the zero-phase low-pass: SciPy's design, a few coefficients for the native filter."""
+    from scipy import signal
+    b, a = signal.butter(order, wn, btype='lowpass', analog=False)
+    return _f64(b), _f64(a), _f64(signal.lfilter_zi(b, a))
 
 
 def butter_lowpass(x, cutoff, fs, order):
-    """Zero-phase Butterworth low-pass with the reference's fall-back chain for short series."""
-    try:
-        b, a = _butter_design(order, cutoff / (0.5 * fs))
-        return _signal.filtfilt(b, a, x)
-    except Exception:
-        pass
-    for width in (5, 3):
-        try:
-            y = np.convolve(x, np.ones(width), 'same') / 5
-            x[2:len(x) - 2] = y[2:len(x) - 2]
-            return x
-        except Exception:
-            pass
-    return x
-
-
-@functools.lru_cache(maxsize=32)
-def _loess_design(n, window, degree):
-    """Everything of the local regressions that does not depend on the data: neighbourhoods, tricube weights
-    and, for degree > 1, the operator pinv(X^T W X) X^T W of every point (pyloess.py:60-83)."""
-    with np.errstate(all='ignore'):
-        nx = np.arange(n, dtype=np.float64) / (n - 1)
-        h = (window - 1) // 2
-        j = np.arange(n)
-        # neighbourhood chosen by get_min_range (pyloess.py:27-48): the nearer of the two outer neighbours joins next,
-        # the right one on a tie, clamped at the ends -> the symmetric 2h+1 points around j; an even window (never
-        # produced by sc_smoothing, :1668-1670) takes one more point, decided by the same float64 comparison
-        lo = np.clip(j - h, 0, n - (2 * h + 1))
-        if window % 2 == 0:
-            hi = lo + 2 * h
-            dl = np.abs(nx[np.maximum(lo - 1, 0)] - nx[j])
-            dr = np.abs(nx[np.minimum(hi + 1, n - 1)] - nx[j])
-            left = (hi == n - 1) | ((lo > 0) & (dl < dr))
-            left &= (j != 0)                                          # argmin at an end: arange(0, window) / arange(n - window, n)
-            left |= (j == n - 1)
-            lo = np.where(left, lo - 1, lo)
-        idx = lo[:, None] + np.arange(window)[None, :]                # [n, window]
-        dist = np.abs(nx[idx] - nx[j][:, None])
-        r = dist / dist.max(axis=1, keepdims=True)
-        w = np.where((r >= -1) & (r <= 1), (1.0 - np.abs(r) ** 3) ** 3, 0.0)
-        if degree > 1:
-            xm = nx[idx][:, :, None] ** np.arange(degree + 1)[None, None, :]     # [n, window, d+1]
-            xtw = np.transpose(xm, (0, 2, 1)) * w[:, None, :]                    # X^T W
-            op = np.linalg.pinv(xtw @ xm) @ xtw                                   # [n, d+1, window]
-            xp = nx[j][:, None] ** np.arange(degree + 1)[None, :]
-            return idx, w, nx, op, xp
-        return idx, w, nx, None, None
+    """Zero-phase Butterworth low-pass with the reference's fall-back for short series."""
+    lib = _lib.load()
+    b, a, zi = _butter_design(order, cutoff / (0.5 * fs))
+    x = _f64(x)
+    out = np.empty_like(x)
+    _lib.check(lib.svc_host_lowpass(_p(b), _p(a), _p(zi), len(b), _p(x), len(x), _p(out)))
+    return out
 
 
 def loess(y, window, degree):
-    """pyloess.Loess(arange(n), y).estimate(j, window, degree=degree) for every j, vectorised."""
-    y = np.asarray(y, np.float64)
-    n = y.shape[0]
-    ymin, ymax = y.min(), y.max()
-    idx, w, nx, op, xp = _loess_design(n, int(window), int(degree))
-    with np.errstate(all='ignore'):
-        ny = (y - ymin) / (ymax - ymin)
-        if degree > 1:
-            beta = op @ ny[idx][:, :, None]                                       # [n, d+1, 1]
-            est = np.einsum('nd,nd->n', beta[:, :, 0], xp)
-        else:
-            j = np.arange(n)
-            sx, sy = nx[idx], ny[idx]
-            sw = w.sum(axis=1)
-            mx, my = (sx * w).sum(1) / sw, (sy * w).sum(1) / sw
-            b = ((sx * sy * w).sum(1) - mx * my * sw) / ((sx * sx * w).sum(1) - mx * mx * sw)
-            est = (my - b * mx) + b * nx[j]
-        return est * (ymax - ymin) + ymin
+    """pyloess.Loess(arange(n), y).estimate(j, window, degree=degree) for every j."""
+    lib = _lib.load()
+    y = _f64(y)
+    out = np.empty_like(y)
+    _lib.check(lib.svc_host_loess(_p(y), len(y), int(window), int(degree), _p(out)))
+    return out
 
 
 def loess_handler(di, loess_filt, window, degree):
@@ -144,7 +112,38 @@ def loess_handler(di, loess_filt, window, degree):
     if loess_filt:
         ds = loess(di, window, degree)
         return list(di) if np.isnan(np.sum(ds)) else list(ds)
-    return list(_signal.savgol_filter(di, window, degree))
+    lib = _lib.load()
+    y = _f64(di)
+    out = np.empty_like(y)
+    if lib.svc_host_savgol(_p(y), n, int(window), int(degree), _p(out)) < 0:
+        raise ValueError(lib.svc_last_error().decode(errors='replace'))
+    return list(out)
+
+
+def temporal_params(fr, CP):
+    """-> (SvcTemporalParams, b, a, zi) for svc_host_temporal."""
+    b = a = zi = None
+    if CP['lp_filt']:
+        b, a, zi = _butter_design(CP['lp_order'], CP['lp_cutoff'] / (0.5 * fr))
+    p = _lib.SvcTemporalParams(ctypes.sizeof(_lib.SvcTemporalParams), int(bool(CP['lp_filt'])), 0 if b is None else len(b),
+                               int(bool(CP['loess_filt'])), int(CP['loess_degree']), 0, float(CP['loess_w_secs']), float(fr))
+    return p, b, a, zi
+
+
+def centres_to_series(xy, true_inds, segmentation, segmentation_sel, fc, fr, CP):
+    """sc_interpolate + sc_smoothing of one video in ONE native call: xy float64 [n_sel, 2] without NaN ->
+    (xi, yi, xs, ys) float64 [fc] each (interpolated, then low-passed and LOESS / Savitzky-Golay smoothed)."""
+    lib = _lib.load()
+    p, b, a, zi = temporal_params(fr, CP)
+    cx, cy = _f64(xy[:, 0]), _f64(xy[:, 1])
+    ti, seg, sel = _i32(true_inds), _i32(segmentation).reshape(-1, 2), _i32(segmentation_sel).reshape(-1, 2)
+    n_out = int((seg[:, 1] - seg[:, 0] + 1).sum())
+    out = np.empty((4, max(n_out, int(fc))), np.float64)
+    rc = lib.svc_host_temporal(ctypes.byref(p), _p(b) if b is not None else None, _p(a) if a is not None else None,
+                               _p(zi) if zi is not None else None, _p(cx), _p(cy), len(cx), _p(ti), _p(seg), _p(sel), len(seg),
+                               out.shape[1], _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]))
+    _lib.check(rc)
+    return out[0, :rc], out[1, :rc], out[2, :rc], out[3, :rc]
 
 
 def smoothing(dxi, dyi, segmentation, fr, CP):
@@ -161,6 +160,21 @@ def smoothing(dxi, dyi, segmentation, fr, CP):
             dl = butter_lowpass(d, CP['lp_cutoff'], fr, CP['lp_order']) if CP['lp_filt'] else d
             out += loess_handler(dl, CP['loess_filt'], win, CP['loess_degree'])
     return dxs, dys
+
+
+def boxes(dxs, dys, w_orig, h_orig, w_process, h_process, w_final, h_final, borders=(0, 0, 0, 0)):
+    """sc_compute_bb's arithmetic (smartVidCrop.py:979-1048) -> (boxes int64 [fc, 4], truncated centres int64 [fc, 2],
+    fbb_w, fbb_h)."""
+    lib = _lib.load()
+    xs, ys = _f64(dxs), _f64(dys)
+    fc = len(xs)
+    bb = np.empty((fc, 4), np.int64)
+    ctr = np.empty((fc, 2), np.int64)
+    wh = np.zeros(2, np.int32)
+    brd = _i32(borders)
+    _lib.check(lib.svc_host_boxes(_p(xs), _p(ys), fc, int(w_orig), int(h_orig), int(w_process), int(h_process), int(w_final),
+                                  int(h_final), _p(brd), _p(bb), _p(ctr), _p(wh)))
+    return bb, ctr, int(wh[0]), int(wh[1])
 
 
 def _points_on_line(p1x, p1y, p2x, p2y, w, h, min_d):

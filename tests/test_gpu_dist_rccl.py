@@ -1,7 +1,9 @@
 """-m gpu: the multi-rank code path of bench.py on RCCL with the one GPU a test box has: a child
 `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` with BENCH_FORCE_DIST=1 takes
 init_process_group('nccl'), the barriers, the MAX all-reduce of the timings and the box gather (dist.gather_boxes)
-on the device.  This module touches no GPU itself (no `engine` fixture): the child must be the first to initialise it."""
+on the device -- and runs the sharded 200-video job (config.config3: dist.crop_job over RCCL), whose gathered windows must be
+those of a single process without torch.distributed.  This module touches no GPU before the child has finished (no `engine`
+fixture): the child must be the first to initialise it."""
 import json
 import os
 import socket
@@ -30,3 +32,16 @@ def test_bench_under_torchrun_takes_the_rccl_path_at_world_1():
     d = json.loads(line)
     assert d['n_gpus'] == 1 and d['config']['world_size_seen_by_rccl'] == 1
     assert d['value'] > 0 and d['steps'] == 2
+    c3 = d['config']['config3']
+    assert c3['videos'] == 200 and c3['n_gpus'] == 1 and c3['per_rank_fixed_costs_s']['rccl_init'] > 0
+    # the same job in THIS process, no process group, frames generated on the fly: the windows must be the gathered ones
+    import numpy as np
+    from retargetvid_amd import evaluate as E, smartVidCrop as S, synth
+    fcs = E.frame_counts(os.path.join(ROOT, 'tests', 'golden', 'retargetvid'))
+    vids = list(E.VID_INDS)
+    videos = [dict(fr=30.0, frame_count=fcs[v], w=640, h=360, frames=synth.LazyBlobVideo(fcs[v], seed=v),
+                   trans_inds=synth.retargetvid_cuts(v, fcs[v])) for v in vids]
+    res = S.crop_videos(videos, S.sc_init_crop_params(), ('1:3', '3:1'), workers=4)
+    boxes = {r: {i: np.asarray(res[i][r][0]['bbs_np'], np.int32) for i in range(len(vids))} for r in ('1:3', '3:1')}
+    assert synth.windows_crc32(boxes, ('1:3', '3:1'), len(vids)) == c3['windows_crc32']
+    assert sum(len(b) for b in boxes['1:3'].values()) == c3['video_frames'] == 122684

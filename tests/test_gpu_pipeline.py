@@ -320,6 +320,9 @@ def test_feature_cache_in_temp_path(engine, tmp_path):
     b, _ = S.smart_vid_crop(no_frames, CP31, save_vid=False, engine=engine, temp_path=str(tmp_path))
     assert b['bbs'] == fresh31['bbs'] and b['true_inds'] == fresh31['true_inds']
     assert np.array_equal(b['smaps'], fresh31['smaps'])
+    with pytest.raises(TypeError):                             # another frame selection: the cached analysis is not re-used
+        S.smart_vid_crop(no_frames, dict(CP31, skip=4), save_vid=False, engine=engine, temp_path=str(tmp_path))
+    assert 'bbs' in b and b.get('bbs') == fresh31['bbs'] and set(['bbs', 'smaps']) <= set(dict(b))     # the lazy keys look present
 
 
 def test_frame_numbers_reach_the_device_without_a_synchronising_copy(engine):

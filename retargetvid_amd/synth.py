@@ -33,6 +33,22 @@ def blob_frames(n, h=360, w=640, seed=0, n_blobs=None, dtype=np.uint8, sigma=(20
     return out
 
 
+def blob_tracks(n, h=360, w=640, seed=0, n_blobs=None, sigma=(20, 60)):
+    """Where blob_frames(n, h, w, seed, ...) puts its blobs: -> (x [n, nb], y [n, nb], sigma [nb], amplitude [nb]) in pixels
+    of the h x w frame (the same RandomState draws, without rendering)."""
+    rng = np.random.RandomState(seed)
+    nb = int(rng.randint(1, 4)) if n_blobs is None else n_blobs
+    s = max(h, w) / 640.0
+    cx = rng.uniform(0.15 * w, 0.85 * w, nb)
+    cy = rng.uniform(0.2 * h, 0.8 * h, nb)
+    vx = rng.uniform(-3, 3, nb) * s
+    vy = rng.uniform(-2, 2, nb) * s
+    sig = rng.uniform(sigma[0], sigma[1], nb) * s
+    amp = rng.uniform(150, 200, nb)
+    i = np.arange(n)[:, None]
+    return (cx[None] + vx[None] * i) % w, (cy[None] + vy[None] * i) % h, sig, amp
+
+
 class LazyBlobVideo:
     """A synthetic video whose frames are generated on demand on the GPU (torch), so a
     RetargetVid-sized run (122 684 frames of 640x360) never materialises 85 GB of pixels.

@@ -88,6 +88,33 @@ def test_forward_matches_reference_model_without_carrier_all_geometries(golden_d
     assert np.ptp(g['u8_ri_16x9_0']) > 100
 
 
+def test_forward_matches_reference_model_on_the_trained_like_checkpoint(golden_dir):
+    """tests/golden/unisal_golden3.npz (tools/make_golden_unisal3.py): the reference model with its last decoder stage FITTED
+    to blob targets -- peaky maps like a trained network's -- at the three geometries, every frame."""
+    from retargetvid_amd import weights
+    torch.set_num_threads(4)
+    g = np.load(os.path.join(golden_dir, 'unisal_golden3.npz'))
+    sd = weights.make_trained_like_state_dict(golden_dir)
+    for gname in ('16x9', '4x3', 'port'):
+        frames = g['frames_' + gname]
+        h, w = frames.shape[1:3]
+        taps = {}
+        maps = U.saliency_u8(sd, frames, taps)
+        for i in range(frames.shape[0]):
+            tag = 'tl_%s_%d' % (gname, i)
+            t = taps['frames'][i]
+            lp = torch.log_softmax(t['pre'].reshape(1, -1), 1).reshape(h, w).numpy()
+            assert np.abs(lp - g['logp_' + tag]).max() < 1e-4, tag               # the log-softmax spans ~40 here (a peaky map)
+            d = np.abs(maps[:, :, i].astype(int) - g['u8_' + tag].astype(int))
+            assert d.max() <= 1 and (d > 0).mean() < 2e-3, tag
+            if i == 0:
+                ref = g['adapt_' + tag]
+                assert np.allclose(t['adapt'][0].numpy(), ref[0], rtol=1e-4, atol=1e-5 * np.abs(ref).max()), tag
+    # peaky: a few hundred points above the default threshold, a handful of pixels per grey level next to it
+    hist = g['level_hist_16x9'] / 24.0
+    assert 100 < hist[120:].sum() < 3000 and hist[110:131].mean() < 20
+
+
 def test_quantise_is_floor_of_scaled_softmax():
     x = torch.randn(2, 140, 250)
     q = U.quantise_u8(x)

@@ -22,6 +22,8 @@ def checkpoint(kind):
         return weights.make_synthetic_state_dict(0)
     if kind == 'nc':
         return weights.make_synthetic_state_dict(3, carrier=False)
+    if kind == 'tl':                                      # trained-like: the reference model fitted to blob targets (golden3)
+        return weights.make_trained_like_state_dict(os.path.join(ROOT, 'tests', 'golden'))
     g = np.load(os.path.join(ROOT, 'tests', 'golden', 'unisal_golden2.npz'))
     return weights.make_reference_init_state_dict(7, {k[3:]: g[k] for k in g.files if k.startswith('bn/')})
 
@@ -86,7 +88,7 @@ def main():
     from retargetvid_amd import ops
     out = {}
     n_vid = int(os.environ.get('PARITY_VIDEOS', 10))
-    for kind in os.environ.get('PARITY_CHECKPOINTS', 'ri,nc').split(','):
+    for kind in os.environ.get('PARITY_CHECKPOINTS', 'tl,ri,nc').split(','):
         sd = checkpoint(kind)
         eng = ops.Engine(sd)
         for best in (False, True):
@@ -101,7 +103,7 @@ def main():
                 out[key] = dict(error=repr(e))
                 print(key, 'ERROR', repr(e), flush=True)
         eng.close()
-    dst = os.path.join(ROOT, 'gpurun_out' if os.path.isdir(os.path.join(ROOT, 'gpurun_out')) else 'profiles', 'r03_iou_parity_ri.json')
+    dst = os.path.join(ROOT, 'gpurun_out' if os.path.isdir(os.path.join(ROOT, 'gpurun_out')) else 'profiles', os.environ.get('PARITY_OUT', 'r04_iou_parity.json'))
     with open(dst, 'w') as fp:
         json.dump(out, fp, indent=1)
     print('wrote', dst)

@@ -1318,6 +1318,428 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
 }
 __global__ __launch_bounds__(TB) void k_prim_lvl(TailArgs A) { prim_lvl_body(A); }
 
+// --------------------------------------------------------------------------------------
+// k_prim_lvl_big: the same rounds for maps of MORE than LVL_CAP points (up to the whole 255 x 255 grid).  Per-point state
+// does not fit in LDS there (35 000 points x (tree node 8 + core 4 + row/col 2 + reach 4 + block flags 0.5) B = 650 KB),
+// so it lives in the frame's workspace -- L2-resident, read with gathers -- and LDS keeps what every probe touches: the
+// occupancy grid, F, the ring table, the batch table, one box + minimum per chunk of 64 points.  The reach R of a chunk is
+// loaded, relaxed and stored per sweep instead of sitting in registers; a batch's 64 tree nodes are staged into a per-wave
+// LDS slab (one coalesced load) before they are broadcast to the lanes.  Same (last node, new node, weight) sequence as
+// k_prim_lvl and the library (tests: test_tail_maximum_size_all_pixels_set, the 288-map comparison with the one-node-per-step
+// kernels, tools/soak_tail.py).  Replaces the one-node-per-step k_prim_big (3 171 spilled VGPRs; 12 ms per map at N = 10 k,
+// 3.3 s at 25 k: profiles/r04_tail_vs_N.txt) on the default path.
+// --------------------------------------------------------------------------------------
+#define LVL_NBB 576                    // batches of tree nodes a big map can have pending: 36 864 nodes >= a whole 140 x 250 map (18 flag words per chunk)
+static size_t lvl_big_lds_bytes(int h, int w, int n_ring) {
+    const size_t cap = (size_t)h * w;
+    const size_t cells = (size_t)(h + 2 * LVL_PAD) * (w + 2 * LVL_PAD);
+    const size_t nf = (cap + 63) / 64;
+    auto up = [](size_t b) { return (b + 15) / 16 * 16; };
+    return up((cells + 31) / 32 * sizeof(OccW)) + up(nf * 8) + up((size_t)n_ring * 8) + up(64 * 4 * 4) + up(64 * 4 * 8) +
+           up(2 * NW16 * 4) + up(16) + up(LVL_NBB * 16) + up((LVL_RING2 + 1) * 2) + up(nf * 8) + up(nf * 4) + up(NW16 * 64 * 8) +
+           up(nf * (LVL_NBB / 32) * 4) + 64;
+}
+
+// lvl_sweep_chunk with the batch staged through the wave's LDS slab (tnode is in global memory here)
+template <bool NEAREST>
+__device__ __forceinline__ uint32_t lvl_sweep_chunk_big(const LvlLds &S, uint2 *stage, const uint4 *btab, uint32_t *proc, int nb, uint32_t limit,
+                                                        bool all, uint2 cb, uint32_t rcv, uint32_t cj, uint32_t r) {
+    const int lane = threadIdx.x & 63;
+    LvlLds T = S;
+    T.tnode = stage;
+    auto relax = [&](int b0) {
+        const uint32_t sl = btab[b0].x;
+        const int start = (int)(sl & 0xFFFFu), len = (int)(sl >> 16);
+        __builtin_amdgcn_wave_barrier();                                // the slab's previous readers are done
+        stage[lane] = S.tnode[start + min(lane, len - 1)];
+        __builtin_amdgcn_wave_barrier();
+        r = lvl_relax_block(T, 0, len, rcv, cj, r);
+    };
+    uint32_t bestkey = LVL_NONE;
+    for (int bb = 0; bb < nb; bb += 64) {
+        const int b = bb + lane;
+        uint32_t lb = LVL_NONE;
+        if (b < nb && !((proc[b >> 5] >> (b & 31)) & 1u)) {
+            const uint4 e = btab[b];
+            lb = all ? 0u : max(max(lvl_box_d2(e.y, cb.x), e.z), cb.y);
+        }
+        if (NEAREST) {
+            if (lb <= limit) bestkey = min(bestkey, (min(lb, 0x3FFFFFu) << 10) | (uint32_t)b);
+            continue;
+        }
+        unsigned long long todo = __ballot(lb <= limit && lb != LVL_NONE);
+        if (lane == 0 && todo) {
+            proc[bb >> 5] |= (uint32_t)todo;
+            if (bb + 32 < LVL_NBB) proc[(bb >> 5) + 1] |= (uint32_t)(todo >> 32);
+        }
+        while (todo) {
+            const int b0 = bb + __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            relax(b0);
+        }
+    }
+    if (NEAREST) {
+        bestkey = wave_min_u32(bestkey);
+        if (bestkey != LVL_NONE) {
+            const int b0 = (int)(bestkey & 1023u);
+            if (lane == 0) proc[b0 >> 5] |= 1u << (b0 & 31);
+            relax(b0);
+        }
+    }
+    return r;
+}
+
+__device__ __forceinline__ void prim_lvl_big_body(const TailArgs &A) {
+    uint8_t *ws = A.ws + (size_t)(A.slot0 + (int)blockIdx.x) * A.ws_stride;
+    int32_t *hdr = (int32_t *)(ws + A.L.hdr);
+    if (!hdr[3]) return;
+    const int N = hdr[0];
+    if (N <= LVL_CAP) return;                                         // k_prim_lvl (inside k_tail_front) has done it
+    extern __shared__ uint8_t sm_lvl[];
+    __shared__ int lds16[NW16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gw = A.w + 2 * LVL_PAD, gcells = (A.h + 2 * LVL_PAD) * gw, nocc = (gcells + 31) >> 5;
+    const int NF64 = (N + 63) >> 6;
+    const int capf = (A.h * A.w + 63) >> 6;
+    LvlLds S;
+    uint2 *cbx;                 // per chunk: box of its points outside the tree, their smallest core distance (LVL_NONE: none left)
+    uint32_t *cmin;             // per chunk: minimum of R
+    uint2 *stage;               // [NW16][64] a batch's tree nodes, per wavefront
+    {
+        uint8_t *p = sm_lvl;
+        S.occ = carve<OccW>(p, nocc);
+        S.F = carve<uint32_t>(p, (size_t)capf * 2);
+        S.ring = carve<uint2>(p, A.n_ring);
+        S.cand = carve<uint32_t>(p, 64 * 4);
+        S.slot = carve<uint2>(p, 64 * 4);
+        S.red = carve<uint32_t>(p, 2 * NW16);
+        S.ctl = carve<int>(p, 4);
+        S.btab = carve<uint4>(p, LVL_NBB);
+        S.rcnt = carve<uint16_t>(p, LVL_RING2 + 1);
+        cbx = carve<uint2>(p, capf);
+        cmin = carve<uint32_t>(p, capf);
+        stage = carve<uint2>(p, NW16 * 64);
+        S.proc = carve<uint32_t>(p, (size_t)capf * (LVL_NBB / 32));     // [chunks][LVL_NBB / 32] batch already relaxed against the chunk
+        S.gw = gw;
+    }
+    // per-point state in the frame's workspace (regions of stages that run later or not at all for this map)
+    S.tnode = (uint2 *)(ws + A.L.ea);                                 // k_sort's ping-pong buffer
+    S.corei = (uint32_t *)(ws + A.L.reach);
+    S.rc = (uint16_t *)(ws + A.L.sp);
+    uint32_t *Rg = (uint32_t *)(ws + A.L.absw);
+    uint2 *mystage = stage + wave * 64;
+    const long long t0 = wall_clock64();
+    const uint32_t *pts = (const uint32_t *)(ws + A.L.pts);
+    const uint32_t *core_g = (const uint32_t *)(ws + A.L.core);
+    hdb::Edge *mst = (hdb::Edge *)(ws + A.L.mst);
+    for (int i = tid; i < nocc; i += TB) S.occ[i] = OccW{0u, 0u};
+    for (int i = tid; i <= LVL_RING2; i += TB) S.rcnt[i] = A.ring_cnt[i];
+    for (int i = tid; i < A.n_ring; i += TB) {
+        const uint32_t o = A.ring[i];
+        S.ring[i] = make_uint2(o >> 16, (uint32_t)(((int)(o & 255) - 128) * gw + ((int)((o >> 8) & 255) - 128)));
+    }
+    __syncthreads();
+    for (int p = tid; p < N; p += TB) {
+        const uint32_t v = pts[p];
+        S.rc[p] = (uint16_t)(v & 0xFFFFu);
+        S.corei[p] = core_g[p];
+        Rg[p] = LVL_RINF;
+        const int cell = ((int)(v & 255) + LVL_PAD) * gw + (int)((v >> 8) & 255) + LVL_PAD;
+        atomicOr(&S.occ[cell >> 5].bits, 1u << (cell & 31));
+    }
+    for (int c = tid; c < NF64; c += TB) cmin[c] = LVL_RINF;
+    for (int i = tid; i < NF64 * (LVL_NBB / 32); i += TB) S.proc[i] = 0u;
+    __syncthreads();
+    {
+        const int per = (nocc + TB - 1) / TB, lo = min(nocc, tid * per), hi = min(nocc, lo + per);
+        int mine = 0;
+        for (int i = lo; i < hi; ++i) mine += __popc(S.occ[i].bits);
+        int tot;
+        int ex = block_excl_scan(mine, lds16, &tot);
+        for (int i = lo; i < hi; ++i) { S.occ[i].base = (uint32_t)ex; ex += __popc(S.occ[i].bits); }
+    }
+    if (tid == 0) {
+        const uint32_t v = S.rc[0];
+        S.tnode[0] = make_uint2((v & 255) | ((v >> 8) << 16), S.corei[0]);
+        S.corei[0] |= LVL_TREE;
+    }
+    __syncthreads();
+    int cnt = 1, done = 0, nb = 0, parity = 0;
+    uint32_t m = 0, cur = 0, swept = 0;
+    bool need_rise = true;
+    int n_rounds = 0, n_rises = 0;
+    if (tid == 0) hdr[24] = (int)(wall_clock64() - t0);
+    // minimum of cmin over the block (all wavefronts get it); one barrier
+    auto block_min_R = [&]() -> uint32_t {
+        uint32_t best = LVL_RINF;
+        for (int c = wave + lane * NW16; c < NF64; c += 64 * NW16) best = min(best, cmin[c]);      // this wavefront's own chunks
+        best = wave_min_u32(best);
+        uint32_t *red = S.red + parity * NW16;
+        parity ^= 1;
+        if (lane == 0) red[wave] = best;
+        __syncthreads();
+        uint32_t k2 = red[lane & 15];
+        k2 = dpp_min_u32<0x111, 0xF>(k2);
+        k2 = dpp_min_u32<0x112, 0xF>(k2);
+        k2 = dpp_min_u32<0x114, 0xF>(k2);
+        k2 = dpp_min_u32<0x118, 0xF>(k2);
+        return (uint32_t)__builtin_amdgcn_readlane((int)k2, 15);
+    };
+    // one sweep over this wavefront's chunks that still hold points outside the tree: R is loaded, relaxed, stored
+    auto sweep_all = [&](int mode, uint32_t limit, bool all) {      // mode 0: every batch within the limit, 1: the nearest one
+        for (int c = wave; c < NF64; c += NW16) {
+            const uint2 cb = cbx[c];
+            if (cb.y == LVL_NONE) continue;
+            const int p = c * 64 + lane;
+            uint32_t cj = LVL_TREE, rcv = 0, r = LVL_RINF;
+            if (p < N) {
+                cj = S.corei[p];
+                const uint32_t v = S.rc[p];
+                rcv = (v & 255) | ((v >> 8) << 16);
+                r = Rg[p];
+            }
+            uint32_t *proc = S.proc + c * (LVL_NBB / 32);
+            const uint32_t r0 = r;
+            if (mode == 0) r = lvl_sweep_chunk_big<false>(S, mystage, S.btab, proc, nb, limit, all, cb, rcv, cj, r);
+            else r = lvl_sweep_chunk_big<true>(S, mystage, S.btab, proc, nb, limit, all, cb, rcv, cj, r);
+            if (cj & LVL_TREE) r = LVL_RINF;
+            if (p < N && r != r0) Rg[p] = r;
+            const uint32_t mn = wave_min_u32(r);
+            if (lane == 0) cmin[c] = mn;
+        }
+    };
+    while (cnt < N) {
+        if (need_rise) {
+            ++n_rises;
+            // per chunk: tree members get an infinite reach; box and smallest core distance of the points still outside
+            for (int c = wave; c < NF64; c += NW16) {
+                const int p = c * 64 + lane;
+                uint32_t cj = LVL_TREE, rcv = 0;
+                if (p < N) {
+                    cj = S.corei[p];
+                    const uint32_t v = S.rc[p];
+                    rcv = (v & 255) | ((v >> 8) << 16);
+                }
+                const bool live = !(cj & LVL_TREE);
+                uint32_t r = LVL_RINF;
+                if (p < N) {
+                    r = live ? Rg[p] : LVL_RINF;
+                    if (!live) Rg[p] = LVL_RINF;
+                }
+                const uint32_t mn = wave_min_u32(r);
+                uint2 cb = make_uint2(0u, LVL_NONE);
+                if (__ballot(live)) {
+                    const uint32_t r_ = rcv & 0xFFFFu, c_ = rcv >> 16;
+                    const uint32_t rmin = wave_min_u32(live ? r_ : 255u), rmax = 255u - wave_min_u32(live ? 255u - r_ : 255u);
+                    const uint32_t cmn = wave_min_u32(live ? c_ : 255u), cmx = 255u - wave_min_u32(live ? 255u - c_ : 255u);
+                    const uint32_t kmin = wave_min_u32(live ? cj : LVL_RINF);
+                    cb = make_uint2(rmin | (rmax << 8) | (cmn << 16) | (cmx << 24), kmin);
+                }
+                if (lane == 0) { cbx[c] = cb; cmin[c] = mn; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // batches of <= 64 of the nodes [first, cnt) -> table entries from position `at` on
+            auto add_batches = [&](int first, int nbat, int at) {
+                for (int g = wave; g < nbat; g += NW16) {
+                    const int s0 = first + 64 * g, len = min(64, cnt - s0);
+                    const uint2 tn = S.tnode[s0 + min(lane, len - 1)];
+                    const uint32_t r = tn.x & 0xFFFFu, cc = tn.x >> 16;
+                    const uint32_t rmin = wave_min_u32(r), rmax = 255u - wave_min_u32(255u - r);
+                    const uint32_t cmn = wave_min_u32(cc), cmx = 255u - wave_min_u32(255u - cc);
+                    const uint32_t kmin = wave_min_u32(tn.y);
+                    if (lane == 0) S.btab[at + g] = make_uint4((uint32_t)s0 | ((uint32_t)len << 16), rmin | (rmax << 8) | (cmn << 16) | (cmx << 24), kmin, 0u);
+                }
+            };
+            int nnew = (cnt - done + 63) >> 6;
+            while (nb + nnew > LVL_NBB) {
+                // table full: settle every pending block, start afresh (N^2 work: the table is sized so that a 140 x 250 map never
+                // fills it).  More new nodes than the table holds (maps beyond 36 864 points) are entered a table at a time
+                if (nb) {
+                    sweep_all(0, 0u, true);
+                    for (int c = wave; c < NF64; c += NW16)
+                        for (int i = lane; i < LVL_NBB / 32; i += 64) S.proc[c * (LVL_NBB / 32) + i] = 0u;
+                    nb = 0;
+                    swept = 0;
+                    __syncthreads();                                   // every wavefront is done with the old table
+                }
+                if (nnew > LVL_NBB) {
+                    add_batches(done, LVL_NBB, 0);
+                    nb = LVL_NBB;
+                    done += 64 * LVL_NBB;
+                    nnew -= LVL_NBB;
+                    __syncthreads();                                   // the table is published
+                }
+            }
+            add_batches(done, nnew, nb);
+            const bool single = cnt - done == 1;                       // one new node (the start, a jump beyond the ring table)
+            if (single) {
+                const uint2 tn = S.tnode[done];
+                for (int c = wave; c < NF64; c += NW16) {
+                    if (cbx[c].y == LVL_NONE) continue;
+                    const int p = c * 64 + lane;
+                    uint32_t r = LVL_RINF;
+                    if (p < N) {
+                        const uint32_t cj = S.corei[p];
+                        if (!(cj & LVL_TREE)) {
+                            const uint32_t v = S.rc[p];
+                            const uint32_t rcv = (v & 255) | ((v >> 8) << 16);
+                            const lvl_s2 d = __builtin_bit_cast(lvl_s2, rcv) - __builtin_bit_cast(lvl_s2, tn.x);
+                            const uint32_t r0 = Rg[p];
+                            r = min(r0, max(max((uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false), cj), tn.y));
+                            if (r != r0) Rg[p] = r;
+                        }
+                    }
+                    const uint32_t mn = wave_min_u32(r);
+                    if (lane == 0) {
+                        cmin[c] = mn;
+                        S.proc[c * (LVL_NBB / 32) + (nb >> 5)] |= 1u << (nb & 31);
+                    }
+                }
+            }
+            nb += nnew;
+            done = cnt;
+            const uint32_t ub0 = block_min_R();                        // (its barrier also publishes the new batches)
+            const bool need_sweep = !(single && ub0 <= swept);
+            if (need_sweep) {
+                sweep_all(0, single ? ub0 : min(ub0, LVL_NEAR), false);
+                swept = single ? ub0 : min(ub0, LVL_NEAR);
+            }
+            if (ub0 > LVL_NEAR && !single) {
+                const uint32_t ub1 = block_min_R();
+                sweep_all(1, ub1, false);
+                const uint32_t ub2 = block_min_R();
+                sweep_all(0, ub2, false);
+                swept = max(swept, ub2);
+            }
+            m = need_sweep ? block_min_R() : ub0;
+            for (int c = wave; c < NF64; c += NW16) {
+                unsigned long long bal = 0ull;
+                if (cmin[c] == m) {
+                    const int p = c * 64 + lane;
+                    bal = __ballot(p < N && Rg[p] == m);
+                }
+                if (lane == 0) ((unsigned long long *)S.F)[c] = bal;
+            }
+            __syncthreads();
+            need_rise = false;
+        }
+        // ---- a round (as in prim_lvl_body)
+        const bool worker = wave < LVL_WORKERS;
+        const bool slow = m > (uint32_t)LVL_RING2;
+        const int nk = slow ? 0 : (int)S.rcnt[m];
+        const bool fast = nk <= 32 * LVL_WORKERS;
+        int ncand = 0, a = 1;
+        uint32_t mycand = LVL_NONE, m2 = LVL_NONE, entmask = 0;
+        bool dropped = false;
+        if (worker) {
+            uint32_t *cw = S.cand + wave * 64;
+            for (int wb = 0; wb < NF64 && ncand < 64; wb += 64) {
+                const int k = wb + lane;
+                const unsigned long long W = k < NF64 ? ((const unsigned long long *)S.F)[k] : 0ull;
+                unsigned long long nz = __ballot(W != 0ull);
+                while (nz && ncand < 64) {
+                    const int src = __builtin_ctzll(nz);
+                    nz &= nz - 1ull;
+                    const unsigned long long Wk = readlane_u64(W, src);
+                    if ((Wk >> lane) & 1ull) {
+                        const int rank = ncand + __popcll(Wk & ((1ull << lane) - 1ull));
+                        if (rank < 64) cw[rank] = (uint32_t)((wb + src) * 64 + lane);
+                    }
+                    ncand += __popcll(Wk);
+                }
+            }
+            ncand = min(ncand, 64);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < ncand) mycand = cw[lane];
+            if (!slow) {
+                uint32_t dmin, nmin;
+                lvl_walk<false>(S, wave, nk, m, lane < ncand, mycand, gw, dmin, nmin, entmask);
+                S.slot[wave * 64 + lane] = make_uint2(dmin, nmin);
+            }
+        }
+        if (!slow) __syncthreads();
+        ++n_rounds;
+        if (worker) {
+            if (!slow) {
+                uint2 sl = S.slot[lane];
+#pragma unroll
+                for (int w2 = 1; w2 < LVL_WORKERS; ++w2) {
+                    const uint2 t = S.slot[w2 * 64 + lane];
+                    sl.x = min(sl.x, t.x); sl.y = min(sl.y, t.y);
+                }
+                if (lane >= ncand) sl = make_uint2(LVL_NONE, LVL_NONE);
+                const uint32_t pend = wave_prefix_min_u32(sl.y);
+                const uint32_t nextf = (uint32_t)__builtin_amdgcn_update_dpp((int)mycand, (int)mycand, 0x130, 0xF, 0xF, false);
+                const bool stop = lane < ncand && (sl.x != LVL_NONE || (lane + 1 < ncand && pend < nextf));
+                const unsigned long long bal = __ballot(stop);
+                a = bal ? __builtin_ctzll(bal) + 1 : ncand;
+                m2 = (uint32_t)__builtin_amdgcn_readlane((int)sl.x, a - 1);
+                dropped = m2 != LVL_NONE;
+            }
+            const uint32_t prevc = (uint32_t)__builtin_amdgcn_update_dpp((int)mycand, (int)mycand, 0x138, 0xF, 0xF, false);
+            if (wave == 0 && lane < a) {
+                const uint32_t from = lane == 0 ? cur : prevc;
+                mst[cnt - 1 + lane] = hdb::Edge{(uint16_t)from, (uint16_t)mycand, m};
+                const uint32_t v = S.rc[mycand];
+                const uint32_t cj = S.corei[mycand];
+                S.tnode[cnt + lane] = make_uint2((v & 255) | ((v >> 8) << 16), cj);
+                S.corei[mycand] = cj | LVL_TREE;
+                if (!dropped) atomicAnd(&S.F[mycand >> 5], ~(1u << (mycand & 31u)));
+            }
+            if (!slow && !dropped && fast && lane < a && entmask) {
+                const uint32_t v = S.rc[mycand];
+                const uint32_t cell0 = ((v & 255) + LVL_PAD) * (uint32_t)gw + (v >> 8) + LVL_PAD;
+                uint32_t em = entmask;
+                while (em) {
+                    const int it = __builtin_ctz(em);
+                    em &= em - 1u;
+                    const uint32_t cell = cell0 + S.ring[LVL_WORKERS * it + wave].y;
+                    const OccW ow = S.occ[cell >> 5];
+                    const uint32_t j = ow.base + (uint32_t)__popc(ow.bits & ((1u << (cell & 31u)) - 1u));
+                    atomicOr(&S.F[j >> 5], 1u << (j & 31u));
+                }
+            }
+            if (dropped) for (int i = tid; i < 2 * NF64; i += 64 * LVL_WORKERS) S.F[i] = 0u;
+            if (wave == 0) {
+                const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)mycand, a - 1);
+                if (lane == 0) {
+                    S.ctl[0] = a;
+                    S.ctl[1] = dropped ? 1 : 0;
+                    S.ctl[2] = (int)(dropped ? m2 : m);
+                    S.ctl[3] = (int)last;
+                }
+            }
+        }
+        __syncthreads();
+        a = S.ctl[0];
+        dropped = S.ctl[1] != 0;
+        const uint32_t mnew = (uint32_t)S.ctl[2];
+        cur = (uint32_t)S.ctl[3];
+        cnt += a;
+        if (cnt >= N) break;
+        if (slow) { need_rise = true; continue; }
+        if (dropped || !fast) {
+            if (worker) {
+                const bool on = dropped ? lane == a - 1 : lane < a;
+                uint32_t d_, n_, e_;
+                lvl_walk<true>(S, wave, (int)S.rcnt[mnew], mnew, on, mycand, gw, d_, n_, e_);
+            }
+            m = mnew;
+            __syncthreads();
+        }
+        {
+            bool any = false;
+            for (int wb = 0; wb < NF64; wb += 64) {
+                const int k = wb + lane;
+                any = any || (__ballot(k < NF64 && ((const unsigned long long *)S.F)[k] != 0ull) != 0ull);
+            }
+            need_rise = !any;
+        }
+    }
+    if (tid == 0) { hdr[12] = (int)(wall_clock64() - t0); hdr[16] = n_rounds; hdr[17] = n_rises; }
+}
+__global__ __launch_bounds__(TB) void k_prim_lvl_big(TailArgs A) { prim_lvl_big_body(A); }
+
 // One 1x5 (ROWS) or 5x1 pass of the separable grey CLOSE over a map in LDS: MAX = dilate, else erode; samples
 // outside the image are ignored (OpenCV's morphology border).  A thread produces four consecutive outputs
 // along the pass direction from one sliding window of eight samples (2 LDS reads per output instead of 5).
@@ -1951,7 +2373,8 @@ __global__ __launch_bounds__(64) void k_tree(TailArgs A) {
 // the library's order), as in hdb::accumulate.  N - 1 serial union-find steps become ~15 block-wide passes.
 // --------------------------------------------------------------------------------------
 #define TP_CAP 4352                     // points per map with everything in LDS
-#define TP_CAP_BIG 8192                 // ... with the jump buffers, weights and order in the frame's workspace (above: k_tree)
+#define TP_CAP_BIG 8192                 // ... with the jump buffers, weights and order in the frame's workspace
+#define TP_CAP_HUGE 65025               // ... with every per-edge array there (L2-resident); LDS keeps the rank-maxima levels and the cluster tables
 #define TP_NONE 0xFFFFu
 enum { TP_SMALL = 0, TP_BIRTH = 1, TP_SPLIT = 2, TP_ABS_A = 3, TP_ABS_B = 4 };   // ABS_A: the a side is big, the b side falls out
 
@@ -1963,17 +2386,23 @@ struct TpCl {            // per condensed cluster
     uint8_t *sel;
 };
 
-static size_t tp_lds_bytes(int hw, int mcs, int *cap_clusters) {
+static size_t tp_lds_bytes(int hw, int mcs, int *cap_clusters, int *cap_clusters_huge = nullptr) {
     const int cap = std::min(hw, TP_CAP), capb = std::min(hw, TP_CAP_BIG);
     auto up = [](size_t b) { return (b + 15) / 16 * 16; };
     const size_t small = up((size_t)cap * 2) * 8 + up((size_t)(cap + 256) * 2) + up((size_t)cap * 4) * 3 + up((size_t)((cap + 256) / 16 + 16) * 2) + 64;
     const size_t big = hw > TP_CAP ? up((size_t)capb * 2) * 6 + up((size_t)(capb + 256) * 2) + up((size_t)((capb + 256) / 16 + 16) * 2) + 64 : 0;
-    const size_t per_edge = std::max(small, big);
-    int cc = hdb::max_clusters(capb, mcs);
+    const size_t huge = hw > TP_CAP_BIG ? up((size_t)((hw + 256) / 16 + 16) * 2) + up(((size_t)hw / 256 + 32) * 2) + up(32 * 2) + 64 : 0;
+    const size_t per_edge = std::max({small, big, huge});
+    int cc = hdb::max_clusters(std::min(hw, TP_CAP_HUGE), mcs);
     const size_t budget = 160 * 1024 - 4096;
     while (cc > 8 && per_edge + (size_t)cc * 48 + 512 > budget) cc /= 2;
     *cap_clusters = cc;
-    return per_edge + (size_t)cc * 48 + 512;
+    const size_t total = per_edge + (size_t)cc * 48 + 512;
+    if (cap_clusters_huge) {                               // MODE 2 keeps only the rank-maxima levels in LDS: the rest of the launch's allocation is cluster tables
+        const size_t room = total > huge + 512 ? (total - huge - 512) / 48 : 0;
+        *cap_clusters_huge = (int)std::min<size_t>(room, (size_t)hdb::max_clusters(std::min(hw, TP_CAP_HUGE), mcs));
+    }
+    return total;
 }
 
 // bit i set when the i-th of the 16 uint16 at p (32-byte aligned) is greater than r
@@ -1993,26 +2422,34 @@ __device__ __forceinline__ int tp_class(int sa, int sb, int mcs) {
     return sa >= mcs ? TP_ABS_A : TP_ABS_B;
 }
 
-// BIG = false: maps of up to TP_CAP points, everything in LDS.  BIG = true: up to TP_CAP_BIG points -- the weights and
+// MODE 0: maps of up to TP_CAP points, everything in LDS.  MODE 1 (BIG): up to TP_CAP_BIG points -- the weights and
 // the sorted order are read from the frame's workspace, the two jump buffers live there, the row lists re-use the
-// child links (dead by then), so that the rest still fits in LDS.
-template <bool BIG>
+// child links (dead by then), so that the rest still fits in LDS.  MODE 2 (HUGE, round 4): any map the tail takes -- the
+// seven per-edge arrays live in the workspace too (14 B per edge: 490 KB at 35 000 points, L2-resident), the passes are the
+// same block-wide gathers; the nearest-greater search walks four levels of rank maxima (fan-out 16: 16^4 = 65 536 >= E)
+// instead of three.  Replaces the serial k_tree (one wavefront: 4 - 11 ms per map at 10 - 35 k points) on the default path.
+template <int MODE>
 __device__ __forceinline__ void tp_body(const TailArgs &A, int cap_clusters, uint8_t *ws, int32_t *hdr, int N, uint8_t *sm_tp,
                                         int *lds16, int &sh_nc, int &sh_nsel) {
     const int E = N - 1, mcs = A.mcs;
 #define TP_STAMP(i) do { if (tid == 0) hdr[25 + (i)] = (int)(wall_clock64() - t0); } while (0)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long t0 = wall_clock64();
-    const int cap = min(A.h * A.w, BIG ? TP_CAP_BIG : TP_CAP);
+    constexpr bool BIG = MODE >= 1, HUGE = MODE == 2;
+    const int cap = min(A.h * A.w, HUGE ? TP_CAP_HUGE : (BIG ? TP_CAP_BIG : TP_CAP));
     uint8_t *p = sm_tp;
-    uint16_t *rho = carve<uint16_t>(p, cap + 256), *sa = carve<uint16_t>(p, cap), *sb = carve<uint16_t>(p, cap);
-    uint16_t *par = carve<uint16_t>(p, cap), *lch = carve<uint16_t>(p, cap), *rch = carve<uint16_t>(p, cap), *cid = carve<uint16_t>(p, cap);
+    // HUGE: regions of the frame's workspace that only the serial builder (k_tree) and the finished Prim use
+    uint16_t *rho = HUGE ? (uint16_t *)(ws + A.L.absw) : carve<uint16_t>(p, cap + 256);
+    uint16_t *sa = HUGE ? (uint16_t *)(ws + A.L.sp) : carve<uint16_t>(p, cap), *sb = HUGE ? (uint16_t *)(ws + A.L.ssz) : carve<uint16_t>(p, cap);
+    uint16_t *par = HUGE ? (uint16_t *)(ws + A.L.absc) : carve<uint16_t>(p, cap), *lch = HUGE ? (uint16_t *)(ws + A.L.evc) : carve<uint16_t>(p, cap);
+    uint16_t *rch = HUGE ? (uint16_t *)(ws + A.L.evs) : carve<uint16_t>(p, cap), *cid = HUGE ? (uint16_t *)(ws + A.L.sdn) : carve<uint16_t>(p, cap);
     uint16_t *order = BIG ? nullptr : carve<uint16_t>(p, cap);
     uint16_t *rowlist = BIG ? lch : carve<uint16_t>(p, cap);
     uint32_t *w = BIG ? nullptr : carve<uint32_t>(p, cap);
     uint32_t *jA = BIG ? (uint32_t *)(ws + A.L.dparent) : carve<uint32_t>(p, cap);
     uint32_t *jB = BIG ? (uint32_t *)(ws + A.L.dparent) + (size_t)A.h * A.w : carve<uint32_t>(p, cap);
-    uint16_t *l1 = carve<uint16_t>(p, (cap + 256) / 16 + 16), *l2 = carve<uint16_t>(p, 32);
+    uint16_t *l1 = carve<uint16_t>(p, (cap + 256) / 16 + 16), *l2 = carve<uint16_t>(p, HUGE ? cap / 256 + 32 : 32);
+    uint16_t *l3 = HUGE ? carve<uint16_t>(p, 32) : nullptr;
 #define TP_ORDER(s_) (BIG ? (int)perm[s_] : (int)order[s_])
 #define TP_W(k_) (BIG ? mst[k_].w : w[k_])
     TpCl C;
@@ -2046,12 +2483,21 @@ __device__ __forceinline__ void tp_body(const TailArgs &A, int cap_clusters, uin
         l1[g] = (uint16_t)mx;
     }
     __syncthreads();
-    for (int g = tid; g < 32; g += TB) {
+    const int n3 = (n2 + 15) >> 4;                                        // HUGE: <= 16 groups of 16 second-level maxima
+    for (int g = tid; g < (HUGE ? n3 * 16 : 32); g += TB) {
         uint32_t mx = 0;
         if (g < n2) for (int i = 0; i < 16; ++i) mx = max(mx, (uint32_t)l1[16 * g + i]);
         l2[g] = (uint16_t)mx;
     }
     __syncthreads();
+    if (HUGE) {
+        for (int g = tid; g < 16; g += TB) {
+            uint32_t mx = 0;
+            if (g < n3) for (int i = 0; i < 16; ++i) mx = max(mx, (uint32_t)l2[16 * g + i]);
+            l3[g] = (uint16_t)mx;
+        }
+        __syncthreads();
+    }
     // ---- nearest greater ranks on both sides -> side sizes, Cartesian-tree parent, children
     for (int k = tid; k < E; k += TB) {
         const uint32_t r = rho[k];
@@ -2065,7 +2511,20 @@ __device__ __forceinline__ void tp_body(const TailArgs &A, int cap_clusters, uin
                 int g = -1;
                 uint32_t m1 = tp_gt_mask16(l1 + 16 * s0, r) & ~((2u << (g0 & 15)) - 1u);
                 if (m1) g = 16 * s0 + __builtin_ctz(m1);
-                else {
+                else if (HUGE) {
+                    const int t0_ = s0 >> 4;
+                    int sx = -1;
+                    const uint32_t m2 = tp_gt_mask16(l2 + 16 * t0_, r) & ~((2u << (s0 & 15)) - 1u);
+                    if (m2) sx = 16 * t0_ + __builtin_ctz(m2);
+                    else {
+                        const uint32_t m3 = tp_gt_mask16(l3, r) & ~((2u << t0_) - 1u);
+                        if (m3) {
+                            const int tx = __builtin_ctz(m3);
+                            sx = 16 * tx + __builtin_ctz(tp_gt_mask16(l2 + 16 * tx, r));
+                        }
+                    }
+                    if (sx >= 0) g = 16 * sx + __builtin_ctz(tp_gt_mask16(l1 + 16 * sx, r));
+                } else {
                     uint32_t m2 = (tp_gt_mask16(l2, r) | (tp_gt_mask16(l2 + 16, r) << 16)) & ~((2u << s0) - 1u);
                     if (s0 >= 31) m2 = 0;
                     if (m2) {
@@ -2085,7 +2544,20 @@ __device__ __forceinline__ void tp_body(const TailArgs &A, int cap_clusters, uin
                 int g = -1;
                 uint32_t m1 = tp_gt_mask16(l1 + 16 * s0, r) & ((1u << (g0 & 15)) - 1u);
                 if (m1) g = 16 * s0 + 31 - __builtin_clz(m1);
-                else {
+                else if (HUGE) {
+                    const int t0_ = s0 >> 4;
+                    int sx = -1;
+                    const uint32_t m2 = tp_gt_mask16(l2 + 16 * t0_, r) & ((1u << (s0 & 15)) - 1u);
+                    if (m2) sx = 16 * t0_ + 31 - __builtin_clz(m2);
+                    else {
+                        const uint32_t m3 = tp_gt_mask16(l3, r) & ((1u << t0_) - 1u);
+                        if (m3) {
+                            const int tx = 31 - __builtin_clz(m3);
+                            sx = 16 * tx + 31 - __builtin_clz(tp_gt_mask16(l2 + 16 * tx, r));
+                        }
+                    }
+                    if (sx >= 0) g = 16 * sx + 31 - __builtin_clz(tp_gt_mask16(l1 + 16 * sx, r));
+                } else {
                     const uint32_t m2 = (tp_gt_mask16(l2, r) | (tp_gt_mask16(l2 + 16, r) << 16)) & ((1u << s0) - 1u);
                     if (m2) {
                         const int sx = 31 - __builtin_clz(m2);
@@ -2305,19 +2777,20 @@ __device__ __forceinline__ void tp_body(const TailArgs &A, int cap_clusters, uin
 #undef TP_ORDER
 #undef TP_W
 
-__device__ __forceinline__ void tree_par_body(const TailArgs &A, int cap_clusters) {
+__device__ __forceinline__ void tree_par_body(const TailArgs &A, int cap_clusters, int cap_clusters_huge) {
     uint8_t *ws = A.ws + (size_t)(A.slot0 + (int)blockIdx.x) * A.ws_stride;
     int32_t *hdr = (int32_t *)(ws + A.L.hdr);
     if (!hdr[3]) return;
     const int N = hdr[0];
-    if (N > TP_CAP_BIG) return;                                        // k_tree takes it
+    if (N > TP_CAP_HUGE) return;                                       // (never: the tail takes maps of up to 255 x 255)
     extern __shared__ uint8_t sm_tp[];
     __shared__ int lds16[NW16];
     __shared__ int sh_nc, sh_nsel;
-    if (N <= TP_CAP) tp_body<false>(A, cap_clusters, ws, hdr, N, sm_tp, lds16, sh_nc, sh_nsel);
-    else tp_body<true>(A, cap_clusters, ws, hdr, N, sm_tp, lds16, sh_nc, sh_nsel);
+    if (N <= TP_CAP) tp_body<0>(A, cap_clusters, ws, hdr, N, sm_tp, lds16, sh_nc, sh_nsel);
+    else if (N <= TP_CAP_BIG) tp_body<1>(A, cap_clusters, ws, hdr, N, sm_tp, lds16, sh_nc, sh_nsel);
+    else tp_body<2>(A, cap_clusters_huge, ws, hdr, N, sm_tp, lds16, sh_nc, sh_nsel);
 }
-__global__ __launch_bounds__(TB) void k_tree_par(TailArgs A, int cap_clusters) { tree_par_body(A, cap_clusters); }
+__global__ __launch_bounds__(TB) void k_tree_par(TailArgs A, int cap_clusters, int cap_clusters_huge) { tree_par_body(A, cap_clusters, cap_clusters_huge); }
 
 // k_finish: zero everything outside the kept cluster, CLOSE 5x5, write the map back, centroid
 __device__ __forceinline__ void finish_body(const TailArgs &A) {
@@ -2424,12 +2897,12 @@ __global__ __launch_bounds__(TB) void k_tail_front(TailArgs A) {           // k_
     prim_lvl_body(A);
 }
 
-__global__ __launch_bounds__(TB) void k_tail_back(TailArgs A, int cap_clusters) {   // k_sort -> k_tree_par -> k_finish
+__global__ __launch_bounds__(TB) void k_tail_back(TailArgs A, int cap_clusters, int cap_clusters_huge) {   // k_sort -> k_tree_par -> k_finish
     int32_t *hdr = (int32_t *)(A.ws + (size_t)(A.slot0 + (int)blockIdx.x) * A.ws_stride + A.L.hdr);
     if (A.tail_prio) __builtin_amdgcn_s_setprio(3);
     sort_body(A);
     __syncthreads();
-    tree_par_body(A, cap_clusters);
+    tree_par_body(A, cap_clusters, cap_clusters_huge);
     __syncthreads();
     if (hdr[3] && !hdr[23]) return;                                        // hierarchy not done here: k_tree, then k_finish
     finish_body(A);
@@ -2704,6 +3177,7 @@ static int cluster_center_impl(SvcHandle *h, uint8_t *maps, int n, int height, i
         SVC_HIP(hipFuncSetAttribute((const void *)k_prim_pt<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_prim_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_prim_lvl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_prim_lvl_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_tree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_tree_par, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
@@ -2728,9 +3202,10 @@ static int cluster_center_impl(SvcHandle *h, uint8_t *maps, int n, int height, i
             k_map_resize<<<dim3(8, m), 256, 0, s>>>(full_maps, maps, rs_down, ord, full_h, full_w, height, width);
             SVC_CHECK_LAUNCH();
         }
-        int cap_cl = 0;
-        const size_t lds_tp = tp_lds_bytes(hw, params->hdbscan_min, &cap_cl);
-        const bool tree_fallback = !h->tree_par || hw > TP_CAP_BIG || hdb::max_clusters(std::min(hw, TP_CAP_BIG), params->hdbscan_min) > cap_cl;
+        int cap_cl = 0, cap_cl_huge = 0;
+        const size_t lds_tp = tp_lds_bytes(hw, params->hdbscan_min, &cap_cl, &cap_cl_huge);
+        const bool tree_fallback = !h->tree_par || hw > TP_CAP_HUGE || hdb::max_clusters(std::min(hw, TP_CAP_BIG), params->hdbscan_min) > cap_cl ||
+                                   (hw > TP_CAP_BIG && hdb::max_clusters(std::min(hw, TP_CAP_HUGE), params->hdbscan_min) > cap_cl_huge);
         if (params->clust_filt && h->tail_merge && h->prim_lvl && h->tree_par) {
             // two fused launches per round (k_tail_front, k_tail_back) + the stand-alone kernels for what they leave
             const size_t lds_front = std::max({(size_t)(hw + 15) / 16 * 16, lds_core, lvl_lds_bytes(height, width, h->tail_n_offsets)});
@@ -2739,10 +3214,10 @@ static int cluster_center_impl(SvcHandle *h, uint8_t *maps, int n, int height, i
                 ProfScope ps(h, SVC_K_PRIM, s);
                 k_tail_front<<<m, TB, lds_front, s>>>(A);
                 SVC_CHECK_LAUNCH();
-                if (hw > 8 * TB) { k_prim_big<<<m, TB, lds_prim, s>>>(A, LVL_CAP); SVC_CHECK_LAUNCH(); }
+                if (hw > LVL_CAP) { k_prim_lvl_big<<<m, TB, lvl_big_lds_bytes(height, width, h->tail_n_offsets), s>>>(A); SVC_CHECK_LAUNCH(); }
             }
             ProfScope ps(h, SVC_K_FINISH, s);
-            k_tail_back<<<m, TB, lds_back, s>>>(A, cap_cl);
+            k_tail_back<<<m, TB, lds_back, s>>>(A, cap_cl, cap_cl_huge);
             SVC_CHECK_LAUNCH();
             if (tree_fallback) {
                 k_tree<<<m, 64, FIN_LDS_BYTES, s>>>(A);
@@ -2773,7 +3248,8 @@ static int cluster_center_impl(SvcHandle *h, uint8_t *maps, int n, int height, i
                 if (h->prim_pt <= 4 && (hw > 2 * TB || h->prim_pt > 2)) { k_prim_pt<4><<<m, TB, lds_prim, s>>>(A, n_min); SVC_CHECK_LAUNCH(); }
                 if (hw > 4 * TB || h->prim_pt > 4) { k_prim_pt<8><<<m, TB, lds_prim, s>>>(A, n_min); SVC_CHECK_LAUNCH(); }
             }
-            if (hw > 8 * TB) { k_prim_big<<<m, TB, lds_prim, s>>>(A, n_min); SVC_CHECK_LAUNCH(); }
+            if (hw > LVL_CAP && h->prim_lvl) { k_prim_lvl_big<<<m, TB, lvl_big_lds_bytes(height, width, h->tail_n_offsets), s>>>(A); SVC_CHECK_LAUNCH(); }
+            else if (hw > 8 * TB) { k_prim_big<<<m, TB, lds_prim, s>>>(A, n_min); SVC_CHECK_LAUNCH(); }
         }
         {
             ProfScope ps(h, SVC_K_FINISH, s);
@@ -2781,7 +3257,7 @@ static int cluster_center_impl(SvcHandle *h, uint8_t *maps, int n, int height, i
                 k_sort<<<m, TB, SORT_LDS_BYTES, s>>>(A);
                 SVC_CHECK_LAUNCH();
                 if (h->tree_par) {
-                    k_tree_par<<<m, TB, lds_tp, s>>>(A, cap_cl);
+                    k_tree_par<<<m, TB, lds_tp, s>>>(A, cap_cl, cap_cl_huge);
                     SVC_CHECK_LAUNCH();
                 }
                 // the serial builder: maps the parallel one does not hold in LDS (more points or clusters), or all (SVC_TREE_PAR=0)

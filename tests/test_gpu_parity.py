@@ -378,6 +378,73 @@ def test_tail_maximum_size_all_pixels_set(engine):
     _check_tail(engine, m, None, CP)                   # (the O(N^2) oracle needs about a minute for this one map)
 
 
+def _dense_maps(rng, n, lo, hi):
+    """140 x 250 maps with between lo and hi points: big soft blobs, dense noise, noise inside a blob, stripes with holes."""
+    ys, xs = np.mgrid[0:140, 0:250]
+    out = []
+    while len(out) < n:
+        kind = len(out) % 4
+        m = np.zeros((140, 250), np.float32)
+        if kind in (0, 2):
+            for _ in range(rng.randint(1, 4)):
+                cy, cx = rng.uniform(20, 120), rng.uniform(30, 220)
+                ry, rx = rng.uniform(25, 90), rng.uniform(40, 160)
+                m = np.maximum(m, 255 * np.exp(-(((ys - cy) / ry) ** 2 + ((xs - cx) / rx) ** 2) * rng.uniform(0.6, 2.0)))
+            if kind == 2:
+                m = m * (rng.rand(140, 250) < rng.uniform(0.5, 0.9))          # a blob with holes: core distances vary
+        elif kind == 1:
+            m = 255.0 * (rng.rand(140, 250) < rng.uniform(0.25, 0.95))        # dense noise
+        else:
+            m = 255.0 * (np.sin(xs / rng.uniform(3, 11)) * np.sin(ys / rng.uniform(3, 9)) > rng.uniform(-0.6, 0.2))
+        u = np.clip(m + rng.uniform(0, 30) * rng.rand(140, 250), 0, 255).astype(np.uint8)
+        u[u < 120] = 0
+        if lo <= int((u > 0).sum()) <= hi:
+            out.append(u)
+    return np.stack(out)
+
+
+def test_maps_beyond_8192_points_new_kernels_equal_the_round2_kernels_and_the_oracle(engine):
+    """Round 4: maps of more than 8 192 points run the level-bucketed Prim with its per-point state in the workspace
+    (k_prim_lvl_big) and the path-structured hierarchy with its per-edge arrays there (tp_body<2>) instead of the
+    one-node-per-step Prim and the serial union-find.  24 maps of 8.5 - 22 k points (blobs, dense noise, blobs with holes,
+    lattices) x both parameter sets against those round-2 kernels (Prim edge list, labels, maps, centres: identical), one
+    ~9 k-point map against the oracle, and no map left to the fall-back kernels (hdr[23] = done by k_tree_par)."""
+    import os
+    saved = {k: os.environ.get(k) for k in ('SVC_PRIM_LVL', 'SVC_TREE_PAR', 'SVC_TAIL_MERGE')}
+    try:
+        os.environ.update(SVC_PRIM_LVL='0', SVC_TREE_PAR='0', SVC_TAIL_MERGE='0')
+        old = ops.Engine(seed=0)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        rng = np.random.RandomState(77)
+        maps = _dense_maps(rng, 24, 8500, 22000)
+        flags = np.zeros(24, np.uint8)
+        flags[[3, 4, 11]] = 1
+        for CP in (P.init_crop_params(), dict(P.init_crop_params(), hdbscan_min=5, hdbscan_min_samples=3, select_sum=1)):
+            a, b = torch.from_numpy(maps).cuda(), torch.from_numpy(maps).cuda()
+            xa, sa = old.cluster_center_(a, flags, CP, want_stats=True)
+            xb, sb = engine.cluster_center_(b, flags, CP, want_stats=True)
+            assert torch.equal(a, b) and torch.equal(sa, sb)
+            assert np.array_equal(xa.cpu().numpy(), xb.cpu().numpy(), equal_nan=True)
+            assert int(sb[:, 0].min()) > 8192
+            for i in range(0, 24, 3):
+                s_old, s_new = old.cluster_state(i, 35000), engine.cluster_state(i, 35000)
+                assert np.array_equal(s_old['mst'], s_new['mst']), 'Prim sequence of map %d (N = %d)' % (i, s_old['n'])
+                assert np.array_equal(s_old['labels'], s_new['labels']), 'labels of map %d' % i
+                assert s_new['hdr'][16] > 0                                    # Prim in rounds (k_prim_lvl_big)
+                if CP['hdbscan_min'] == 26:                                    # (min_cluster_size 5 on 20 k points: more clusters than the
+                    assert s_new['hdr'][23] == 1                               #  LDS tables hold -> the serial builder; not a shipped setting)
+        small = _dense_maps(np.random.RandomState(78), 1, 8300, 9500)
+        _check_tail(engine, small, None, P.init_crop_params())                  # (the O(N^2) oracle: ~10 s)
+    finally:
+        old.close()
+
+
 def test_tail_batch_independence_at_full_size(engine):
     """Size-independent property at BASELINE config 2 (B=32, 640x360): every map's result is
     independent of the batch it is processed in, and filtering only ever removes/closes."""

@@ -1994,6 +1994,12 @@ static int launch_dw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer
 // the end and are added in wave order, so the result is deterministic and independent of the batch.
 // --------------------------------------------------------------------------------------
 #define IRB_ES 36      // LDS row stride (floats) of 32-channel tiles: 32 + 4 pad (conflict-free float4 rows)
+#ifndef IRB_XREG
+#define IRB_XREG 1     // 0: the pixel operand of k_irb's expand GEMM staged in LDS (rounds 1-3), for A/B runs of tools/micro/irb_time.hip
+#endif
+#ifndef IRB_WAVES
+#define IRB_WAVES 4    // minimum waves per SIMD the register allocation of k_irb has to allow (4: <= 128 VGPRs, four workgroups per CU)
+#endif
 #ifndef IRB_STAMP
 #define IRB_STAMP(i)   // phase stamps of k_irb: defined by tools/micro/irb_phases.hip only (no code in the product)
 #endif
@@ -2191,7 +2197,7 @@ static int launch_dwpw(SvcHandle *h, hipStream_t s, const float *X, const SvcLay
     ProfScope ps(h, SVC_K_PW, s);
     const int C = Ld.cout, N = Lp.cout, Npad = (N + 31) / 32 * 32, tiles = Npad / 32;
     // output-channel groups of at most 5 tiles, as even as possible (the depthwise part is redone per group)
-    const int groups = ceil_div(tiles, 5), nt = ceil_div(tiles, groups);
+    const int groups = ceil_div(tiles, std::min(5, std::max(1, h->dwpw_max_nt))), nt = ceil_div(tiles, groups);
     const int pw = (W % 8 == 0 || W > 16) ? 8 : 16;          // 8x4 patches; 16x2 on the narrow 13-wide level
     const int tx = ceil_div(W, pw), ty = ceil_div(H, 32 / pw);
     dim3 grid((unsigned)(n * tx * ty), groups);
@@ -2238,9 +2244,9 @@ struct IrbGeom {
     // floats of LDS; rows NPX..MT*32-1 of Xs are never written: the expand MFMA reads whatever lies behind them
     // (the E array, so still inside the allocation) into accumulator rows that are discarded.  Every byte counts:
     // three workgroups per CU need <= 53 KB each.
-    static size_t lds_floats(int Cin, int CoutP, bool expand, int Ce = 0) {
+    static size_t lds_floats(int Cin, int CoutP, bool expand, int Ce = 0, bool xreg = false) {
         const size_t XS = Cin + 4;
-        size_t n = (size_t)NPX * XS + (expand ? (size_t)NPX * IRB_ES : 0) + (size_t)NOUT * IRB_ES;
+        size_t n = (xreg ? 0 : (size_t)NPX * XS) + (expand ? (size_t)NPX * IRB_ES : 0) + (size_t)NOUT * IRB_ES;
         n += (expand ? 32 * XS : 0) + (size_t)CoutP * IRB_ES + 9 * 32;
         n += 2 * (size_t)((Ce + 31) / 32 * 32);             // expand / depthwise biases of every chunk
         return n;
@@ -2251,7 +2257,7 @@ struct IrbGeom {
 // distinct shapes): strides, trip counts and the slice bookkeeping fold to constants, which matters because the
 // kernel is bound by instruction issue.  0 = take them from the arguments (any other shape).
 template <int S, int TOH, int TOW, bool EXPAND, bool STEM = false, int CIN = 0, int CE = 0, int COUT = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_irb(const float *__restrict__ X, int H, int W, int Cin_,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRB_WAVES, 8))) void k_irb(const float *__restrict__ X, int H, int W, int Cin_,
                                              const float *__restrict__ We, const float *__restrict__ be, int Ce_,
                                              const float *__restrict__ Wd, const float *__restrict__ bd,
                                              const float *__restrict__ Wp, const float *__restrict__ bp, int Cout_,
@@ -2265,8 +2271,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     constexpr int NOUT = G::NOUT, MP = NOUT / 32;
     extern __shared__ float sm_irb[];
     const int XS = Cin + 4;
-    float *Xs = sm_irb;                                     // [NPX][XS]
-    float *E = EXPAND ? Xs + NPX * XS : Xs;                 // [NPX][IRB_ES]   (t=1: XS == IRB_ES, E is Xs)
+    // XREG (round 4; the fixed-shape expanding instances): the pixel operand of the expand GEMM -- the lane's halo pixel, Cin
+    // floats -- does not depend on the chunk, so it is loaded ONCE from global memory into registers (Cin / 8 float4 per
+    // expand tile of the wave) instead of being staged in LDS and re-read for every chunk: no Xs array (11 - 14 KB less LDS:
+    // four workgroups per CU instead of three where the rest fits in 40 KB), no prologue fill, 3 - 4 ds_read_b128 less per
+    // chunk and wave.  Same values, same k order: bit-identical.
+    constexpr bool XREG = IRB_XREG && EXPAND && !STEM && CIN > 0 && CIN <= 32 && (CIN % 8) == 0;
+    float *Xs = sm_irb;                                     // [NPX][XS]   (not with XREG)
+    float *E = EXPAND ? Xs + (XREG ? 0 : NPX * XS) : Xs;    // [NPX][IRB_ES]   (t=1: XS == IRB_ES, E is Xs)
     float *D = E + NPX * IRB_ES;                            // [NOUT][IRB_ES]
     float *Wes = D + NOUT * IRB_ES;                         // [32][XS]        expand weights of the chunk
     float *Wps = Wes + (EXPAND ? 32 * XS : 0);              // [CoutP][IRB_ES] project weights of the chunk
@@ -2366,6 +2378,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     } else {
         // 1. input halo and the first weight slices -> LDS (zeros outside the image)
         const float *xf = X + (size_t)f * H * W * Cin;
+        if (!XREG)
         for (int idx = tid; idx < NPX * c4n; idx += 256) {
             const int row = idx / c4n, c4 = idx - row * c4n;
             const int hy = row / IW, hx = row - hy * IW;
@@ -2378,6 +2391,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 #pragma unroll
         for (int q = 0; q < 3; ++q) store_we(q, load_we(0, q));
         if (wd_mine) *(float4 *)(Wds + wd_t * 32 + wd_c4 * 4) = load_wd(0);
+    }
+    // XREG: the lane's halo pixel(s), Cin floats each, straight from global memory into registers (requested before the
+    // prologue's barrier; rows beyond the halo and pixels outside the image read a clamped address: their E rows are
+    // masked in the expand epilogue)
+    constexpr int XK = XREG ? CIN / 8 : 1, XT = XREG ? (G::MT + 3) / 4 : 1;
+    float4 xa[XT][XK];
+    if constexpr (XREG) {
+        const float *xf = X + (size_t)f * H * W * Cin;
+#pragma unroll
+        for (int u = 0; u < XT; ++u) {
+            const int mt = (G::MT == 5 && u == 1) ? 4 : wave + 4 * u;
+            const int rr = min(mt * 32 + r, NPX - 1);
+            const int hy = rr / IW, hx = rr - hy * IW;
+            const int iy = min(max(iy0 + hy, 0), H - 1), ix = min(max(ix0 + hx, 0), W - 1);
+            const float *xp = xf + ((size_t)iy * W + ix) * Cin + 4 * hh;
+#pragma unroll
+            for (int q = 0; q < XK; ++q) xa[u][q] = *(const float4 *)(xp + 8 * q);
+        }
     }
     for (int i = tid; i < ((Ce + 31) / 32 * 32); i += 256) {
         if (EXPAND) Bes[i] = i < Ce ? be[i] : 0.f;
@@ -2433,8 +2464,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 for (int i = 0; i < 16; ++i) e[i] = 0.f;
                 const float *ap = Xs + (mt * 32 + r) * XS + 4 * hh;
                 const float *bq = Wes + r * XS + 4 * hh;
+#pragma unroll
                 for (int k = 0; k < Cin; k += 8) {
-                    const float4 a = *(const float4 *)(ap + k);
+                    float4 a;
+                    if constexpr (XREG) a = xa[u][k >> 3]; else a = *(const float4 *)(ap + k);
                     const float4 b = *(const float4 *)(bq + k);
                     e = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, e, 0, 0, 0);
                     e = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, e, 0, 0, 0);
@@ -2640,7 +2673,7 @@ static int launch_irb(SvcHandle *h, hipStream_t s, const float *X, int n, int H,
 #define IRB_LAUNCH3(S_, TOH_, TOW_, EXP_, STEM_, CI_, CE_, CO_)                                                      \
     do {                                                                                                             \
         const int tx = ceil_div(OW, TOW_), ty = ceil_div(OH, TOH_);                                                  \
-        const size_t lds = IrbGeom<S_, TOH_, TOW_>::lds_floats(Cin, CoutP, EXP_, Ce) * 4;                                \
+        const size_t lds = IrbGeom<S_, TOH_, TOW_>::lds_floats(Cin, CoutP, EXP_, Ce, IRB_XREG && EXP_ && !(STEM_) && (CI_) > 0 && (CI_) <= 32 && ((CI_) % 8) == 0) * 4; \
         auto kfn = k_irb<S_, TOH_, TOW_, EXP_, STEM_, CI_, CE_, CO_>;                                                \
         /* tiles of the 96-channel blocks need more than the default 64 KB of dynamic LDS; the attribute is per  */  \
         /* device, so the once-flag lives in the handle (one handle = one device), not in the process            */  \
@@ -3057,6 +3090,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->dwpw = atoi(env) != 0;
     env = getenv("SVC_DWPW_MIN_PX");
     if (env) h->dwpw_min_px = atoi(env);
+    env = getenv("SVC_DWPW_NT");
+    if (env) h->dwpw_max_nt = atoi(env);
     env = getenv("SVC_DW_TILE");
     if (env) h->dw_tile = atoi(env);
     env = getenv("SVC_SHOT_FORM");

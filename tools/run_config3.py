@@ -28,7 +28,7 @@ def main():
     ap.add_argument('--videos', type=int, default=200)
     ap.add_argument('--max-frames', type=int, default=0, help='truncate every video (0 = real length)')
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'config3'))
-    ap.add_argument('--workers', type=int, default=4, help='videos in flight per GPU (S.crop_videos)')
+    ap.add_argument('--workers', type=int, default=8, help='videos in flight per GPU (S.crop_videos)')
     ap.add_argument('--stream-batch', type=int, default=int(os.environ.get('STREAM_BATCH', 64)), help='maps per tail call inside the ingest (pipeline.StreamPipeline); 0 = one call per video')
     ap.add_argument('--packed', type=int, default=1, help='1: the job-level scheduler (retargetvid_amd/scheduler.py: full network chunks across video boundaries); 0: one video per worker thread (round 3)')
     ap.add_argument('--resident', type=int, default=1, help='1: the frames the job selects are generated before the timed run and lie in HBM (synth.ResidentBlobVideo), as bench.py\'s batch does; 0: generated on the fly inside the run (40 element-wise passes per frame on the GPU: the generator, not the path)')

@@ -492,7 +492,10 @@ def main():
 
     c3 = None
     if os.environ.get('BENCH_CONFIG3', '1') != '0' and not plain:
-        c3 = config3_job(world, rank, dist_on, dev, sd, int(os.environ.get('BENCH_CONFIG3_LANES', 8)), rccl_init_s)
+        try:
+            c3 = config3_job(world, rank, dist_on, dev, sd, int(os.environ.get('BENCH_CONFIG3_LANES', 8)), rccl_init_s)
+        except Exception as e:                                 # the headline line must not depend on the extra job
+            c3 = dict(error=repr(e))
     if rank == 0:
         front_fused = eng.front_fused()
         work = layer_work(B, front_fused=front_fused)

@@ -1011,6 +1011,9 @@ __global__ __launch_bounds__(256) void k_pw16(const float *__restrict__ X, int l
 // four waves each take a quarter of K; the partial tiles meet in LDS and are summed in a fixed
 // order (deterministic), every wave finishing four of the sixteen accumulator rows.
 // --------------------------------------------------------------------------------------
+#ifndef SK_DEPTH
+#define SK_DEPTH 2     // k-steps k_pw_sk keeps in flight per wave (measured round 4: 2 / 4 / 6 -> pw class 1.442 / 1.437 / 1.476 ms: not the limiter)
+#endif
 template <int TN>
 __global__ __launch_bounds__(256) void k_pw_sk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
                                                const float *__restrict__ bias, const float *__restrict__ R, int ldr,
@@ -1048,24 +1051,27 @@ __global__ __launch_bounds__(256) void k_pw_sk(const float *__restrict__ X, int 
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(B_[t].w, A_.w, acc[t], 0, 0, 0);           \
     }
     if (s_hi > s_lo) {
-        const int last = s_hi - 1, pairs = (s_hi - s_lo) >> 1;
-        float4 A0, A1, B0[TN], B1[TN];
-        SK_LOAD(A0, B0, s_lo)
-        SK_LOAD(A1, B1, min(s_lo + 1, last))
+        // SK_DEPTH k-steps in flight, the same ascending k order per wave whatever the depth
+        constexpr int D = SK_DEPTH;
+        const int last = s_hi - 1, groups = (s_hi - s_lo) / D, rem = (s_hi - s_lo) - groups * D;
+        float4 A[D], B[D][TN];
+#pragma unroll
+        for (int d = 0; d < D; ++d) SK_LOAD(A[d], B[d], min(s_lo + d, last))
         int st = s_lo;
-        for (int q = 0; q < pairs; ++q, st += 2) {
-            float4 a = A0, b[TN];
+        for (int q = 0; q < groups; ++q, st += D) {
 #pragma unroll
-            for (int t = 0; t < TN; ++t) b[t] = B0[t];
-            SK_LOAD(A0, B0, min(st + 2, last))
-            SK_MFMA(a, b)
-            a = A1;
+            for (int d = 0; d < D; ++d) {
+                const float4 a = A[d];
+                float4 b[TN];
 #pragma unroll
-            for (int t = 0; t < TN; ++t) b[t] = B1[t];
-            SK_LOAD(A1, B1, min(st + 3, last))
-            SK_MFMA(a, b)
+                for (int t = 0; t < TN; ++t) b[t] = B[d][t];
+                SK_LOAD(A[d], B[d], min(st + D + d, last))
+                SK_MFMA(a, b)
+            }
         }
-        if ((s_hi - s_lo) & 1) SK_MFMA(A0, B0)          // A0 / B0 hold step s_hi - 1 by now
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d)
+            if (d < rem) SK_MFMA(A[d], B[d])            // A[d] / B[d] hold step st + d by now
     }
 #undef SK_LOAD
 #undef SK_MFMA

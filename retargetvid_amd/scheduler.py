@@ -233,7 +233,7 @@ class JobScheduler:
     """crop_videos' engine room.  ``videos``: sequence of ingest_pickle dicts or zero-argument callables producing them."""
 
     def __init__(self, CP, ratios=None, lanes=4, chunk=32, state_dict=None, seed=0, engines=None, shot_net=None,
-                 host_threads=3, depth=2, lane_rows=8192, piece_frames=256, piece_bytes=256 << 20):
+                 host_threads=3, depth=2, lane_rows=4096, piece_frames=256, piece_bytes=256 << 20):
         import torch
         from . import ops as _ops
         if CP['exit_on_spread_sal'] or CP['exit_on_low_cvrg'] or CP['t_border'] != -1:

@@ -72,7 +72,7 @@ const char *svc_last_error(void);
  * checks it once after dlopen.  2 = SvcParams starts with struct_size and carries resize_factor.
  * 3 = SvcParams ends with com_km; SVC_MAP_HELD is honoured by svc_cluster_center (a v2 library ignores the bit), svc_debug_cluster_state
  *     returns 32 header words, svc_debug_round_plan / svc_debug_argsort_u32 / svc_transnet_* exist.
- * 4 = the host stages svc_host_* (SvcTemporalParams) exist. */
+ * 4 = the host stages svc_host_* (SvcTemporalParams) and svc_saliency_thresholded_u8 exist. */
 #define SVC_ABI_VERSION 4
 int svc_abi_version(void);
 
@@ -90,6 +90,12 @@ int svc_resize_frames_u8(SvcHandle *h, const uint8_t *frames, int n, int height,
  * caller only when someone asks for VD['smaps']. */
 int svc_saliency_u8(SvcHandle *h, const uint8_t *frames_nhwc, int n, int height, int width,
                     uint8_t *maps_nhw, void *stream);
+
+/* svc_saliency_u8 followed by svc_threshold_u8(t) in one pass: the last kernel of the network writes the thresholded map
+ * (sc_threshold, smartVidCrop.py:1050-1059, applied to the u8 value as the reference applies it to the stored map).
+ * Identical bytes; one launch less per chunk.  t in 0..255 (0 = svc_saliency_u8). */
+int svc_saliency_thresholded_u8(SvcHandle *h, const uint8_t *frames_nhwc, int n, int height, int width,
+                                uint8_t *maps_nhw, int t, void *stream);
 
 /* maps[i] = maps[i] < t ? 0 : maps[i], in place. */
 int svc_threshold_u8(SvcHandle *h, uint8_t *maps, size_t n_bytes, int t, void *stream);

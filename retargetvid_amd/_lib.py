@@ -16,7 +16,7 @@ EXPORTS = ('svc_last_error', 'svc_abi_version', 'svc_create', 'svc_destroy', 'sv
            'svc_debug_argsort_u32',
            'svc_profile_enable', 'svc_profile_read', 'svc_profile_read_raw',
            'svc_host_fill_empty_centres', 'svc_host_interp_segment', 'svc_host_lowpass', 'svc_host_loess', 'svc_host_savgol',
-           'svc_host_temporal', 'svc_host_boxes')
+           'svc_host_temporal', 'svc_host_boxes', 'svc_saliency_thresholded_u8')
 
 
 class SvcParams(ctypes.Structure):
@@ -69,6 +69,7 @@ def load():
     lib.svc_destroy.argtypes = [vp]
     lib.svc_resize_frames_u8.argtypes = [vp, vp, i32, i32, i32, vp, i32, i32, vp]
     lib.svc_saliency_u8.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    lib.svc_saliency_thresholded_u8.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp]
     lib.svc_threshold_u8.argtypes = [vp, vp, sz, i32, vp]
     lib.svc_cluster_center.argtypes = [vp, vp, i32, i32, i32, vp, ctypes.POINTER(SvcParams), vp, vp, vp]
     lib.svc_iou_i32.argtypes = [vp, vp, sz, vp, vp]

@@ -1441,13 +1441,14 @@ __global__ __launch_bounds__(256) void k_smooth_down(const float *__restrict__ l
 
 // u8 = trunc(255 * exp(x - max x)): the softmax normaliser cancels in p / max p.
 __global__ __launch_bounds__(256) void k_quantise(const float *__restrict__ pre, const unsigned *__restrict__ fmax,
-                                                  uint8_t *__restrict__ out, int n, int hw, FDiv dhw) {
+                                                  uint8_t *__restrict__ out, int n, int hw, FDiv dhw, int thr) {
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t total = (uint32_t)n * hw;
     if (gid >= total) return;
     float m = dec_f32(fmax[fdiv(gid, dhw)]);
     float e = expf(pre[gid] - m);
-    out[gid] = (uint8_t)(e * 255.0f);
+    const uint8_t v = (uint8_t)(e * 255.0f);
+    out[gid] = (int)v < thr ? (uint8_t)0 : v;              // thr = 0: the plain map; > 0: sc_threshold fused in (svc_saliency_thresholded_u8)
 }
 
 // --------------------------------------------------------------------------------------
@@ -2711,7 +2712,7 @@ static int launch_irb(SvcHandle *h, hipStream_t s, const float *X, int n, int H,
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
 // One pass of the network over n <= plan->nb frames.
-static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *maps, hipStream_t s) {
+static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *maps, hipStream_t s, int thr = 0) {
     NetPlan *p = h->plan;
     const int NH = p->NH, NW = p->NW;
     int H = NH / 2, W = NW / 2;
@@ -2918,14 +2919,26 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
         SVC_CHECK_LAUNCH();
     }
     k_quantise<<<blocks256((size_t)n * p->h * p->w), 256, 0, s>>>(p->buf(B_PRE), (const unsigned *)p->fmax.p, maps, n,
-                                                                 p->h * p->w, make_fdiv(p->h * p->w));
+                                                                 p->h * p->w, make_fdiv(p->h * p->w), thr);
     SVC_CHECK_LAUNCH();
     p->last_n = n;
     return SVC_OK;
 }
 
+static int saliency_impl(SvcHandle *h, const uint8_t *frames, int n, int height, int width, uint8_t *maps, int thr, void *stream);
+
 extern "C" int svc_saliency_u8(SvcHandle *h, const uint8_t *frames, int n, int height, int width, uint8_t *maps,
                                void *stream) {
+    return saliency_impl(h, frames, n, height, width, maps, 0, stream);
+}
+
+extern "C" int svc_saliency_thresholded_u8(SvcHandle *h, const uint8_t *frames, int n, int height, int width, uint8_t *maps,
+                                           int t, void *stream) {
+    if (t < 0 || t > 255) { svc_set_error("svc_saliency_thresholded_u8: threshold outside 0..255"); return SVC_E_INVALID; }
+    return saliency_impl(h, frames, n, height, width, maps, t, stream);
+}
+
+static int saliency_impl(SvcHandle *h, const uint8_t *frames, int n, int height, int width, uint8_t *maps, int thr, void *stream) {
     if (!h || n < 0 || (n > 0 && (!frames || !maps)) || height < 8 || width < 8) {     // n = 0: a no-op, null buffers allowed
         svc_set_error("svc_saliency_u8: invalid argument");
         return SVC_E_INVALID;
@@ -2944,7 +2957,7 @@ extern "C" int svc_saliency_u8(SvcHandle *h, const uint8_t *frames, int n, int h
         // hipGraph (captured on the second sighting: the first runs eagerly, so one-time work -- function attributes,
         // the constant prior maps -- stays out of the graph).  Profiled passes and the null stream always launch directly.
         if (h->use_graph && h->prof_class < 0 && s) {
-            const auto key = std::make_tuple((const void *)fr, (void *)mp, m, height, width, (const void *)h->plan->ws.p);
+            const auto key = std::make_tuple((const void *)fr, (void *)mp, m, height * 256 + thr, width, (const void *)h->plan->ws.p);
             auto it = h->graphs.find(key);
             if (it != h->graphs.end() && it->second) {
                 SVC_HIP(hipGraphLaunch(it->second, s));
@@ -2954,7 +2967,7 @@ extern "C" int svc_saliency_u8(SvcHandle *h, const uint8_t *frames, int n, int h
             if (it != h->graphs.end()) {                    // second sighting: capture, instantiate, launch
                 hipGraph_t g = nullptr;
                 SVC_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                const int rc = forward_chunk(h, fr, m, mp, s);
+                const int rc = forward_chunk(h, fr, m, mp, s, thr);
                 const hipError_t e = hipStreamEndCapture(s, &g);
                 if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
                 SVC_HIP(e);
@@ -2971,7 +2984,7 @@ extern "C" int svc_saliency_u8(SvcHandle *h, const uint8_t *frames, int n, int h
             }
             h->graphs.emplace(key, nullptr);
         }
-        RC(forward_chunk(h, fr, m, mp, s));
+        RC(forward_chunk(h, fr, m, mp, s, thr));
     }
     return SVC_OK;
 }

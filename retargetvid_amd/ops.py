@@ -70,8 +70,10 @@ class Engine:
         return out
 
     # -- saliency ------------------------------------------------------------------------
-    def saliency(self, frames, out=None):
-        """uint8 [n,h,w,3] RGB at saliency size -> uint8 [n,h,w] maps (frame-major); `out`: write into this tensor."""
+    def saliency(self, frames, out=None, threshold=0):
+        """uint8 [n,h,w,3] RGB at saliency size -> uint8 [n,h,w] maps (frame-major); `out`: write into this tensor.
+        threshold > 0: the maps come out thresholded (sc_threshold fused into the network's last kernel: the bytes of
+        saliency() + threshold_(), one launch less)."""
         _need_cuda(frames, torch.uint8, 'frames')
         n, h, w, c = frames.shape
         assert c == 3
@@ -80,7 +82,10 @@ class Engine:
         else:
             _need_cuda(out, torch.uint8, 'out')
             assert tuple(out.shape) == (n, h, w)
-        _lib.check(self.lib.svc_saliency_u8(self._h, _ptr(frames), n, h, w, _ptr(out), _stream()))
+        if threshold:
+            _lib.check(self.lib.svc_saliency_thresholded_u8(self._h, _ptr(frames), n, h, w, _ptr(out), int(threshold), _stream()))
+        else:
+            _lib.check(self.lib.svc_saliency_u8(self._h, _ptr(frames), n, h, w, _ptr(out), _stream()))
         return out
 
     def tap(self, which, frame, shape):

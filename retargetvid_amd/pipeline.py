@@ -114,8 +114,7 @@ class StreamPipeline:
             if tev:
                 tev[0].record(self.stream)
             sm = frames if small else self.eng.resize_frames(frames, self.h, self.w)
-            self.eng.saliency(sm, out=dst)
-            self.eng.threshold_(dst, self.CP['t_threshold'])
+            self.eng.saliency(sm, out=dst, threshold=self.CP['t_threshold'])       # (threshold fused into the network's last kernel)
             if tev:
                 tev[1].record(self.stream)
         return self._call(n, blend_next, timed=bool(tev))

@@ -180,16 +180,15 @@ class _Lane:
                 rows = self.row_of_frame[f0:f0 + k]
                 r0 = int(rows[0])
                 if int(rows[-1]) - r0 + 1 == k:                       # no zero row inside: the network writes in place
-                    self.eng.saliency(self.small[f0:f0 + k], out=self.maps[r0:r0 + k])
+                    self.eng.saliency(self.small[f0:f0 + k], out=self.maps[r0:r0 + k], threshold=sc.CP['t_threshold'])
                 else:
-                    self.eng.saliency(self.small[f0:f0 + k], out=self.tmp[:k])
+                    self.eng.saliency(self.small[f0:f0 + k], out=self.tmp[:k], threshold=sc.CP['t_threshold'])
                     brk = np.flatnonzero(np.diff(rows) != 1) + 1
                     a = 0
                     for b in list(brk) + [k]:                         # runs of consecutive rows
                         ra = int(rows[a])
                         self.maps[ra:ra + (b - a)].copy_(self.tmp[a:b])
                         a = int(b)
-            self.eng.threshold_(dst, sc.CP['t_threshold'])
         t1 = time.perf_counter()
         self.pipe.submit_rows(n_rows, self.flags[self.rows_called:R])
         t2 = time.perf_counter()

@@ -83,6 +83,14 @@ def test_saliency_other_aspect_ratio(engine, synthetic_sd):
     assert d.max() <= 1 and (d > 0).mean() < 1e-3
 
 
+def test_fused_threshold_entry_gives_the_bytes_of_the_two_calls(engine):
+    fr = torch.from_numpy(synth.blob_frames(5, 140, 250, seed=12)).cuda()
+    for t in (1, 90, 120, 255):
+        two = engine.threshold_(engine.saliency(fr), t)
+        assert torch.equal(engine.saliency(fr, threshold=t), two)
+    assert torch.equal(engine.saliency(fr, threshold=0), engine.saliency(fr))
+
+
 def test_saliency_batch_and_chunk_independence(engine):
     fr = torch.from_numpy(synth.blob_frames(40, 140, 250, seed=9)).cuda()      # 40 > default chunk of 32
     full = engine.saliency(fr)

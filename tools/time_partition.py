@@ -39,9 +39,12 @@ def run_layout(P, T, steps=120):
         net_bits, tail_bits = cu_sets(T)
         nets = [masked_stream(net_bits) for _ in range(P)]
         tails = [masked_stream(tail_bits) for _ in range(P)]
-    elif T < 0:                                         # unmasked, but the tail on a stream of its own: the slot's next network pass runs beside it
+    elif T == -3:                                       # one HIGH-PRIORITY stream per slot for network and tail alike (does priority change anything?)
+        nets = [torch.cuda.Stream(priority=-1) for _ in range(P)]
+        tails = nets
+    elif T < 0:                                         # unmasked, but the tail on a stream of its own (T = -2: a high-priority one): the slot's next network pass runs beside it
         nets = [torch.cuda.Stream() for _ in range(P)]
-        tails = [torch.cuda.Stream() for _ in range(P)]
+        tails = [torch.cuda.Stream(priority=-1 if T == -2 else 0) for _ in range(P)]
     else:
         nets = [torch.cuda.Stream() for _ in range(P)]
         tails = nets
@@ -81,4 +84,4 @@ def run_layout(P, T, steps=120):
 for lay in sys.argv[1:] or ['4:0', '4:16', '4:32', '5:32', '6:32']:
     P, T = (int(v) for v in lay.split(':'))
     ms = run_layout(P, T)
-    print('%d batches in flight, tail on %3d reserved CUs (%s): %.4f ms per step of %d frames = %.0f frames/s' % (P, max(T, 0), 'own unmasked stream' if T < 0 else (order if T else 'product layout'), ms, B, B / ms * 1e3), flush=True)
+    print('%d batches in flight, tail on %3d reserved CUs (%s): %.4f ms per step of %d frames = %.0f frames/s' % (P, max(T, 0), ('own unmasked stream' if T == -1 else 'own HIGH-PRIORITY stream' if T == -2 else 'one high-priority stream per slot') if T < 0 else (order if T else 'product layout'), ms, B, B / ms * 1e3), flush=True)

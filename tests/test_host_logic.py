@@ -285,3 +285,26 @@ def test_transnet_weights_from_tensorflow_variable_names():
     bad['TransNet/dense_1/kernel:0'] = np.zeros((2, 256), np.float32)                         # transposed by mistake
     with pytest.raises(ValueError, match='dense_1/kernel'):
         W.transnet_from_tf_variables(bad)
+
+
+def test_plan_video_bookkeeping_for_the_scheduler():
+    """smartVidCrop.plan_video (host only): selection as the oracle's, the all-zero-map rows = the last selected frame of
+    every read batch (the reference's off-by-one, smartVidCrop.py:408-453), blend flags ending with two zeros (nothing is
+    blended across a video boundary when videos are packed into one stream), errors for inconsistent input."""
+    import pytest
+    n = 437
+    video = dict(fr=25.0, frame_count=n, w=480, h=640, frames=np.zeros((n, 1, 1, 3), np.uint8), trans_inds=[0, 100, 290, n])
+    CP = dict(S.sc_init_crop_params(), read_batch=150)
+    plan = S.plan_video(video, CP)
+    ti, m2o, batches = P.select_frames(n, n, [0, 100, 290, n], CP['skip'], CP['read_batch'])
+    assert plan['true_inds'] == ti and plan['map2orig'] == m2o and plan['batches'] == batches
+    assert (plan['sal_h'], plan['sal_w']) == P.sal_size(480, 640, 250) == (250, 187)
+    zero = np.flatnonzero(plan['zero_map']).tolist()
+    assert zero == [first + cnt - 1 for first, cnt in batches] and len(zero) == 3
+    assert plan['flags'].tolist() == S.blend_flags(plan['n_sel'], plan['seg_sel']).tolist()
+    assert plan['flags'][-2:].tolist() == [0, 0] and plan['flags'][:2].tolist() == [1, 1]
+    assert plan['seg'].tolist() == [[0, 99], [100, 289], [290, n - 1]] and plan['seg_sel'][-1][1] == plan['n_sel'] - 1
+    with pytest.raises(ValueError):
+        S.plan_video(dict(video, trans_inds=[7]), CP)
+    with pytest.raises(ValueError):
+        S.plan_video(dict(video, trans_inds=None), CP)              # no shots and no shot network

@@ -453,6 +453,44 @@ def test_maps_beyond_8192_points_new_kernels_equal_the_round2_kernels_and_the_or
         old.close()
 
 
+def test_largest_geometries_up_to_65025_points_equal_the_round2_kernels(engine):
+    """What a 140 x 250 map cannot reach: more new tree nodes than k_prim_lvl_big's batch table holds (> 36 864 since the last
+    rise), the fourth level of the hierarchy's nearest-greater search (> 8 192 x 4 edges), a 255 x 255 map with every pixel set
+    (65 025 points).  Against the round-2 kernels: Prim edge list, labels, maps, centres identical (tools/soak_big_maps.py is
+    the long form: four geometries x 8 maps x two parameter sets)."""
+    import os
+    saved = {k: os.environ.get(k) for k in ('SVC_PRIM_LVL', 'SVC_TREE_PAR', 'SVC_TAIL_MERGE')}
+    try:
+        os.environ.update(SVC_PRIM_LVL='0', SVC_TREE_PAR='0', SVC_TAIL_MERGE='0')
+        old = ops.Engine(seed=0)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        rng = np.random.RandomState(91)
+        for (h, w) in ((187, 250), (255, 255)):
+            maps = np.zeros((3, h, w), np.uint8)
+            maps[0] = 200                                                    # every pixel: one plateau longer than the batch table
+            maps[1] = np.where(rng.rand(h, w) < 0.8, 220, 0)
+            ys, xs = np.mgrid[0:h, 0:w]
+            maps[2] = np.where(np.sin(xs / 4.0) * np.sin(ys / 3.0) > -0.7, 180, 0)
+            CP = P.init_crop_params()
+            a, b = torch.from_numpy(maps).cuda(), torch.from_numpy(maps).cuda()
+            xa, sa = old.cluster_center_(a, None, CP, want_stats=True)
+            xb, sb = engine.cluster_center_(b, None, CP, want_stats=True)
+            assert torch.equal(a, b) and torch.equal(sa, sb) and int(sb[:, 0].min()) > 30000
+            assert np.array_equal(xa.cpu().numpy(), xb.cpu().numpy(), equal_nan=True)
+            for i in range(3):
+                s_old, s_new = old.cluster_state(i, h * w), engine.cluster_state(i, h * w)
+                assert np.array_equal(s_old['mst'], s_new['mst']), (h, w, i, s_old['n'])
+                assert np.array_equal(s_old['labels'], s_new['labels']), (h, w, i)
+    finally:
+        old.close()
+
+
 def test_tail_batch_independence_at_full_size(engine):
     """Size-independent property at BASELINE config 2 (B=32, 640x360): every map's result is
     independent of the batch it is processed in, and filtering only ever removes/closes."""

@@ -161,3 +161,27 @@ def test_smart_vid_crop_runs_shot_detection_inside_the_ingest(net):
             S.smart_vid_crop(video, CP, save_vid=False, engine=eng)      # no trans_inds and no shot network
     finally:
         eng.close()
+
+
+def test_packed_job_with_shot_detection_inside_equals_sequential_runs(net):
+    """crop_videos / JobScheduler with shot_net=: videos WITHOUT trans_inds (the reference's video path) packed into one
+    stream -- TransNet runs on the lane's stream when a video is planned -- give the windows of one smart_vid_crop call per video."""
+    from retargetvid_amd import smartVidCrop as S, synth
+    n, sd = net
+    usd = weights.make_synthetic_state_dict(0)
+    eng = ops.Engine(usd)
+    try:
+        vids = []
+        for k in range(4):
+            frames = synth.blob_frames(70 + 20 * k, 90, 160, seed=30 + k)
+            frames[25 + 5 * k:] = frames[25 + 5 * k:][:, ::-1]          # a hard cut
+            vids.append(dict(fr=25.0, frame_count=len(frames), w=160, h=90, frames=frames))
+        CP = dict(S.sc_init_crop_params(), read_batch=64, hdbscan_min=5)
+        seq = [{r: S.smart_vid_crop(v, dict(CP, out_ratio=r), save_vid=False, engine=eng, shot_net=n) for r in ('1:3', '3:1')} for v in vids]
+        par = S.crop_videos(vids, CP, ('1:3', '3:1'), workers=2, state_dict=usd, shot_net=n)
+        for a, b in zip(seq, par):
+            for r in ('1:3', '3:1'):
+                assert a[r][0]['true_inds'] == b[r][0]['true_inds'] and np.array_equal(a[r][0]['segmentation'], b[r][0]['segmentation'])
+                assert a[r][0]['bbs'] == b[r][0]['bbs'] and a[r][0]['dx'] == b[r][0]['dx']
+    finally:
+        eng.close()

@@ -146,7 +146,12 @@ int svc_iou_i32(const int32_t *a, const int32_t *b, size_t n, double *out, void 
  *   svc_host_boxes               sc_compute_bb :979-1048: smoothed centres (saliency-map pixels) -> boxes[fc][4] int64
  *                                (x1, y1, x2, y2), centres[fc][2] (may be NULL) = the truncated full-resolution centres the
  *                                reference writes back to dxs / dys, fbb_wh[2] (may be NULL) = box width, height;
- *                                borders_tblr (may be NULL = 0) = border_t, border_b, border_l, border_r */
+ *                                borders_tblr (may be NULL = 0) = border_t, border_b, border_l, border_r
+ *   svc_host_focus_stability     the jump statistics and the focus hold of the ISM 2021 parameter set (get_points_on_line /
+ *                                sc_check_for_extra_cuts :1337-1455, the hold loop :2425-2473): centres of the n selected frames (in
+ *                                place), the FILTERED maps frame-major uint8 [n][h][w] (host) -> jumps[n] (mean map value along the
+ *                                move from centre i-1 to centre i, 255 = none), inds[] = frames with a jump below stab_t (returned
+ *                                count); float32 buffer / slope arithmetic as in the reference */
 typedef struct SvcTemporalParams {
     uint32_t struct_size;       /* = sizeof(SvcTemporalParams) as the caller compiled it */
     int32_t lp_filt;            /* CP['lp_filt'] */
@@ -157,6 +162,8 @@ typedef struct SvcTemporalParams {
     double loess_w_secs;        /* CP['loess_w_secs'] */
     double fr;                  /* frames per second of the video */
 } SvcTemporalParams;
+int svc_host_focus_stability(double *cx, double *cy, int n, const uint8_t *maps_nhw, int h, int w, double fr, int skip,
+                             double min_d_jump, double stab_t, double stab_s, double *jumps, int32_t *inds);
 int svc_host_fill_empty_centres(double *cx, double *cy, int n_sel, const int32_t *seg_sel, int n_seg);
 int svc_host_interp_segment(const double *sampled_t, const double *d1, const double *d2, int n, int n_out, double *out1, double *out2);
 int svc_host_lowpass(const double *b, const double *a, const double *zi, int taps, const double *x, int n, double *out);

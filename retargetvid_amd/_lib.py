@@ -16,7 +16,7 @@ EXPORTS = ('svc_last_error', 'svc_abi_version', 'svc_create', 'svc_destroy', 'sv
            'svc_debug_argsort_u32',
            'svc_profile_enable', 'svc_profile_read', 'svc_profile_read_raw',
            'svc_host_fill_empty_centres', 'svc_host_interp_segment', 'svc_host_lowpass', 'svc_host_loess', 'svc_host_savgol',
-           'svc_host_temporal', 'svc_host_boxes', 'svc_saliency_thresholded_u8')
+           'svc_host_temporal', 'svc_host_boxes', 'svc_host_focus_stability', 'svc_saliency_thresholded_u8')
 
 
 class SvcParams(ctypes.Structure):
@@ -91,6 +91,8 @@ def load():
     lib.svc_host_savgol.argtypes = [vp, i32, i32, i32, vp]
     lib.svc_host_temporal.argtypes = [ctypes.POINTER(SvcTemporalParams), vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp]
     lib.svc_host_boxes.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+    f64 = ctypes.c_double
+    lib.svc_host_focus_stability.argtypes = [vp, vp, i32, vp, i32, i32, f64, i32, f64, f64, f64, vp, vp]
     for name in EXPORTS:
         if name not in ('svc_last_error', 'svc_abi_version'):
             getattr(lib, name).restype = i32

@@ -15,6 +15,7 @@
 //   svc_host_savgol               scipy.signal.savgol_filter(mode='interp')  :1643
 //   svc_host_temporal             sc_interpolate + sc_smoothing for one video :1550-1597, :1648-1734
 //   svc_host_boxes                sc_compute_bb                              :979-1048
+//   svc_host_focus_stability      get_points_on_line, sc_check_for_extra_cuts, the focus hold  :1337-1455, :2425-2473
 //
 // What is bit-for-bit SciPy's arithmetic (same operations, same order; -ffp-contract=off): linear interpolation, the
 // filtfilt chain (odd extension, direct-form-II-transposed recurrence, initial conditions zi * x0) given SciPy's b, a, zi,
@@ -350,7 +351,81 @@ int smooth_handler(const double *d, int n, int loess_filt, int window, int degre
     return savgol(d, n, window, degree, out);
 }
 
+// numpy.arange(start, stop, step) for float arguments: ceil((stop - start) / step) elements, element i = start + i * step
+inline long arange_len(double start, double stop, double step) {
+    const double v = ceil((stop - start) / step);
+    return v > 0 ? (long)v : 0;
+}
+
+// get_points_on_line + the mean of sc_check_for_extra_cuts (:1337-1455): the integer-stepped samples strictly after p1 up to p2
+// along the dominant axis, kept where they fall inside the image, and the mean map value over them.  The reference builds
+// them in a float32 buffer with a float32 slope; the same conversions in the same order here.  false = "no jump statistic"
+// (a move below min_d, a sample count that does not match the buffer -- NumPy raises there --, no sample inside the image).
+bool jump_mean(const uint8_t *map, int h, int w, double p1x, double p1y, double p2x, double p2y, double min_d, double *mean) {
+    const double dX = p2x - p1x, dY = p2y - p1y, dXa = fabs(dX), dYa = fabs(dY);
+    if (dXa < min_d && dYa < min_d) return false;
+    const long m = (long)ceil(std::max(dYa, dXa));
+    if (m < 1) return false;
+    const bool negY = p1y > p2y, negX = p1x > p2x;
+    const double sy0 = negY ? p1y - 1 : p1y + 1, sys = negY ? -1.0 : 1.0;
+    const double sx0 = negX ? p1x - 1 : p1x + 1, sxs = negX ? -1.0 : 1.0;
+    const long ny = arange_len(sy0, negY ? (p1y - dYa) - 1 : (p1y + dYa) + 1, sys);
+    const long nx = arange_len(sx0, negX ? (p1x - dXa) - 1 : (p1x + dXa) + 1, sxs);
+    // an array assigned to a column of the buffer must have its length (or length 1: broadcast)
+    auto fits = [&](long len) { return len == m || len == 1; };
+    int mode;                                                // 0: x fixed, 1: y fixed, 2: y leads, 3: x leads
+    if (p1x == p2x) { if (!fits(ny)) return false; mode = 0; }
+    else if (p1y == p2y) { if (!fits(nx)) return false; mode = 1; }
+    else if (dYa > dXa) { if (!fits(ny)) return false; mode = 2; }
+    else { if (!fits(nx)) return false; mode = 3; }
+    const float slope = mode == 2 ? (float)dX / (float)dY : (mode == 3 ? (float)dY / (float)dX : 0.f);
+    const float fp1x = (float)p1x, fp1y = (float)p1y;
+    double total = 0.0;
+    long cnt = 0;
+    for (long i = 0; i < m; ++i) {
+        float bx, by;
+        if (mode == 0 || mode == 2) {
+            by = (float)(sy0 + (double)(ny == 1 ? 0 : i) * sys);
+            if (mode == 0) bx = fp1x;
+            else bx = (float)((double)(long)(slope * (by - fp1y)) + p1x);
+        } else {
+            bx = (float)(sx0 + (double)(nx == 1 ? 0 : i) * sxs);
+            if (mode == 1) by = fp1y;
+            else by = (float)((double)(long)(slope * (bx - fp1x)) + p1y);
+        }
+        if (bx >= 0.f && by >= 0.f && bx < (float)w && by < (float)h) {
+            total += (double)map[(long)floorf(by) * w + (long)floorf(bx)];
+            ++cnt;
+        }
+    }
+    if (cnt == 0) return false;
+    *mean = total / (double)cnt;
+    return true;
+}
+
 }   // namespace
+
+extern "C" int svc_host_focus_stability(double *cx, double *cy, int n, const uint8_t *maps_nhw, int h, int w, double fr, int skip,
+                                        double min_d_jump, double stab_t, double stab_s, double *jumps, int32_t *inds) {
+    if (n < 0 || (n && (!cx || !cy || !maps_nhw || !jumps || !inds)) || h < 1 || w < 1 || !(fr > 0)) {
+        svc_set_error("svc_host_focus_stability: invalid argument");
+        return SVC_E_INVALID;
+    }
+    int ni = 0;
+    for (int i = 0; i < n; ++i) jumps[i] = 255.0;
+    for (int i = 1; i < n; ++i) {
+        double mean;
+        if (jump_mean(maps_nhw + (size_t)i * h * w, h, w, cx[i - 1], cy[i - 1], cx[i], cy[i], min_d_jump, &mean)) jumps[i] = mean;
+        if (jumps[i] < stab_t) inds[ni++] = i;
+    }
+    // the focus hold (:2448-2473): between two low-saliency jumps close in time the first centre is kept
+    for (int k = 0; k + 1 < ni; ++k) {
+        const int start = std::max(inds[k] - 1, 0), end = std::min(inds[k + 1] + 1, n - 1);
+        if (((double)((end - start) * skip)) / fr <= stab_s)
+            for (int j = 0; j < end - start; ++j) { cx[start + j] = cx[start]; cy[start + j] = cy[start]; }
+    }
+    return ni;
+}
 
 extern "C" int svc_host_fill_empty_centres(double *cx, double *cy, int n_sel, const int32_t *seg_sel, int n_seg) {
     if (n_sel < 0 || (n_sel && (!cx || !cy)) || n_seg < 1 || !seg_sel) { svc_set_error("svc_host_fill_empty_centres: invalid argument"); return SVC_E_INVALID; }

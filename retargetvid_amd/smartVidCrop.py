@@ -679,9 +679,9 @@ def after_ingest(VD, CP, engine, verbose=False):
     VD['dxnf'], VD['dynf'] = list(VD['dx']), list(VD['dy'])
     t = time.perf_counter()
     if CP['focus_stability']:            # best settings: hold the focus across short low-saliency jumps (host)
-        VD['dx'], VD['dy'], VD['jumps'], VD['jumps_inds'] = temporal.focus_stability(
-            VD['dx'], VD['dy'], VD['smaps'], VD['fr'], CP)
-        xy = np.stack([VD['dx'], VD['dy']], 1).astype(np.float64)
+        maps_host = VD['smaps_dev'].cpu().numpy()        # frame-major [n,h,w]: no [H,W,n] transposition (VD['smaps'] stays lazy)
+        xy, VD['jumps'], VD['jumps_inds'] = temporal.focus_stability_native(xy, maps_host, VD['fr'], CP)
+        VD['dx'], VD['dy'] = xy[:, 0].tolist(), xy[:, 1].tolist()
     sc_register_time(t, '_focus_stability')
 
     t = time.perf_counter()                            # interpolation + low-pass + LOESS / Savitzky-Golay: one native call

@@ -177,58 +177,28 @@ def boxes(dxs, dys, w_orig, h_orig, w_process, h_process, w_final, h_final, bord
     return bb, ctr, int(wh[0]), int(wh[1])
 
 
-def _points_on_line(p1x, p1y, p2x, p2y, w, h, min_d):
-    """get_points_on_line (smartVidCrop.py:1337-1393): integer-stepped samples strictly after p1 up
-    to p2 along the dominant axis; the reference's removed ``np.int`` cast is the intended
-    truncation.  -> float32 [m,2] (x, y) inside the image, or None for a jump below min_d."""
-    dX, dY = p2x - p1x, p2y - p1y
-    dXa, dYa = abs(dX), abs(dY)
-    if dXa < min_d and dYa < min_d:
-        return None
-    m = int(np.ceil(max(dYa, dXa)))
-    buf = np.full((m, 2), np.nan, np.float32)
-    sy = np.arange(p1y - 1, p1y - dYa - 1, -1) if p1y > p2y else np.arange(p1y + 1, p1y + dYa + 1)
-    sx = np.arange(p1x - 1, p1x - dXa - 1, -1) if p1x > p2x else np.arange(p1x + 1, p1x + dXa + 1)
-    try:
-        if p1x == p2x:
-            buf[:, 0], buf[:, 1] = p1x, sy
-        elif p1y == p2y:
-            buf[:, 1], buf[:, 0] = p1y, sx
-        elif dYa > dXa:
-            buf[:, 1] = sy
-            buf[:, 0] = (np.float32(dX) / np.float32(dY) * (buf[:, 1] - p1y)).astype(int) + p1x
-        else:
-            buf[:, 0] = sx
-            buf[:, 1] = (np.float32(dY) / np.float32(dX) * (buf[:, 0] - p1x)).astype(int) + p1y
-    except Exception:
-        return None
-    keep = (buf[:, 0] >= 0) & (buf[:, 1] >= 0) & (buf[:, 0] < w) & (buf[:, 1] < h)
-    return buf[keep]
+def focus_stability_native(xy, maps_nhw, fr, CP):
+    """focus_stability on arrays, native (svc_host_focus_stability): xy float64 [n, 2]; maps_nhw: the FILTERED maps frame-major
+    uint8 [n, h, w] on the host (as they come from the device: no [H,W,n] transposition).  -> (xy, jumps list, jumps_inds list);
+    a jump without a statistic is the integer 255, as in the reference."""
+    lib = _lib.load()
+    maps = np.ascontiguousarray(maps_nhw, np.uint8)
+    n, h, w = maps.shape
+    cx, cy = _f64(xy[:, 0]).copy(), _f64(xy[:, 1]).copy()
+    jumps = np.empty(n, np.float64)
+    inds = np.empty(max(n, 1), np.int32)
+    ni = _lib.check(lib.svc_host_focus_stability(_p(cx), _p(cy), n, _p(maps), h, w, float(fr), int(CP['skip']), float(CP['min_d_jump']),
+                                                 float(CP['foces_stab_t']), float(CP['foces_stab_s']), _p(jumps), _p(inds)))
+    jl = [255 if v == 255.0 else float(v) for v in jumps]
+    return np.stack([cx, cy], 1), jl, [int(v) for v in inds[:ni]]
 
 
 def focus_stability(dx, dy, smaps_hwn, fr, CP):
-    """Jump statistics + focus hold (smartVidCrop.py:1395-1455, :2425-2473).  smaps_hwn: the
-    filtered maps in the reference's [H,W,n] layout.  -> (dx, dy, jumps, jumps_inds)."""
-    dx, dy = list(dx), list(dy)
-    n = len(dx)
-    h, w = smaps_hwn.shape[:2]
-    jumps, inds = [255] * n, []
-    for i in range(1, n):
-        pts = _points_on_line(dx[i - 1], dy[i - 1], dx[i], dy[i], w, h, CP['min_d_jump'])
-        if pts is not None:
-            ok = ~np.isnan(pts[:, 0])
-            if ok.any():
-                xs = np.floor(pts[ok, 0]).astype(np.int64)
-                ys = np.floor(pts[ok, 1]).astype(np.int64)
-                jumps[i] = float(smaps_hwn[ys, xs, i].astype(np.float64).sum()) / float(ok.sum())
-        if jumps[i] < CP['foces_stab_t']:
-            inds.append(i)
-    for a, b in zip(inds[:-1], inds[1:]):
-        start, end = max(a - 1, 0), min(b + 1, n - 1)
-        if ((end - start) * CP['skip']) / fr <= CP['foces_stab_s']:
-            for j in range(end - start):
-                dx[start + j], dy[start + j] = dx[start], dy[start]
-    return dx, dy, jumps, inds
+    """Jump statistics + focus hold (smartVidCrop.py:1337-1455, :2425-2473) with the reference's argument layout: smaps_hwn =
+    the filtered maps as [H,W,n].  -> (dx, dy, jumps, jumps_inds).  (after_ingest calls focus_stability_native on the
+    frame-major maps directly.)"""
+    xy, jumps, inds = focus_stability_native(np.stack([_f64(dx), _f64(dy)], 1), np.transpose(np.asarray(smaps_hwn), (2, 0, 1)), fr, CP)
+    return xy[:, 0].tolist(), xy[:, 1].tolist(), jumps, inds
 
 
 def shift_time(bbs, shift):

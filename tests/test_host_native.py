@@ -139,3 +139,37 @@ def test_empty_centre_fill_and_boxes_are_the_oracles():
             ref = T.compute_bb(list(xs), list(ys), 300, w, h, wp, hp, wf, hf)
             bb, ctr, fw, fh = temporal.boxes(xs, ys, w, h, wp, hp, wf, hf)
             assert bb.tolist() == ref[0] and (fw, fh) == ref[1:]
+
+
+def test_focus_stability_is_the_oracles_to_the_last_bit():
+    """svc_host_focus_stability against oracle/temporal_ref.focus_stability (get_points_on_line + sc_check_for_extra_cuts + the
+    hold loop, smartVidCrop.py:1337-1455, :2425-2473): the float32 buffer / float32 slope arithmetic, NumPy's arange lengths,
+    the sample-count mismatch that makes NumPy raise (-> no statistic), moves along one axis, integer-valued centres, centres
+    outside the image.  Jump statistics, held centres and the list of low-saliency jumps: equal, not close."""
+    rng = np.random.RandomState(0)
+    n_stats = 0
+    for trial in range(120):
+        n = rng.randint(7, 40)
+        h, w = (35, 62) if trial % 2 else (140, 250)
+        maps = np.zeros((n, h, w), np.uint8)
+        for i in range(n):
+            maps[i] = np.where(rng.rand(h, w) < rng.choice([0.02, 0.2, 0.6]), rng.randint(90, 256, (h, w)), 0)
+        kind = trial % 4
+        if kind == 0:
+            dx, dy = rng.uniform(-3, w + 3, n), rng.uniform(-3, h + 3, n)
+        elif kind == 1:
+            dx, dy = np.round(rng.uniform(0, w, n)), np.round(rng.uniform(0, h, n))
+            dx[3], dy[5] = dx[2], dy[4]
+        elif kind == 2:
+            dx, dy = np.cumsum(rng.randn(n) * 0.7) + w / 2, np.cumsum(rng.randn(n) * 0.4) + h / 2
+        else:
+            dx, dy = rng.uniform(0, w, n), np.full(n, float(rng.randint(0, h)))
+        dx, dy = [float(v) for v in dx], [float(v) for v in dy]          # Python floats, as the pipeline hands them on
+        hwn = np.ascontiguousarray(np.transpose(maps, (1, 2, 0)))
+        for best in (True, False):
+            CP = dict(P.init_crop_params(best), foces_stab_t=int(rng.choice([60, 120, 200])))
+            ref = TR.focus_stability(list(dx), list(dy), hwn, 30.0, CP)
+            got = temporal.focus_stability(list(dx), list(dy), hwn, 30.0, CP)
+            assert got[0] == list(ref[0]) and got[1] == list(ref[1]) and got[2] == list(ref[2]) and got[3] == list(ref[3]), (trial, best)
+            n_stats += sum(1 for v in got[2] if v != 255)
+    assert n_stats > 2000

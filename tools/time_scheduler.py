@@ -25,12 +25,13 @@ def main():
     ap.add_argument('--chunk', type=int, default=32)
     ap.add_argument('--depth', type=int, default=2)
     ap.add_argument('--host-threads', type=int, default=3)
+    ap.add_argument('--best', type=int, default=0, help='1: the ISM 2021 parameter set (use_best_settings: clustering at 35x62, focus stability on the host)')
     args = ap.parse_args()
     torch.cuda.set_device(0)
     annots = E.load_annotations(os.path.join(ROOT, 'tests', 'golden', 'retargetvid'))
     vids = E.VID_INDS[:args.videos]
     counts = [len(annots[0]['1-3'][v]) for v in vids]
-    CP = S.sc_init_crop_params()
+    CP = S.sc_init_crop_params(use_best_settings=bool(args.best))
     videos = []
     for i, n in enumerate(counts):
         rng = np.random.RandomState(vids[i])
@@ -54,9 +55,9 @@ def main():
             js.close()
         t3 = time.perf_counter()
         rows.append(dict(create=round(t1 - t0, 3), run=round(t2 - t1, 3), close=round(t3 - t2, 3),
-                         device_side=round(js.stats['seconds_device_side'], 3), feeder=js.stats['feeder_seconds'],
+                         device_side=round(js.stats['seconds_device_side'], 3), host_drain=round(js.stats['seconds_host_stage_drain'], 3), feeder=js.stats['feeder_seconds'],
                          mem_GB=round(torch.cuda.memory_reserved() / 2**30, 2)))
-    print(json.dumps(dict(lanes=args.lanes, chunk=args.chunk, depth=args.depth, fresh=bool(args.fresh), saliency_frames=js.stats['network_frames'] + len(videos),
+    print(json.dumps(dict(best_settings=bool(args.best), lanes=args.lanes, chunk=args.chunk, depth=args.depth, fresh=bool(args.fresh), saliency_frames=js.stats['network_frames'] + len(videos),
                           runs=rows)))
 
 

@@ -23,7 +23,6 @@ the low-occupancy tail of one lane overlaps the full-chip network of the others,
 result equals smartVidCrop.smart_vid_crop_ratios on that video alone (tests/test_gpu_scheduler.py).
 
 Host logic + torch plumbing only; device work goes through ops.Engine (the C ABI)."""
-import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -174,7 +173,7 @@ class _Lane:
         # rows of this call: up to (not including) the row of the next frame the network has not seen
         R = int(self.row_of_frame[f0 + k]) if f0 + k < self.frames_in else self.rows_in
         n_rows = R - self.rows_called
-        dst = self.pipe.slot_for(n_rows)
+        self.pipe.slot_for(n_rows)                                   # (checks that the rows fit the storage)
         with torch.cuda.stream(self.stream):
             if k:
                 rows = self.row_of_frame[f0:f0 + k]
@@ -253,7 +252,6 @@ class JobScheduler:
         self.engines = list(engines)
         self.streams = lane_streams(self.dev, len(self.engines))
         self.pool = ThreadPoolExecutor(max_workers=max(1, int(host_threads)))
-        self.lock = threading.Lock()
 
     def close(self):
         self.pool.shutdown(wait=True)
@@ -267,6 +265,9 @@ class JobScheduler:
         """-> list, in input order, of {ratio: (VD, smart_crop_results)}; each entry equals smart_vid_crop_ratios on that
         video alone.  stats of the run in self.stats."""
         import torch
+        if not self.CP['clust_filt']:
+            raise NotImplementedError('JobScheduler runs the cluster filter inside the stream (clust_filt=True, as in both '
+                                      'published parameter sets); use crop_videos(..., packed=False) otherwise')
         self.videos = list(videos)
         self.out = [None] * len(self.videos)
         self.next_idx = 0
@@ -275,9 +276,6 @@ class JobScheduler:
         self.host_s = dict(plan=0.0, intake=0.0, enqueue_net=0.0, enqueue_tail=0.0, wait=0.0, dispatch=0.0)
         t0 = time.perf_counter()
         lanes = [_Lane(self, e, s, k) for k, (e, s) in enumerate(zip(self.engines, self.streams))]
-        if not self.CP['clust_filt']:
-            raise NotImplementedError('JobScheduler runs the cluster filter inside the stream (clust_filt=True, as in both '
-                                      'published parameter sets); use crop_videos(..., packed=False) otherwise')
         with torch.cuda.device(self.dev):
             live = list(lanes)
             while live:

@@ -168,7 +168,7 @@ def crop_job(make_video, frame_counts, names, CP, ratios, out_dir=None, workers=
             allb[r].update(box[0])
         elif skip:
             allb[r].update({i: kept[i][r] for i in kept})
-    if world > 1:
+    if world > 1 and out_dir is not None:                    # (only the result files need the info dicts: no files, no object collective)
         bucket = [None] * world if rank == 0 else None
         dist.gather_object(infos, bucket, dst=0)                                # host-side text, outside the data path
         if rank == 0:

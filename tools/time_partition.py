@@ -39,6 +39,9 @@ def run_layout(P, T, steps=120):
         net_bits, tail_bits = cu_sets(T)
         nets = [masked_stream(net_bits) for _ in range(P)]
         tails = [masked_stream(tail_bits) for _ in range(P)]
+    elif T == -9:                                       # product layout, the tail replaced by a one-thread spin of the same duration (its footprint gone)
+        nets = [torch.cuda.Stream() for _ in range(P)]
+        tails = nets
     elif T == -3:                                       # one HIGH-PRIORITY stream per slot for network and tail alike (does priority change anything?)
         nets = [torch.cuda.Stream(priority=-1) for _ in range(P)]
         tails = nets
@@ -68,8 +71,11 @@ def run_layout(P, T, steps=120):
             with torch.cuda.stream(tails[k]):
                 if tails[k] is not nets[k]:
                     tails[k].wait_event(ev_net[k][j])
-                xy = engs[k].cluster_center_(maps[k][j], flags, CP)
-                xyh[k][j].copy_(xy, non_blocking=True)
+                if T == -9:
+                    torch.cuda._sleep(SPIN)
+                else:
+                    xy = engs[k].cluster_center_(maps[k][j], flags, CP)
+                    xyh[k][j].copy_(xy, non_blocking=True)
                 ev_done[k][j].record(tails[k])
             used[k][j] = True
         torch.cuda.synchronize()
@@ -81,7 +87,23 @@ def run_layout(P, T, steps=120):
     return ms
 
 
+# cycles of torch.cuda._sleep that last as long as one lone tail round of this batch (~0.5 ms)
+def _calibrate():
+    e = ops.Engine(sd)
+    m = e.saliency(e.resize_frames(frames, 140, 250)); e.threshold_(m, CP['t_threshold'])
+    fl = np.zeros(B, np.uint8)
+    for _ in range(3): e.cluster_center_(m.clone(), fl, CP)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(10): e.cluster_center_(m.clone(), fl, CP)
+    torch.cuda.synchronize(); tail_ms = (time.perf_counter() - t) / 10 * 1e3
+    torch.cuda._sleep(1000000); torch.cuda.synchronize(); t = time.perf_counter()
+    torch.cuda._sleep(10000000); torch.cuda.synchronize(); per = (time.perf_counter() - t) * 1e3 / 10000000
+    e.close()
+    return int(tail_ms / per), tail_ms
+SPIN, TAIL_MS = _calibrate()
+print('one lone tail round: %.3f ms = %d spin cycles' % (TAIL_MS, SPIN), flush=True)
+
 for lay in sys.argv[1:] or ['4:0', '4:16', '4:32', '5:32', '6:32']:
     P, T = (int(v) for v in lay.split(':'))
     ms = run_layout(P, T)
-    print('%d batches in flight, tail on %3d reserved CUs (%s): %.4f ms per step of %d frames = %.0f frames/s' % (P, max(T, 0), ('own unmasked stream' if T == -1 else 'own HIGH-PRIORITY stream' if T == -2 else 'one high-priority stream per slot') if T < 0 else (order if T else 'product layout'), ms, B, B / ms * 1e3), flush=True)
+    print('%d batches in flight, tail on %3d reserved CUs (%s): %.4f ms per step of %d frames = %.0f frames/s' % (P, max(T, 0), ('the tail replaced by a one-thread spin of its duration' if T == -9 else 'own unmasked stream' if T == -1 else 'own HIGH-PRIORITY stream' if T == -2 else 'one high-priority stream per slot') if T < 0 else (order if T else 'product layout'), ms, B, B / ms * 1e3), flush=True)

@@ -140,6 +140,10 @@ struct SvcHandle {
     std::map<std::tuple<const void *, void *, int, int, int, const void *>, hipGraphExec_t> graphs;
     bool keep_input = false;           // ... which then also writes the normalised network input for svc_debug_tap(SVC_TAP_INPUT) (SVC_KEEP_INPUT=1)
     bool dwpw = true;                  // depthwise 3x3 fused into the following 1x1 project (SVC_DWPW=0: two kernels)
+    bool dwpwx = false;                // k_dwpw also computes the NEXT block's 1x1 expansion where the tile is complete in one workgroup (SVC_DWPWX=1).
+                                       // Measured: a lone pass -47 us (pw class 1.414 -> 1.367 ms), the pipelined step +1.7 % (the expansion's MFMAs
+                                       // then run under k_dwpw's 184 registers, two workgroups per CU, where k_pwr's 40-register waves co-resided
+                                       // with other streams' kernels): off by default
     int dwpw_max_nt = 5;               // output-channel tiles (32 columns each) per k_dwpw workgroup: fewer = more workgroups, the depthwise part redone per group (SVC_DWPW_NT)
     int dwpw_min_px = 400;             // ... on levels with at least this many pixels per frame; the 8x13 level has too few patches (SVC_DWPW_MIN_PX)
     int dw_tile = 42;                  // stride-1 depthwise: outputs per thread as TX*10+TY (SVC_DW_TILE: 21, 22, 41, 42, 44; 0 = one output per thread)

@@ -2011,15 +2011,28 @@ static int launch_dw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer
 #define IRB_STAMP(i)   // phase stamps of k_irb: defined by tools/micro/irb_phases.hip only (no code in the product)
 #endif
 
-template <int NT, int PW, int NWV>     // NWV = waves per workgroup = ways of the K split (8 was measured: no gain)
+// XE (round 4): the NEXT block's 1x1 expansion in the same launch.  The project's output tile -- 32 pixels x N = 32 NT channels,
+// complete in this workgroup (one output-channel group) -- is the whole input of the next block's expand GEMM for those
+// pixels (a 1x1 convolution: no halo), so after the K partials are summed the tile is parked in LDS (over the dead depthwise
+// slabs), every wave takes a quarter of the 6 N expansion columns with the weights straight from L2 (A operand) and the tile's
+// rows resident in registers (B operand; the k order of k_pwr, so the sums are bit-identical to the separate kernel), and
+// writes ReLU6(. + bias) through its transposition slab.  One launch, one prologue and one read of the block's output less per
+// block; what the launch adds is the expansion's MFMA time with every SIMD busy (blocks 8-13 at 16x26: DESIGN.md 5).
+template <int NT, int PW, int NWV, bool XE = false>     // NWV = waves per workgroup = ways of the K split (8 was measured: no gain)
 __global__ __launch_bounds__(64 * NWV) void k_dwpw(const float *__restrict__ X, int H, int W, int C,
                                               const float *__restrict__ Wd, const float *__restrict__ bd,
                                               const float *__restrict__ Wp, const float *__restrict__ bp, int N,
                                               int Npad, const float *__restrict__ R, int ldr, float *__restrict__ Y,
-                                              int ldy, int relu6, int tiles_x, int tiles_y) {
+                                              int ldy, int relu6, int tiles_x, int tiles_y,
+                                              const float *__restrict__ We2 = nullptr, const float *__restrict__ be2 = nullptr,
+                                              int Ce2 = 0, float *__restrict__ E2 = nullptr) {
     constexpr int PH = 32 / PW;
-    __shared__ float Dw[NWV][32 * IRB_ES];
-    __shared__ float red[NWV][16][64];
+    // one LDS block: the waves' depthwise slabs [NWV][32 x IRB_ES], then the K partials [NWV][16][64].  XE re-uses it once both are
+    // dead: the finished tile over the first slabs, the expansion's per-wave transposition slabs over the rest (no LDS on top)
+    __shared__ float smem_dwpw[NWV * 32 * IRB_ES + NWV * 16 * 64];
+    float (*Dw)[32 * IRB_ES] = (float (*)[32 * IRB_ES])smem_dwpw;
+    float (*red)[16][64] = (float (*)[16][64])(smem_dwpw + NWV * 32 * IRB_ES);
+    float *xslab = smem_dwpw + (NWV * 32 * IRB_ES + NWV * 16 * 64 - NWV * 32 * PWR_SLAB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     int bid = blockIdx.x;
     const int tx = bid % tiles_x;
@@ -2178,29 +2191,93 @@ __global__ __launch_bounds__(64 * NWV) void k_dwpw(const float *__restrict__ X, 
         if (wave >= 4) continue;                            // (8-wave form: the upper waves only contribute partials)
         const int g = wave;
         const int col = n0 + t * 32 + 8 * g + 4 * hh;
-        if (col >= N || !live) continue;
-        float4 v = make_float4(red[0][4 * g][lane], red[0][4 * g + 1][lane], red[0][4 * g + 2][lane], red[0][4 * g + 3][lane]);
+        if (!XE && (col >= N || !live)) continue;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < N && live) {
+            v = make_float4(red[0][4 * g][lane], red[0][4 * g + 1][lane], red[0][4 * g + 2][lane], red[0][4 * g + 3][lane]);
 #pragma unroll
-        for (int q = 1; q < NWV; ++q) {
-            v.x += red[q][4 * g][lane]; v.y += red[q][4 * g + 1][lane];
-            v.z += red[q][4 * g + 2][lane]; v.w += red[q][4 * g + 3][lane];
+            for (int q = 1; q < NWV; ++q) {
+                v.x += red[q][4 * g][lane]; v.y += red[q][4 * g + 1][lane];
+                v.z += red[q][4 * g + 2][lane]; v.w += red[q][4 * g + 3][lane];
+            }
+            const float4 bv = *(const float4 *)(bp + col);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (R) {
+                const float4 rv = *(const float4 *)(R + pix * ldr + col);
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            }
+            if (relu6) {
+                v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
+                v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
+            }
+            *(float4 *)(Y + pix * ldy + col) = v;
         }
-        const float4 bv = *(const float4 *)(bp + col);
-        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        if (R) {
-            const float4 rv = *(const float4 *)(R + pix * ldr + col);
-            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        // XE: the finished tile stays on chip: [32 pixels][N + 4] over the depthwise slabs (every wave is past its chunk loop:
+        // the barrier above), zeros for pixels outside the image
+        if (XE) *(float4 *)(&Dw[0][0] + r * (NT * 32 + 4) + t * 32 + 8 * g + 4 * hh) = v;
+    }
+    if constexpr (XE) {
+        static_assert(NWV == 4, "the expansion splits its columns over four waves");
+        constexpr int K2 = NT * 32, KS2 = K2 / 8, YS = K2 + 4;
+        static_assert(32 * YS <= NWV * 32 * IRB_ES + NWV * 16 * 64 - NWV * 32 * PWR_SLAB, "the tile must end where the transposition slabs begin");
+        __syncthreads();
+        const float *yt = &Dw[0][0] + r * YS + 4 * hh;
+        float4 yb[KS2];
+#pragma unroll
+        for (int p = 0; p < KS2; ++p) yb[p] = *(const float4 *)(yt + 8 * p);
+        float *slab = xslab + wave * (32 * PWR_SLAB);
+        const int srow = lane >> 3, sc = (lane & 7) * 4;    // store role: rows srow + 8 it, channels sc .. sc + 3 of the tile
+        size_t spix[4];
+        bool slive[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = srow + 8 * it, sy = y0 + row / PW, sx = x0 + row % PW;
+            slive[it] = sy < H && sx < W;
+            spix[it] = ((size_t)f * H + min(sy, H - 1)) * W + min(sx, W - 1);
         }
-        if (relu6) {
-            v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
-            v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
+        const int tiles2 = Ce2 >> 5;
+        for (int tile = wave; tile < tiles2; tile += NWV) {
+            const float *wr = We2 + (size_t)(tile * 32 + r) * K2 + 4 * hh;
+            float4 wv[KS2];
+#pragma unroll
+            for (int p = 0; p < KS2; ++p) wv[p] = *(const float4 *)(wr + 8 * p);
+            f32x16 a2;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a2[i] = 0.f;
+#pragma unroll
+            for (int p = 0; p < KS2; ++p) {
+                a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[p].x, yb[p].x, a2, 0, 0, 0);       // swapped: lane = pixel (k_pwr's order)
+                a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[p].y, yb[p].y, a2, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[p].z, yb[p].z, a2, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[p].w, yb[p].w, a2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g2 = 0; g2 < 4; ++g2)
+                *(float4 *)(slab + r * PWR_SLAB + 8 * g2 + 4 * hh) = make_float4(a2[4 * g2], a2[4 * g2 + 1], a2[4 * g2 + 2], a2[4 * g2 + 3]);
+            __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): the slab is private to the wave
+            __builtin_amdgcn_wave_barrier();
+            const float4 bv = *(const float4 *)(be2 + tile * 32 + sc);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                float4 v = *(const float4 *)(slab + (srow + 8 * it) * PWR_SLAB + sc);
+                if (!slive[it]) continue;
+                v.x = fminf(fmaxf(v.x + bv.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y + bv.y, 0.f), 6.f);
+                v.z = fminf(fmaxf(v.z + bv.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w + bv.w, 0.f), 6.f);
+                *(float4 *)(E2 + spix[it] * (size_t)Ce2 + tile * 32 + sc) = v;
+            }
+            __builtin_amdgcn_wave_barrier();                // the next tile overwrites the slab
         }
-        *(float4 *)(Y + pix * ldy + col) = v;
     }
 }
 
+// Can the next block's expansion ride in this block's k_dwpw launch?  (one output-channel group, N = 64 or 96, 8x4 patches)
+static bool dwpw_takes_expand(const SvcHandle *h, const SvcLayer &Lp, const SvcLayer &Le2, int W) {
+    return h->dwpwx && (Lp.cout == 64 || Lp.cout == 96) && Lp.cout / 32 <= std::min(5, h->dwpw_max_nt) && Le2.cin == Lp.cout &&
+           (Le2.cout % 32) == 0 && Le2.relu6 && !Lp.relu6 && (W % 8 == 0 || W > 16);
+}
+
 static int launch_dwpw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer &Ld, const SvcLayer &Lp, const float *R,
-                       int ldr, float *Y, int ldy, int n, int H, int W) {
+                       int ldr, float *Y, int ldy, int n, int H, int W, const SvcLayer *Le2 = nullptr, float *E2 = nullptr) {
     ProfScope ps(h, SVC_K_PW, s);
     const int C = Ld.cout, N = Lp.cout, Npad = (N + 31) / 32 * 32, tiles = Npad / 32;
     // output-channel groups of at most 5 tiles, as even as possible (the depthwise part is redone per group)
@@ -2208,6 +2285,14 @@ static int launch_dwpw(SvcHandle *h, hipStream_t s, const float *X, const SvcLay
     const int pw = (W % 8 == 0 || W > 16) ? 8 : 16;          // 8x4 patches; 16x2 on the narrow 13-wide level
     const int tx = ceil_div(W, pw), ty = ceil_div(H, 32 / pw);
     dim3 grid((unsigned)(n * tx * ty), groups);
+    if (Le2) {                                               // + the next block's expansion (dwpw_takes_expand has said yes)
+        if (nt == 2) k_dwpw<2, 8, 4, true><<<grid, 256, 0, s>>>(X, H, W, C, Ld.w.dev, Ld.b.dev, Lp.w.dev, Lp.b.dev, N, Npad, R, ldr, Y, ldy,
+                                                             Lp.relu6, tx, ty, Le2->w.dev, Le2->b.dev, Le2->cout, E2);
+        else k_dwpw<3, 8, 4, true><<<grid, 256, 0, s>>>(X, H, W, C, Ld.w.dev, Ld.b.dev, Lp.w.dev, Lp.b.dev, N, Npad, R, ldr, Y, ldy,
+                                                        Lp.relu6, tx, ty, Le2->w.dev, Le2->b.dev, Le2->cout, E2);
+        SVC_CHECK_LAUNCH();
+        return SVC_OK;
+    }
 #define DWPW_ARGS X, H, W, C, Ld.w.dev, Ld.b.dev, Lp.w.dev, Lp.b.dev, N, Npad, R, ldr, Y, ldy, Lp.relu6, tx, ty
 #define DWPW_CASE(NTv)                                                                    \
     case NTv:                                                                             \
@@ -2750,6 +2835,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
         SVC_CHECK_LAUNCH();
     }
     int cur = 0;
+    const float *pre_exp = nullptr;                          // the current block's expansion, if the previous block's launch has computed it
     // backbone blocks 1..17  (MobileNetV2.py:111-136)
     static const int T[7] = {1, 6, 6, 6, 6, 6, 6}, Cc[7] = {16, 24, 32, 64, 96, 160, 320}, Nn[7] = {1, 2, 3, 4, 3, 3, 1},
                      Ss[7] = {1, 2, 2, 2, 1, 2, 1};
@@ -2798,12 +2884,28 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
             } else {
                 const float *dwin = x;
                 if (t != 1) {
-                    RC(launch_pw(h, s, x, inp, next(), nullptr, 0, E0, inp * t, n * H * W, n));
-                    dwin = E0;
+                    const SvcLayer &Le = next();
+                    if (pre_exp) dwin = pre_exp;              // the previous block's launch has computed this expansion (XE)
+                    else {
+                        RC(launch_pw(h, s, x, inp, Le, nullptr, 0, E0, inp * t, n * H * W, n));
+                        dwin = E0;
+                    }
                 }
+                pre_exp = nullptr;
                 const SvcLayer &Ld = next();
                 if (h->dwpw && dws == 1 && H * W >= h->dwpw_min_px) {
-                    RC(launch_dwpw(h, s, dwin, Ld, next(), res ? x : nullptr, oup, y, oup, n, H, W));
+                    const SvcLayer &Lp = next();
+                    // the next block's expansion in the same launch: this block keeps its resolution and is not a tap, the next
+                    // block exists, expands, and takes this same path (un-fused, depthwise + project as k_dwpw)
+                    const SvcLayer *Le2 = nullptr;
+                    float *e2 = nullptr;
+                    if (!tap && idx + 1 <= 17 && idx + 1 > h->fuse_max && li < h->layers.size() && h->layers[li].kind == SvcLayer::PW &&
+                        dwpw_takes_expand(h, Lp, h->layers[li], W)) {
+                        Le2 = &h->layers[li];
+                        e2 = (dwin == E0) ? E1 : E0;          // not the buffer this launch reads
+                    }
+                    RC(launch_dwpw(h, s, dwin, Ld, Lp, res ? x : nullptr, oup, y, oup, n, H, W, Le2, e2));
+                    pre_exp = e2;
                 } else {
                     RC(launch_dw(h, s, dwin, Ld, E1, n, H, W, dws));
                     RC(launch_pw(h, s, E1, inp * t, next(), res ? x : nullptr, oup, y, oup, n * OH * OW, n));
@@ -3109,6 +3211,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->dwpw = atoi(env) != 0;
     env = getenv("SVC_DWPW_MIN_PX");
     if (env) h->dwpw_min_px = atoi(env);
+    env = getenv("SVC_DWPWX");
+    if (env) h->dwpwx = atoi(env) != 0;
     env = getenv("SVC_DWPW_NT");
     if (env) h->dwpw_max_nt = atoi(env);
     env = getenv("SVC_DW_TILE");

@@ -118,6 +118,7 @@ def test_saliency_batch_and_chunk_independence(engine):
     {'SVC_STEM_FUSED': '1'},                                # features.0 inside the kernel of block 1 (MFMA im2col form)
     {'SVC_FRONT': '0'},                                     # LANCZOS, features.0 and features.1 as three kernels instead of k_front
     {'SVC_CHUNK': '5'},                                     # ragged chunks of the batch
+    {'SVC_DWPWX': '1'},                                     # the next block's expansion inside k_dwpw's launch instead of its own k_pwr launch
     {'SVC_CGB': '1'},                                       # 8x13-level blocks as k_cgb (expansion in LDS, channel groups; DESIGN 5, not adopted)
 ])
 def test_saliency_kernel_families_agree(engine, synthetic_sd, knobs):
@@ -146,6 +147,35 @@ def test_saliency_kernel_families_agree(engine, synthetic_sd, knobs):
         assert np.abs(dec - ref_dec).max() <= 2e-4 * np.abs(ref_dec).max()
     d = np.abs(maps.astype(int) - ref_maps.astype(int))
     assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+@pytest.mark.parametrize('shape', [(140, 250), (187, 250), (250, 140)])
+def test_expansion_inside_the_previous_blocks_launch_is_bit_identical(engine, synthetic_sd, shape):
+    """Round 4 (SVC_DWPWX=1; off by default: it shortens a lone pass and lengthens the pipelined step): blocks 8-13
+    compute the NEXT block's 1x1 expansion inside their depthwise+project launch (k_dwpw<.., XE>) with k_pwr's k order: maps and
+    taps are bit-identical to the default path (the expansion as its own launch), at the three geometries (the 4:3 and portrait
+    levels have other patch counts and ragged edges)."""
+    h, w = shape
+    NH, NW = U.get_optimal_out_size((h, w))
+    fr = torch.from_numpy(synth.blob_frames(5, h, w, seed=h + w)).cuda()
+    maps = engine.saliency(fr).cpu().numpy()
+    taps = [engine.tap(ops.TAP_FEAT2X, 4, (NH // 16, NW // 16, 160)), engine.tap(ops.TAP_DEC, 4, (NH // 8, NW // 8, 64))]
+    old = os.environ.get('SVC_DWPWX')
+    os.environ['SVC_DWPWX'] = '1'
+    try:
+        other = ops.Engine(synthetic_sd)
+    finally:
+        if old is None:
+            os.environ.pop('SVC_DWPWX', None)
+        else:
+            os.environ['SVC_DWPWX'] = old
+    try:
+        assert np.array_equal(other.saliency(fr).cpu().numpy(), maps)
+        taps0 = [other.tap(ops.TAP_FEAT2X, 4, (NH // 16, NW // 16, 160)), other.tap(ops.TAP_DEC, 4, (NH // 8, NW // 8, 64))]
+        for a, b in zip(taps, taps0):
+            assert np.array_equal(a, b)
+    finally:
+        other.close()
 
 
 @pytest.mark.parametrize('shape', [(140, 250), (187, 250), (250, 140), (360, 640), (97, 131)])

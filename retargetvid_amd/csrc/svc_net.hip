@@ -1635,6 +1635,7 @@ static inline unsigned blocks256(size_t total) { return (unsigned)((total + 255)
 static int launch_pw_ex(SvcHandle *h, hipStream_t s, const float *X, int ldx, const float *Wt, int ldw, int K,
                         const float *bias, int relu6v, int N, const float *R, int ldr, float *Y, int ldy, int M, int n,
                         const UpsAdd *ups) {
+    if (h->seg_off >> h->seg_cur & 1u) return SVC_OK;
     ProfScope ps(h, SVC_K_PW, s);
     const int Npad = (N + 31) / 32 * 32, tiles = Npad / 32;
     UpsAdd ua = ups ? *ups : UpsAdd{nullptr, 0, 0, 0, make_fdiv(1), make_fdiv(1)};
@@ -1938,6 +1939,7 @@ __global__ __launch_bounds__(256) void k_cgb_sum(const float *__restrict__ part,
 
 static int launch_cgb(SvcHandle *h, hipStream_t s, const float *X, int n, int H, int W, int Cin, const SvcLayer &Le, const SvcLayer &Ld,
                       const SvcLayer &Lp, const float *R, float *Y) {
+    if (h->seg_off >> h->seg_cur & 1u) return SVC_OK;
     ProfScope ps(h, SVC_K_PW, s);
     const int Cexp = Le.cout, Cout = Lp.cout, npx = H * W, groups = (Cexp + CGB_GC - 1) / CGB_GC;
     const size_t per_group = (size_t)n * npx * Cout;
@@ -1959,6 +1961,7 @@ static int launch_cgb(SvcHandle *h, hipStream_t s, const float *X, int n, int H,
 
 static int launch_dw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer &L, float *Y, int n, int H, int W,
                      int stride) {
+    if (h->seg_off >> h->seg_cur & 1u) return SVC_OK;
     ProfScope ps(h, SVC_K_DW, s);
     const int C = L.cout, OH = stride == 2 ? H / 2 : H, OW = stride == 2 ? W / 2 : W;
     size_t total = (size_t)n * OH * OW * (C / 4);
@@ -2278,6 +2281,7 @@ static bool dwpw_takes_expand(const SvcHandle *h, const SvcLayer &Lp, const SvcL
 
 static int launch_dwpw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer &Ld, const SvcLayer &Lp, const float *R,
                        int ldr, float *Y, int ldy, int n, int H, int W, const SvcLayer *Le2 = nullptr, float *E2 = nullptr) {
+    if (h->seg_off >> h->seg_cur & 1u) return SVC_OK;
     ProfScope ps(h, SVC_K_PW, s);
     const int C = Ld.cout, N = Lp.cout, Npad = (N + 31) / 32 * 32, tiles = Npad / 32;
     // output-channel groups of at most 5 tiles, as even as possible (the depthwise part is redone per group)
@@ -2757,6 +2761,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRB_WAVES, 
 static int launch_irb(SvcHandle *h, hipStream_t s, const float *X, int n, int H, int W, int Cin, const SvcLayer *Le,
                       const SvcLayer &Ld, const SvcLayer &Lp, int stride, const float *R, float *Y,
                       const SvcLayer *Lstem = nullptr) {
+    if (h->seg_off >> h->seg_cur & 1u) return SVC_OK;
     ProfScope ps(h, SVC_K_PW, s);
     const int Ce = Ld.cout, Cout = Lp.cout, CoutP = (Cout + 31) / 32 * 32;
     const int OH = H / stride, OW = W / stride;
@@ -2808,8 +2813,10 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     const int fr_lds = front_region_a(p->fr_nr, p->fr_nc) + FR_S_BYTES;
     const bool front = h->front && h->stem_mfma && !h->stem_fused && h->fuse_max >= 1 && p->fr_ok;
     p->last_front = front;
+    h->seg_cur = 0;
+    auto seg_on = [&]() { return !(h->seg_off >> h->seg_cur & 1u); };   // SVC_SEG_OFF (measurement aid): see svc_internal.h
     // K0
-    if (!front) {
+    if (!front && seg_on()) {
         ProfScope ps(h, SVC_K_LANCZOS, s);
         dim3 grid(ceil_div(NH, p->lz_rows), n);
         size_t lds = ((size_t)p->lz_tile_cap * p->w * 3 + 15) / 16 * 16 + ((size_t)p->lz_tile_cap * NW * 3 + 15) / 16 * 16 +
@@ -2822,7 +2829,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     // stem: on its own, or inside the kernel of backbone block 1 (which then reads the network input directly)
     const SvcLayer &Lstem = next();
     const bool stem_fused = h->stem_fused && h->fuse_max >= 1;
-    if (!stem_fused && !front) {
+    if (!stem_fused && !front && seg_on()) {
         ProfScope ps(h, SVC_K_STEM, s);
         if (h->stem_mfma) {
             const int tx = ceil_div(W, STEM_TW), ty = ceil_div(H, STEM_TH);
@@ -2845,6 +2852,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
             const int oup = Cc[st], stride = (i == 0) ? Ss[st] : 1, t = T[st];
             const bool res = (stride == 1 && inp == oup);
             const bool tap = (idx == 7 || idx == 14);             // full-resolution output feeds a skip
+            h->seg_cur = idx <= 1 ? 0 : idx <= 3 ? 1 : idx <= 7 ? 2 : idx <= 14 ? 3 : 4;
             const int dws = (stride == 2 && !tap) ? 2 : 1;        // stride-2 dw == stride-1 dw + ::2 sub-sampling
             const float *x = P[cur];
             int OH = H / dws, OW = W / dws;
@@ -2867,7 +2875,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
                     A.row_lo[i] = p->fr_row_lo[i]; A.row_n[i] = p->fr_row_n[i];
                     A.col_lo[i] = p->fr_col_lo[i]; A.col_n[i] = p->fr_col_n[i];
                 }
-                k_front<<<dim3((unsigned)(n * A.tiles_x * A.tiles_y)), 256, fr_lds, s>>>(A);
+                if (seg_on()) k_front<<<dim3((unsigned)(n * A.tiles_x * A.tiles_y)), 256, fr_lds, s>>>(A);
                 SVC_CHECK_LAUNCH();
             } else if (idx <= h->fuse_max && (t != 1 || inp == 32)) {
                 const SvcLayer *Le = (t != 1) ? &next() : nullptr;
@@ -2913,7 +2921,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
             }
             if (tap) {
                 ProfScope ps(h, SVC_K_RESAMPLE, s);
-                k_subsample<<<blocks256((size_t)n * (OH / 2) * (OW / 2) * (oup / 4)), 256, 0, s>>>(y, P[cur ^ 1], n, OH,
+                if (seg_on()) k_subsample<<<blocks256((size_t)n * (OH / 2) * (OW / 2) * (oup / 4)), 256, 0, s>>>(y, P[cur ^ 1], n, OH,
                                                                                                   OW, oup);
                 SVC_CHECK_LAUNCH();
                 OH /= 2; OW /= 2;
@@ -2925,6 +2933,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     // features.18 -> CAT1[:, 0:1280], Gaussian maps -> CAT1[:, 1280:1296]
     const int H5 = H, W5 = W, H4 = 2 * H5, W4 = 2 * W5, H3 = 4 * H5, W3 = 4 * W5;
     float *CAT1 = p->buf(B_CAT1);
+    h->seg_cur = 5;
     RC(launch_pw(h, s, P[cur], 320, next(), nullptr, 0, CAT1, 1296, n * H5 * W5, n));
     // skips (model.py:443-444)
     float *CAT2 = p->buf(B_CAT2), *CAT3 = p->buf(B_CAT3);
@@ -2949,6 +2958,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
         RC(launch_pw(h, s, p->buf(B_PCD), 1296, next(), nullptr, 0, p->buf(B_PC), 256, n * H5 * W5, n));
     }
     // US1 + concat, US2 block
+    h->seg_cur = 6;
     if (h->split_up) {
         // expand(concat(up(PC), skip)) = relu6(up(W[:, :256] . PC) + W[:, 256:] . skip + b)
         const SvcLayer &Le = next();
@@ -2960,7 +2970,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     } else {
         {
             ProfScope ps(h, SVC_K_RESAMPLE, s);
-            k_upsample2x<<<blocks256((size_t)n * H4 * W4 * 64), 256, 0, s>>>(p->buf(B_PC), CAT2, n, H5, W5, 256, 384,
+            if (seg_on()) k_upsample2x<<<blocks256((size_t)n * H4 * W4 * 64), 256, 0, s>>>(p->buf(B_PC), CAT2, n, H5, W5, 256, 384,
                                                                              make_fdiv(64), make_fdiv(W4), make_fdiv(H4));
             SVC_CHECK_LAUNCH();
         }
@@ -2973,6 +2983,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
         RC(launch_dw(h, s, p->buf(B_U2E), next(), p->buf(B_U2D), n, H4, W4, 1));
         RC(launch_pw(h, s, p->buf(B_U2D), 768, next(), nullptr, 0, p->buf(B_U2), 128, n * H4 * W4, n));
     }
+    h->seg_cur = 7;
     if (h->split_up) {
         const SvcLayer &Le = next();
         RC(launch_pw_ex(h, s, p->buf(B_U2), 128, Le.w.dev, 192, 128, nullptr, 0, 384, nullptr, 0, p->buf(B_T2), 384,
@@ -2983,7 +2994,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     } else {
         {
             ProfScope ps(h, SVC_K_RESAMPLE, s);
-            k_upsample2x<<<blocks256((size_t)n * H3 * W3 * 32), 256, 0, s>>>(p->buf(B_U2), CAT3, n, H4, W4, 128, 192,
+            if (seg_on()) k_upsample2x<<<blocks256((size_t)n * H3 * W3 * 32), 256, 0, s>>>(p->buf(B_U2), CAT3, n, H4, W4, 128, 192,
                                                                              make_fdiv(32), make_fdiv(W3), make_fdiv(H3));
             SVC_CHECK_LAUNCH();
         }
@@ -2997,10 +3008,11 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
         RC(launch_pw(h, s, p->buf(B_P3D), 384, next(), nullptr, 0, p->buf(B_DEC), 64, n * H3 * W3, n));
     }
     // adaptation, smoothing, resize, quantise
+    h->seg_cur = 8;
     const SvcLayer &La = next();
     {
         ProfScope ps(h, SVC_K_RESAMPLE, s);
-        k_adapt<<<blocks256((size_t)n * H3 * W3), 256, 0, s>>>(p->buf(B_DEC), La.w.dev, La.b.dev, p->buf(B_LOGIT),
+        if (seg_on()) k_adapt<<<blocks256((size_t)n * H3 * W3), 256, 0, s>>>(p->buf(B_DEC), La.w.dev, La.b.dev, p->buf(B_LOGIT),
                                                               (size_t)n * H3 * W3, (unsigned *)p->fmax.p, n);
         SVC_CHECK_LAUNCH();
     }
@@ -3011,16 +3023,16 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
         dim3 grid(ceil_div(p->h, p->sd_rows), n);
         if (h->smooth_mfma && NW % 8 == 0 && NW == 8 * W3 && NH == 8 * H3) {
             size_t lds = ((size_t)H3 * W3 + 64 * SD_KP + (size_t)p->sd_tile_cap * NW) * sizeof(float);
-            k_smooth_down_mfma<<<grid, 256, lds, s>>>(p->buf(B_LOGIT), Ls.w.dev, p->buf(B_PRE), (unsigned *)p->fmax.p, H3, W3,
+            if (seg_on()) k_smooth_down_mfma<<<grid, 256, lds, s>>>(p->buf(B_LOGIT), Ls.w.dev, p->buf(B_PRE), (unsigned *)p->fmax.p, H3, W3,
                                                       NH, NW, p->h, p->w, p->sd_rows, p->sd_tile_cap, make_fdiv(p->w));
         } else {
             size_t lds = ((size_t)H3 * W3 + 64 * 49 + (size_t)p->sd_tile_cap * NW) * sizeof(float);
-            k_smooth_down<<<grid, 256, lds, s>>>(p->buf(B_LOGIT), Ls.w.dev, p->buf(B_PRE), (unsigned *)p->fmax.p, H3, W3, NH,
+            if (seg_on()) k_smooth_down<<<grid, 256, lds, s>>>(p->buf(B_LOGIT), Ls.w.dev, p->buf(B_PRE), (unsigned *)p->fmax.p, H3, W3, NH,
                                                  NW, p->h, p->w, p->sd_rows, p->sd_tile_cap, make_fdiv(NW), make_fdiv(p->w));
         }
         SVC_CHECK_LAUNCH();
     }
-    k_quantise<<<blocks256((size_t)n * p->h * p->w), 256, 0, s>>>(p->buf(B_PRE), (const unsigned *)p->fmax.p, maps, n,
+    if (seg_on()) k_quantise<<<blocks256((size_t)n * p->h * p->w), 256, 0, s>>>(p->buf(B_PRE), (const unsigned *)p->fmax.p, maps, n,
                                                                  p->h * p->w, make_fdiv(p->h * p->w), thr);
     SVC_CHECK_LAUNCH();
     p->last_n = n;
@@ -3213,6 +3225,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->dwpw_min_px = atoi(env);
     env = getenv("SVC_DWPWX");
     if (env) h->dwpwx = atoi(env) != 0;
+    env = getenv("SVC_SEG_OFF");
+    if (env) h->seg_off = (unsigned)strtoul(env, nullptr, 0);
     env = getenv("SVC_DWPW_NT");
     if (env) h->dwpw_max_nt = atoi(env);
     env = getenv("SVC_DW_TILE");

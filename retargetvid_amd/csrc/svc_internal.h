@@ -144,6 +144,7 @@ struct SvcHandle {
                                        // Measured: a lone pass -47 us (pw class 1.414 -> 1.367 ms), the pipelined step +1.7 % (the expansion's MFMAs
                                        // then run under k_dwpw's 184 registers, two workgroups per CU, where k_pwr's 40-register waves co-resided
                                        // with other streams' kernels): off by default
+    bool pwpw = true;                  // the skip branches' two 1x1 convolutions (ReLU6 between) as one launch, k_pwpw: the intermediate tensor stays in registers (SVC_PWPW=0: two launches)
     unsigned seg_off = 0;              // MEASUREMENT AID (SVC_SEG_OFF=bitmask): stages of the network pass whose launches are skipped -- the maps are then garbage; tools/time_segments.py prices a stage by leaving it out.  Stages: 0 front, 1 blocks 2-3, 2 blocks 4-7, 3 blocks 8-14, 4 blocks 15-17, 5 features.18 + skips + post_cnn, 6 upsampling block 1, 7 upsampling block 2, 8 adaptation / smoothing / quantisation
     int seg_cur = 0;                   // stage forward_chunk is in
     int dwpw_max_nt = 5;               // output-channel tiles (32 columns each) per k_dwpw workgroup: fewer = more workgroups, the depthwise part redone per group (SVC_DWPW_NT)

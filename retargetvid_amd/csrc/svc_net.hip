@@ -2273,6 +2273,136 @@ __global__ __launch_bounds__(64 * NWV) void k_dwpw(const float *__restrict__ X, 
     }
 }
 
+// --------------------------------------------------------------------------------------
+// Two 1x1 convolutions in a row with a ReLU6 between them (the skip branches, model.py:443-444: 160 -> 320 -> 128 on the
+// 16x26 level, 64 -> 128 -> 64 on the 32x52 level) as ONE launch: the intermediate tensor (17 + 27 MB per 32 frames, written
+// by one kernel and read back by the next) never exists.  k_dwpw's structure with an MFMA producer in place of the depthwise
+// one: a workgroup = 32 pixels, its four waves split the INTERMEDIATE channels in chunks of 32 (chunk c -> wave (c + block) % 4);
+// per chunk a wave computes the 32-channel x 32-pixel tile of the first convolution (weights as the A operand, the pixel's
+// K1 inputs resident in registers, k_pwr's k order), adds the bias, clamps -- and the accumulator IS the B operand the
+// second convolution wants (a lane owns one pixel and channels 8g + 4hh + j of the chunk: the k pairs of k_pwr's steps), so
+// the tile goes straight into NT2 x 16 MFMAs against the chunk's columns of the second weight matrix: no LDS between the
+// two GEMMs.  The four waves' partial sums of the second convolution meet in LDS and are added in chunk-group order
+// (deterministic, independent of the batch; the order differs from k_pwr's / k_pw_sk's sequential sum: fp32 rounding only).
+// --------------------------------------------------------------------------------------
+template <int KS1, int NT2>     // K1 = 8 KS1 input channels, N2 = 32 NT2 output channels
+__global__ __launch_bounds__(256) void k_pwpw(const float *__restrict__ X, int ldx, const float *__restrict__ W1,
+                                              const float *__restrict__ b1, int Cm, const float *__restrict__ W2,
+                                              const float *__restrict__ b2, float *__restrict__ Y, int ldy, int M) {
+    constexpr int K1 = 8 * KS1;
+    __shared__ float red_pp[4][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int m0 = blockIdx.x * 32;
+    const float *xp = X + (size_t)min(m0 + r, M - 1) * ldx + 4 * hh;
+    float4 A1[KS1];
+#pragma unroll
+    for (int p = 0; p < KS1; ++p) A1[p] = *(const float4 *)(xp + 8 * p);
+    f32x16 acc2[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc2[t][i] = 0.f;
+    const float *w2row[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) w2row[t] = W2 + (size_t)(t * 32 + r) * Cm + 4 * hh;
+    const int nchunks = Cm >> 5;
+    for (int ch = (wave + 4 - (blockIdx.x & 3)) & 3; ch < nchunks; ch += 4) {
+        // second-convolution weights of the chunk's first k-steps: requested in front of the first convolution's MFMAs
+        float4 nb[NT2];
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) nb[t] = *(const float4 *)(w2row[t] + ch * 32);
+        const float *w1p = W1 + (size_t)(ch * 32 + r) * K1 + 4 * hh;
+        f32x16 e;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) e[i] = 0.f;
+        float4 wn = *(const float4 *)w1p;
+#pragma unroll
+        for (int p = 0; p < KS1; ++p) {
+            const float4 b = wn;
+            if (p + 1 < KS1) wn = *(const float4 *)(w1p + 8 * (p + 1));
+            e = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, A1[p].x, e, 0, 0, 0);      // swapped: lane = pixel (k_pwr's order)
+            e = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, A1[p].y, e, 0, 0, 0);
+            e = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, A1[p].z, e, 0, 0, 0);
+            e = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, A1[p].w, e, 0, 0, 0);
+        }
+        // e[4g + j] = intermediate channel ch*32 + 8g + 4hh + j of pixel r: bias, ReLU6 -- and it is the B operand of the
+        // second convolution's k-step g
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = *(const float4 *)(b1 + ch * 32 + 8 * g + 4 * hh);
+            e[4 * g] = fminf(fmaxf(e[4 * g] + bv.x, 0.f), 6.f);
+            e[4 * g + 1] = fminf(fmaxf(e[4 * g + 1] + bv.y, 0.f), 6.f);
+            e[4 * g + 2] = fminf(fmaxf(e[4 * g + 2] + bv.z, 0.f), 6.f);
+            e[4 * g + 3] = fminf(fmaxf(e[4 * g + 3] + bv.w, 0.f), 6.f);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 b[NT2];
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) b[t] = nb[t];
+            if (g < 3) {
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) nb[t] = *(const float4 *)(w2row[t] + ch * 32 + 8 * (g + 1));
+            }
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) {
+                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].x, e[4 * g], acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].y, e[4 * g + 1], acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].z, e[4 * g + 2], acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].w, e[4 * g + 3], acc2[t], 0, 0, 0);
+            }
+        }
+    }
+    // sum of the four K partials (wave order), bias, store: wave g finishes the channel runs 8g + 4hh .. + 3 of every tile
+    const bool live = m0 + r < M;
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+        if (t) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red_pp[wave][i][lane] = acc2[t][i];
+        __syncthreads();
+        const int g = wave, col = t * 32 + 8 * g + 4 * hh;
+        if (!live) continue;
+        // (the partials are added in the order of the chunk groups 0, 1, 2, 3 -- group k sits with wave (k + block) % 4 -- so the
+        // rotation that balances the SIMDs does not reach the result: a pixel's sum does not depend on its place in the batch)
+        const int w0 = blockIdx.x & 3;
+        float4 v = make_float4(red_pp[w0][4 * g][lane], red_pp[w0][4 * g + 1][lane], red_pp[w0][4 * g + 2][lane], red_pp[w0][4 * g + 3][lane]);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const int wq = (w0 + q) & 3;
+            v.x += red_pp[wq][4 * g][lane]; v.y += red_pp[wq][4 * g + 1][lane];
+            v.z += red_pp[wq][4 * g + 2][lane]; v.w += red_pp[wq][4 * g + 3][lane];
+        }
+        const float4 bv = *(const float4 *)(b2 + col);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        *(float4 *)(Y + (size_t)(m0 + r) * ldy + col) = v;
+    }
+}
+
+// the pair qualifies: K1 = 64 or 160, intermediate channels a multiple of 32, 64 or 128 outputs, ReLU6 between, none after
+static bool pwpw_takes(const SvcHandle *h, const SvcLayer &L1, const SvcLayer &L2) {
+    return h->pwpw && (L1.cin == 64 || L1.cin == 160) && (L1.cout % 32) == 0 && L2.cin == L1.cout && (L2.cout == 64 || L2.cout == 128) &&
+           L1.relu6 && !L2.relu6;
+}
+
+static int launch_pwpw(SvcHandle *h, hipStream_t s, const float *X, int ldx, const SvcLayer &L1, const SvcLayer &L2, float *Y, int ldy,
+                       int M) {
+    if (h->seg_off >> h->seg_cur & 1u) return SVC_OK;
+    ProfScope ps(h, SVC_K_PW, s);
+    const dim3 grid((unsigned)ceil_div(M, 32));
+#define PWPW_ARGS X, ldx, L1.w.dev, L1.b.dev, L1.cout, L2.w.dev, L2.b.dev, Y, ldy, M
+    if (L1.cin == 64) {
+        if (L2.cout == 64) k_pwpw<8, 2><<<grid, 256, 0, s>>>(PWPW_ARGS);
+        else k_pwpw<8, 4><<<grid, 256, 0, s>>>(PWPW_ARGS);
+    } else {
+        if (L2.cout == 64) k_pwpw<20, 2><<<grid, 256, 0, s>>>(PWPW_ARGS);
+        else k_pwpw<20, 4><<<grid, 256, 0, s>>>(PWPW_ARGS);
+    }
+#undef PWPW_ARGS
+    SVC_CHECK_LAUNCH();
+    return SVC_OK;
+}
+
 // Can the next block's expansion ride in this block's k_dwpw launch?  (one output-channel group, N = 64 or 96, 8x4 patches)
 static bool dwpw_takes_expand(const SvcHandle *h, const SvcLayer &Lp, const SvcLayer &Le2, int W) {
     return h->dwpwx && (Lp.cout == 64 || Lp.cout == 96) && Lp.cout / 32 <= std::min(5, h->dwpw_max_nt) && Le2.cin == Lp.cout &&
@@ -2937,10 +3067,22 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     RC(launch_pw(h, s, P[cur], 320, next(), nullptr, 0, CAT1, 1296, n * H5 * W5, n));
     // skips (model.py:443-444)
     float *CAT2 = p->buf(B_CAT2), *CAT3 = p->buf(B_CAT3);
-    RC(launch_pw(h, s, p->buf(B_F2X), 160, next(), nullptr, 0, p->buf(B_S2E), 320, n * H4 * W4, n));
-    RC(launch_pw(h, s, p->buf(B_S2E), 320, next(), nullptr, 0, CAT2 + 256, 384, n * H4 * W4, n));
-    RC(launch_pw(h, s, p->buf(B_F4X), 64, next(), nullptr, 0, p->buf(B_S4E), 128, n * H3 * W3, n));
-    RC(launch_pw(h, s, p->buf(B_S4E), 128, next(), nullptr, 0, CAT3 + 128, 192, n * H3 * W3, n));
+    {
+        const SvcLayer &Le2 = next();
+        const SvcLayer &Lr2 = next();
+        if (pwpw_takes(h, Le2, Lr2)) RC(launch_pwpw(h, s, p->buf(B_F2X), 160, Le2, Lr2, CAT2 + 256, 384, n * H4 * W4));
+        else {
+            RC(launch_pw(h, s, p->buf(B_F2X), 160, Le2, nullptr, 0, p->buf(B_S2E), 320, n * H4 * W4, n));
+            RC(launch_pw(h, s, p->buf(B_S2E), 320, Lr2, nullptr, 0, CAT2 + 256, 384, n * H4 * W4, n));
+        }
+        const SvcLayer &Le4 = next();
+        const SvcLayer &Lr4 = next();
+        if (pwpw_takes(h, Le4, Lr4)) RC(launch_pwpw(h, s, p->buf(B_F4X), 64, Le4, Lr4, CAT3 + 128, 192, n * H3 * W3));
+        else {
+            RC(launch_pw(h, s, p->buf(B_F4X), 64, Le4, nullptr, 0, p->buf(B_S4E), 128, n * H3 * W3, n));
+            RC(launch_pw(h, s, p->buf(B_S4E), 128, Lr4, nullptr, 0, CAT3 + 128, 192, n * H3 * W3, n));
+        }
+    }
     next();   // GAUSS placeholder layer (raw parameters; maps live in plan->gauss)
     if (p->gauss_filled < n) {       // the prior maps are constants: nothing else writes channels 1280..1295 of CAT1
         ProfScope ps(h, SVC_K_RESAMPLE, s);
@@ -3225,6 +3367,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->dwpw_min_px = atoi(env);
     env = getenv("SVC_DWPWX");
     if (env) h->dwpwx = atoi(env) != 0;
+    env = getenv("SVC_PWPW");
+    if (env) h->pwpw = atoi(env) != 0;
     env = getenv("SVC_SEG_OFF");
     if (env) h->seg_off = (unsigned)strtoul(env, nullptr, 0);
     env = getenv("SVC_DWPW_NT");

@@ -365,15 +365,16 @@ __global__ __launch_bounds__(256) void k_stem_mfma(const float *__restrict__ X, 
 // Every stage keeps the operation order of the kernel it replaces (the resampling is integer arithmetic; the MFMA
 // sequences, the tap order of the depthwise sum and the two-way k split of block 1's project are the same), so the
 // result is bit-identical to the three-kernel path.
-// Measured on MI355X, 32 frames (6656 workgroups, three per CU): 116 us against 160 for the three kernels.  The first
-// form took 154: a tile's time was mostly round trips to memory in series (table look-ups for the patch bounds, then
-// the source bytes, then per-row coefficient loads inside the vertical pass, 17 weight float4 per thread).  Now the patch
-// bounds arrive with the kernel arguments, every global load of the workgroup is issued before the first wait (the
-// source patch as aligned 32-bit words, the weights as one or two float4 per thread parked in LDS until their phase),
-// and the passes read coefficients from registers / LDS.  What is left (skipping one phase at a time): features.0 29 us
-// (six 32-pixel tiles on four waves), vertical pass 17, depthwise 14, project 14 (16 of the 32 MFMA columns are padding),
-// horizontal pass 10, source words 6, workgroup start-up 23.  A persistent variant (one workgroup walking a run of
-// tiles with the next tile's loads in flight) was slower (143 us): fewer independent workgroups hide less.
+// Measured on MI355X, 32 frames (6656 workgroups): 116 us with three workgroups per CU (rounds 2-3), 100 us with four
+// (round 4: the LDS layout below), against 160 for the three kernels.  The first form took 154: a tile's time was mostly
+// round trips to memory in series (table look-ups for the patch bounds, then the source bytes, then per-row coefficient loads
+// inside the vertical pass, 17 weight float4 per thread).  Now the patch bounds arrive with the kernel arguments, the source
+// patch (aligned 32-bit words), coefficients and LUT are requested before the first wait, each layer's weights one phase
+// before their use, and the passes read coefficients from registers / LDS.  Phase shares of the three-per-CU form (skipping
+// one phase at a time): features.0 29 us (six 32-pixel tiles on four waves), vertical pass 17, depthwise 14, project 14 (16 of
+// the 32 MFMA columns are padding), horizontal pass 10, source words 6, workgroup start-up 23.  A persistent variant (one
+// workgroup walking a run of tiles with the next tile's loads in flight) was slower (143 us): fewer independent workgroups
+// hide less.
 // --------------------------------------------------------------------------------------
 #define FR_TH 8
 #define FR_TW 16
@@ -384,8 +385,6 @@ __global__ __launch_bounds__(256) void k_stem_mfma(const float *__restrict__ X, 
 #define FR_PC (2 * FR_HW + 1)       // 37 input columns
 #define FR_PRS 112                  // floats (bytes for the u8 intermediate) per patch row: 37 x 3 = 111
 #define FR_ES 36                    // floats per pixel of S / D (32 channels + 4: conflict-free float4 rows)
-#define FR_D_BYTES (FR_TH * FR_TW * FR_ES * 4)
-#define FR_S_BYTES ((FR_NPX * FR_ES + 48 * FR_ES + 9 * 32) * 4)      // S + the weights of the three layers
 
 #define FR_MAXT 32                  // tiles per frame side (NH, NW <= 416: at most 26 x 13)
 
@@ -401,7 +400,6 @@ struct FrontArgs {
     float *Y;                       // [n][OH][OW][16]
     float *in_dbg;                  // optional: the normalised network input [n][NH][NW][3] (debug tap)
     int nr_cap, nc_cap;             // source rows / columns a tile needs at most
-    int region_a;                   // bytes of the resampling arrays (>= FR_D_BYTES: D lies over them)
     // first source row / column and their number, per tile row / tile column (in the kernel arguments: the first
     // global loads of a workgroup then depend on nothing but its block index)
     short row_lo[FR_MAXT], row_n[FR_MAXT], col_lo[FR_MAXT], col_n[FR_MAXT];
@@ -412,13 +410,16 @@ __host__ __device__ static inline int front_src_stride(int nc_cap) { return ((nc
 __host__ __device__ static inline int front_in_offset(int nr_cap, int nc_cap) {
     return (nr_cap * (front_src_stride(nc_cap) + FR_PRS) + 15) & ~15;
 }
-// bytes of the resampling arrays (source patch, horizontal-pass rows, input patch, vertical coefficient rows, LUT)
-static inline int front_region_a(int nr_cap, int nc_cap) {
-    const int a = front_in_offset(nr_cap, nc_cap) + (FR_PR * FR_PRS + FR_PR * 8 + 24 + 768) * 4;
-    return (std::max(a, (int)FR_D_BYTES) + 15) & ~15;
-}
+// LDS (round 4): 35 KB and <= 128 registers = FOUR workgroups per CU (rounds 2-3: 52 KB, three).  [input patch 9.4 KB][S 25.9 KB]:
+// the source patch, the horizontal-pass rows, the vertical coefficients and the LUT are dead when features.0 starts writing S,
+// so they live INSIDE S's array; D is written over S behind a barrier (the depthwise outputs wait in registers); the three
+// layers' weights are not parked in LDS but requested from L2 one phase before their use.
+#define FR_IN_BYTES (FR_PR * FR_PRS * 4)
+#define FR_SONLY_BYTES (FR_NPX * FR_ES * 4)
+static inline int front_small_bytes(int nr_cap, int nc_cap) { return front_in_offset(nr_cap, nc_cap) + (FR_PR * 8 + 24 + 768) * 4; }
+static inline int front_lds_bytes() { return FR_IN_BYTES + FR_SONLY_BYTES; }
 
-__global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_front(const FrontArgs A) {       // <= 128 registers: four workgroups per CU
     extern __shared__ uint8_t sm_fr[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     int bid = blockIdx.x;
@@ -427,23 +428,15 @@ __global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
     const int ty = bid % A.tiles_y, f = bid / A.tiles_y;
     const int oy0 = ty * FR_TH, ox0 = tx * FR_TW, py0 = 2 * oy0 - 3, px0 = 2 * ox0 - 3;
     const int srs = front_src_stride(A.nc_cap);
-    uint8_t *src_s = sm_fr;                                     // [nr_cap][srs]      source patch (rows start at an aligned word)
+    float *IN_s = (float *)sm_fr;                               // [FR_PR][FR_PRS]  normalised input patch, 0 outside the image
+    float *S = (float *)(sm_fr + FR_IN_BYTES);                  // [180][FR_ES]
+    uint8_t *src_s = (uint8_t *)S;                              // [nr_cap][srs]      source patch (rows start at an aligned word): inside S's array, like the next four
     uint8_t *tile_s = src_s + A.nr_cap * srs;                   // [nr_cap][FR_PRS]   after the horizontal pass
-    float *IN_s = (float *)(sm_fr + front_in_offset(A.nr_cap, A.nc_cap));   // [FR_PR][FR_PRS]  normalised input patch, 0 outside the image
-    int *vk_s = (int *)(IN_s + FR_PR * FR_PRS);                 // [FR_PR][8]         vertical coefficient rows
+    int *vk_s = (int *)(src_s + front_in_offset(A.nr_cap, A.nc_cap));   // [FR_PR][8]  vertical coefficient rows
     int *vb_s = vk_s + FR_PR * 8;                               // [FR_PR]            first source row of every patch row
     float *lut_s = (float *)(vb_s + 24);                        // [768]
-    float *D = (float *)sm_fr;                                  // [128][FR_ES]  over the arrays above once they are dead
-    float *S = (float *)(sm_fr + A.region_a);                   // [180][FR_ES]
-    // 1. every global load of the workgroup is requested here, before anything waits: the weights of the three layers
-    //    (one float4 or two per thread, parked in LDS until their phase), the source patch as aligned words,
-    //    coefficients, LUT
-    float *Wst_s = S + FR_NPX * FR_ES;                          // [32][FR_ES]  features.0, rows = output channels
-    float *Wp_s = Wst_s + 32 * FR_ES;                           // [16][FR_ES]  project
-    float *Wd_s = Wp_s + 16 * FR_ES;                            // [9][32]      depthwise
-    const float4 w_st = *(const float4 *)(A.Wstem + tid * 4);
-    const float4 w_p = tid < 128 ? *(const float4 *)(A.Wp + tid * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 w_d = tid < 72 ? *(const float4 *)(A.Wd + tid * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float *D = S;                                               // [128][FR_ES]  over S once every depthwise tap has been read
+    // 1. the source patch (aligned words), coefficients and LUT are requested here, before anything waits
     const int c4 = tid & 7;
     const int ya = max(py0, 0), yb = min(py0 + FR_PR, A.NH), xa = max(px0, 0), xb = min(px0 + FR_PC, A.NW);
     const int r_lo = A.row_lo[ty], nr = A.row_n[ty], c_lo = A.col_lo[tx], nc3 = A.col_n[tx] * 3, ncol3 = (xb - xa) * 3;
@@ -478,9 +471,6 @@ __global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) lv[i] = A.lut[tid + 256 * i];
     for (int i = tid; i < FR_PR * FR_PRS / 4; i += 256) ((float4 *)IN_s)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    *(float4 *)(Wst_s + (tid >> 3) * FR_ES + (tid & 7) * 4) = w_st;
-    if (tid < 128) *(float4 *)(Wp_s + (tid >> 3) * FR_ES + (tid & 7) * 4) = w_p;
-    if (tid < 72) *(float4 *)(Wd_s + tid * 4) = w_d;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int row = srow + 8 * it;
@@ -503,6 +493,9 @@ __global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
             tile_s[row * FR_PRS + pcol] = (uint8_t)min(max(acc >> LZ_PREC, 0), 255);
         }
     }
+    float4 wv[4];                                               // features.0 weights of this lane's output channel: requested two phases ahead
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wv[q] = *(const float4 *)(A.Wstem + r * 32 + 8 * q + 4 * hh);
     __syncthreads();
     // 3. vertical pass + normalisation LUT
     if (col_ok) {
@@ -522,9 +515,9 @@ __global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
     }
     __syncthreads();
     // 4. features.0 on the 180 halo pixels (k_stem_mfma's operand roles and tap order); zero outside the image
-    float4 wv[4];
+    float4 wd[9];                                               // depthwise weights: requested now, used behind the MFMA phase
 #pragma unroll
-    for (int q = 0; q < 4; ++q) wv[q] = *(const float4 *)(Wst_s + r * FR_ES + 8 * q + 4 * hh);
+    for (int t = 0; t < 9; ++t) wd[t] = *(const float4 *)(A.Wd + t * 32 + c4 * 4);
     for (int t = wave; t < (FR_NPX + 31) / 32; t += 4) {
         const int hp = t * 32 + r, hq = min(hp, FR_NPX - 1);
         const int hy = hq / FR_HW, hx = hq - hy * FR_HW;
@@ -566,11 +559,11 @@ __global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
     __syncthreads();
     // 5. depthwise 3x3 + bias + ReLU6 (k_irb's tap order): thread = channels 4 c4 .. + 3 of four adjacent pixels of a row,
     //    from six columns per halo row (18 LDS reads for four outputs instead of 36: the phase is bound by LDS bandwidth)
+    float4 wq[4];                                               // project weights: requested now, used behind the depthwise phase
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wq[q] = r < 16 ? *(const float4 *)(A.Wp + r * 32 + 8 * q + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
     {
         const float4 b = *(const float4 *)(A.bd + c4 * 4);
-        float4 wd[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wd[t] = *(const float4 *)(Wd_s + t * 32 + c4 * 4);
         const int oy = tid >> 5, ox = ((tid >> 3) & 3) * 4;
         float4 a4[4];
 #pragma unroll
@@ -588,6 +581,7 @@ __global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
                 for (int i = 0; i < 4; ++i) fma4(a4[i], xv[i + kx], w);
             }
         }
+        __syncthreads();                                        // D lies over S: every tap has been read
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float4 o;
@@ -602,9 +596,6 @@ __global__ __launch_bounds__(256) void k_front(const FrontArgs A) {
     // 6. project 32 -> 16: wave = pixels 32 wave .. + 31; k = 0..15 and 16..31 accumulate apart and are added afterwards,
     //    like the two k-split partials of k_irb on this block
     {
-        float4 wq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) wq[q] = r < 16 ? *(const float4 *)(Wp_s + r * FR_ES + 8 * q + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
         f32x16 a0, a1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
@@ -1560,7 +1551,7 @@ static int build_plan(SvcHandle *h, int height, int width, int nb) {
         p->fr_nc = std::max(p->fr_nc, (int)p->fr_col_n[t]);
     }
     p->fr_ok = p->fr_ok && p->fr_nr <= 32 && front_src_stride(p->fr_nc) <= 128 &&
-               front_region_a(p->fr_nr, p->fr_nc) + FR_S_BYTES <= 64 * 1024;
+               front_small_bytes(p->fr_nr, p->fr_nc) <= FR_SONLY_BYTES;
     if ((rc = p->hb.ensure(hb.size() * 4)) || (rc = p->hk.ensure(hk.size() * 4)) || (rc = p->vb.ensure(vb.size() * 4)) ||
         (rc = p->vk.ensure(vk.size() * 4)))
         return rc;
@@ -2940,7 +2931,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     auto next = [&]() -> const SvcLayer & { return h->layers[li++]; };
     float *IN = p->buf(B_IN), *P[2] = {p->buf(B_P0), p->buf(B_P1)}, *E0 = p->buf(B_E0), *E1 = p->buf(B_E1);
     // the front of the network (LANCZOS, features.0, features.1) as one kernel where a tile's resampling arrays fit in LDS
-    const int fr_lds = front_region_a(p->fr_nr, p->fr_nc) + FR_S_BYTES;
+    const int fr_lds = front_lds_bytes();
     const bool front = h->front && h->stem_mfma && !h->stem_fused && h->fuse_max >= 1 && p->fr_ok;
     p->last_front = front;
     h->seg_cur = 0;
@@ -3000,7 +2991,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
                 A.Wstem = (const float *)h->stem_wt.p; A.bstem = Lstem.b.dev;
                 A.Wd = Ld.w.dev; A.bd = Ld.b.dev; A.Wp = Lp.w.dev; A.bp = Lp.b.dev;
                 A.Y = y; A.in_dbg = h->keep_input ? IN : nullptr;
-                A.nr_cap = p->fr_nr; A.nc_cap = p->fr_nc; A.region_a = front_region_a(p->fr_nr, p->fr_nc);
+                A.nr_cap = p->fr_nr; A.nc_cap = p->fr_nc;
                 for (int i = 0; i < FR_MAXT; ++i) {
                     A.row_lo[i] = p->fr_row_lo[i]; A.row_n[i] = p->fr_row_n[i];
                     A.col_lo[i] = p->fr_col_lo[i]; A.col_n[i] = p->fr_col_n[i];

@@ -2729,8 +2729,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRB_WAVES, 
         // instead of 36.  The sums run in the same tap order as before.
         if ((TOW & 1) == 0) {
             for (int idx = tid; idx < (NOUT / 2) * 8; idx += 256) {
-                const int pp = idx >> 3, c4 = idx & 7;
-                const int oy = pp / (TOW / 2), ox = 2 * (pp - oy * (TOW / 2));
+                // Which pixel pair a thread takes decides the LDS banks its 16-lane group touches: eight lanes read one pixel's
+                // 32 channels (32 consecutive banks), the other eight another pixel's -- conflict-free only when the two are
+                // 32 banks (mod 64) apart.  Neighbouring pairs of a row are 72 (stride 2: 144) floats apart = 8 (16) banks: a
+                // two-way conflict on most of every read.  Rows 4 apart (stride 1: 4 x 10 x 36 floats) are 32 banks apart: with
+                // them in one group SQ_LDS_BANK_CONFLICT of the stride-1 blocks halves (6.0 -> 3.2 M cycles per launch of block 3,
+                // LDS-active cycles -14 %).  (Stride 2: pairs 4 outputs apart are 32 banks apart too; measured: no change.)
+                const int c4 = idx & 7;
+                int oy, ox;
+                if (S == 1 && TOH == 8 && TOW == 8) { const int rest = idx >> 4; oy = (rest >> 2) + 4 * ((idx >> 3) & 1); ox = 2 * (rest & 3); }
+                else { const int pp = idx >> 3; oy = pp / (TOW / 2); ox = 2 * (pp - oy * (TOW / 2)); }
                 const int c = ch * 32 + c4 * 4;
                 float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;
                 if (c < Ce) {

@@ -91,11 +91,16 @@ def test_fused_threshold_entry_gives_the_bytes_of_the_two_calls(engine):
     assert torch.equal(engine.saliency(fr, threshold=0), engine.saliency(fr))
 
 
-def test_saliency_batch_and_chunk_independence(engine):
-    fr = torch.from_numpy(synth.blob_frames(40, 140, 250, seed=9)).cuda()      # 40 > default chunk of 32
+@pytest.mark.parametrize('shape', [(140, 250), (187, 250), (250, 140)])
+def test_saliency_batch_and_chunk_independence(engine, shape):
+    """A frame's map does not depend on its batch or its place in it -- also where a level's pixel count is not a multiple of
+    32, so that the 32-pixel workgroups of k_pwpw / k_pw_sk straddle frames (the 4:3 and portrait geometries)."""
+    h, w = shape
+    fr = torch.from_numpy(synth.blob_frames(40, h, w, seed=9)).cuda()           # 40 > default chunk of 32
     full = engine.saliency(fr)
     assert torch.equal(engine.saliency(fr[3:4])[0], full[3])
     assert torch.equal(engine.saliency(fr[33:40]), full[33:40])
+    assert torch.equal(engine.saliency(fr[5:18]), full[5:18])
 
 
 @pytest.mark.parametrize('knobs', [

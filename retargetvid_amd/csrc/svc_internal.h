@@ -117,6 +117,8 @@ struct SvcHandle {
     uint8_t *depth_pinned = nullptr;   // pinned staging ring for the per-map round numbers
     unsigned depth_slot = 0;
     hipEvent_t depth_ev[8] = {};       // recorded behind the upload of a slot; waited on before the slot is rewritten
+    std::map<std::tuple<const void *, int, int, int>, DevBuf> lane_w;   // split-K layers' weights in lane order (svc_net.hip: lane_weights), keyed by (matrix, row stride, K, padded N)
+    bool sk_lane = true;               // k_pw_sk reads its weights from the lane-order copy: a wave's load is 1 KB contiguous instead of 32 rows x 32 B (SVC_SK_LANE=0: from the [N][K] matrix)
     std::set<const void *> lds_attr_done;   // kernels whose dynamic-LDS limit has been raised on this handle's device
     int chunk = 32;                    // frames per network pass
     int pw_min_wg = 1024;              // k_pw narrows its column tile until the grid has this many workgroups (SVC_PW_MIN_WG)

@@ -1005,7 +1005,11 @@ __global__ __launch_bounds__(256) void k_pw16(const float *__restrict__ X, int l
 #ifndef SK_DEPTH
 #define SK_DEPTH 2     // k-steps k_pw_sk keeps in flight per wave (measured round 4: 2 / 4 / 6 -> pw class 1.442 / 1.437 / 1.476 ms: not the limiter)
 #endif
-template <int TN>
+// LW (round 4): the weights come from a LANE-ORDER copy of the matrix (lane_weights below): element ((k-step, column tile), lane)
+// = the float4 that lane feeds into the tile's four MFMAs of the step, so a wave's load is one contiguous KB (8 cache lines,
+// each used whole) instead of 32 rows x 32 B (32 lines, a quarter of each) -- the texture-address units are busy 48 % of this
+// kernel and stalled by the L1 37 % of it (profiles/r04_pmc_mem_pipes.txt).  ldw then carries the number of column tiles.
+template <int TN, bool LW = false>
 __global__ __launch_bounds__(256) void k_pw_sk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
                                                const float *__restrict__ bias, const float *__restrict__ R, int ldr,
                                                float *__restrict__ Y, int ldy, int M, int N, int Npad, int K,
@@ -1017,7 +1021,9 @@ __global__ __launch_bounds__(256) void k_pw_sk(const float *__restrict__ X, int 
     const float *xp = X + (size_t)min(m0 + r, M - 1) * ldx + 4 * hh;
     const float *wp[TN];
 #pragma unroll
-    for (int t = 0; t < TN; ++t) wp[t] = Wt + (size_t)min(n0 + t * 32 + r, Npad - 1) * ldw + 4 * hh;
+    for (int t = 0; t < TN; ++t)
+        wp[t] = LW ? Wt + ((size_t)(blockIdx.y * TN + t) * 64 + lane) * 4 : Wt + (size_t)min(n0 + t * 32 + r, Npad - 1) * ldw + 4 * hh;
+    const size_t wstep = LW ? (size_t)ldw * 256 : 8;       // floats from one k-step's float4 to the next
     f32x16 acc[TN];
 #pragma unroll
     for (int t = 0; t < TN; ++t)
@@ -1032,7 +1038,7 @@ __global__ __launch_bounds__(256) void k_pw_sk(const float *__restrict__ X, int 
 #define SK_LOAD(A_, B_, st_)                                                                     \
     {                                                                                            \
         A_ = *(const float4 *)(xp + 8 * (st_));                                                  \
-        _Pragma("unroll") for (int t = 0; t < TN; ++t) B_[t] = *(const float4 *)(wp[t] + 8 * (st_)); \
+        _Pragma("unroll") for (int t = 0; t < TN; ++t) B_[t] = *(const float4 *)(wp[t] + wstep * (st_)); \
     }
 #define SK_MFMA(A_, B_)                                                                          \
     _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                             \
@@ -1621,6 +1627,32 @@ int svc_net_release(SvcHandle *h) {
 // --------------------------------------------------------------------------------------
 static inline unsigned blocks256(size_t total) { return (unsigned)((total + 255) / 256); }
 
+// Lane-order copy of a weight matrix for k_pw_sk<.., true>: out[((st * tiles + tile) * 64 + lane)] (float4) =
+// W[tile * 32 + (lane & 31)][8 st + 4 (lane >> 5) .. + 3] -- what the lane loads in k-step st for column tile `tile`.
+__global__ void k_lane_weights(const float *__restrict__ Wt, int ldw, int nsteps, int tiles, int Npad, float4 *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)nsteps * tiles * 64) return;
+    const int lane = (int)(i & 63), tile = (int)((i >> 6) % tiles), st = (int)((i >> 6) / tiles);
+    out[i] = *(const float4 *)(Wt + (size_t)min(tile * 32 + (lane & 31), Npad - 1) * ldw + 8 * st + 4 * (lane >> 5));
+}
+
+// the copy is made on the stream of the first launch that needs it (ordered in front of that launch) and kept with the handle
+static int lane_weights(SvcHandle *h, hipStream_t s, const float *Wt, int ldw, int K, int Npad, const float **out) {
+    const auto key = std::make_tuple((const void *)Wt, ldw, K, Npad);
+    auto it = h->lane_w.find(key);
+    if (it == h->lane_w.end()) {
+        DevBuf b;
+        const int nsteps = K >> 3, tiles = Npad >> 5;
+        int rc = b.ensure((size_t)nsteps * tiles * 64 * sizeof(float4));
+        if (rc) return rc;
+        k_lane_weights<<<blocks256((size_t)nsteps * tiles * 64), 256, 0, s>>>(Wt, ldw, nsteps, tiles, Npad, (float4 *)b.p);
+        SVC_CHECK_LAUNCH();
+        it = h->lane_w.emplace(key, b).first;
+    }
+    *out = (const float *)it->second.p;
+    return SVC_OK;
+}
+
 // One pointwise layer, or a column slice of one: K of the ldw input channels of the weight rows, starting at Wt
 // (bias may be null).  ups != null adds the up-sampled low-resolution product (see UpsAdd).
 static int launch_pw_ex(SvcHandle *h, hipStream_t s, const float *X, int ldx, const float *Wt, int ldw, int K,
@@ -1673,7 +1705,13 @@ static int launch_pw_ex(SvcHandle *h, hipStream_t s, const float *X, int ldx, co
     if (!ups && h->pw_sk && K >= 256 && rb_nom * tiles <= h->pw_sk_max) {   // long K, few workgroups: split K over the four waves
         const int tn = (tiles % 2 == 0) ? 2 : 1;
         dim3 g(ceil_div(M, 32), ceil_div(tiles, tn));
-        if (tn == 2) k_pw_sk<2><<<g, 256, 0, s>>>(PW16_ARGS);
+        if (h->sk_lane && !h->use_graph && (K & 7) == 0) {         // (not under SVC_GRAPH=1: the copy is allocated on first use)
+            const float *Wl = nullptr;
+            int rc = lane_weights(h, s, Wt, ldw, K, Npad, &Wl);
+            if (rc) return rc;
+            if (tn == 2) k_pw_sk<2, true><<<g, 256, 0, s>>>(X, ldx, Wl, tiles, bias, R, ldr, Y, ldy, M, N, Npad, K, relu6v);
+            else k_pw_sk<1, true><<<g, 256, 0, s>>>(X, ldx, Wl, tiles, bias, R, ldr, Y, ldy, M, N, Npad, K, relu6v);
+        } else if (tn == 2) k_pw_sk<2><<<g, 256, 0, s>>>(PW16_ARGS);
         else k_pw_sk<1><<<g, 256, 0, s>>>(PW16_ARGS);
         SVC_CHECK_LAUNCH();
         return SVC_OK;
@@ -2012,14 +2050,17 @@ static int launch_dw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer
 // rows resident in registers (B operand; the k order of k_pwr, so the sums are bit-identical to the separate kernel), and
 // writes ReLU6(. + bias) through its transposition slab.  One launch, one prologue and one read of the block's output less per
 // block; what the launch adds is the expansion's MFMA time with every SIMD busy (blocks 8-13 at 16x26: DESIGN.md 5).
-template <int NT, int PW, int NWV, bool XE = false>     // NWV = waves per workgroup = ways of the K split (8 was measured: no gain)
-__global__ __launch_bounds__(64 * NWV) void k_dwpw(const float *__restrict__ X, int H, int W, int C,
+template <int NT, int PW, int NWV, bool XE = false>     // NWV = waves per workgroup = ways of the K split (8 was measured: no gain); two waves per SIMD: the NT = 5 instances sit at 256 registers
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_dwpw(const float *__restrict__ X, int H, int W, int C,
                                               const float *__restrict__ Wd, const float *__restrict__ bd,
                                               const float *__restrict__ Wp, const float *__restrict__ bp, int N,
                                               int Npad, const float *__restrict__ R, int ldr, float *__restrict__ Y,
                                               int ldy, int relu6, int tiles_x, int tiles_y,
                                               const float *__restrict__ We2 = nullptr, const float *__restrict__ be2 = nullptr,
-                                              int Ce2 = 0, float *__restrict__ E2 = nullptr) {
+                                              int Ce2 = 0, float *__restrict__ E2 = nullptr, int lw_tiles = 0) {
+    // lw_tiles > 0: Wp is the LANE-ORDER copy of the project weights (lane_weights: one contiguous KB per wave load instead of
+    // 32 rows x 32 B; lw_tiles = its column tiles) -- the project-weight loads were more than half of the cache lines this
+    // kernel touches
     constexpr int PH = 32 / PW;
     // one LDS block: the waves' depthwise slabs [NWV][32 x IRB_ES], then the K partials [NWV][16][64].  XE re-uses it once both are
     // dead: the finished tile over the first slabs, the expansion's per-wave transposition slabs over the rest (no LDS on top)
@@ -2054,7 +2095,10 @@ __global__ __launch_bounds__(64 * NWV) void k_dwpw(const float *__restrict__ X, 
     constexpr bool PRE = false;        // (the whole 32-deep slice in registers costs the second wave per SIMD: 22 -> 33 us at NT = 2)
     const float *wrow[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) wrow[t] = Wp + (size_t)min(n0 + t * 32 + r, Npad - 1) * C + 4 * hh;
+    for (int t = 0; t < NT; ++t)
+        wrow[t] = lw_tiles ? Wp + ((size_t)min((int)blockIdx.y * NT + t, lw_tiles - 1) * 64 + lane) * 4
+                           : Wp + (size_t)min(n0 + t * 32 + r, Npad - 1) * C + 4 * hh;
+    const size_t wstep = lw_tiles ? (size_t)lw_tiles * 256 : 8;      // floats from one k-step's float4 to the next
     for (int ch = wave; ch < nchunks; ch += NWV) {
         const int kend = min(32, C - ch * 32);
         float4 Bw[PRE ? NT : 1][4];
@@ -2063,7 +2107,7 @@ __global__ __launch_bounds__(64 * NWV) void k_dwpw(const float *__restrict__ X, 
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    Bw[PRE ? t : 0][q] = *(const float4 *)(wrow[t] + ch * 32 + min(8 * q, kend - 8));      // (a short last chunk re-reads its last k-step: unused)
+                    Bw[PRE ? t : 0][q] = *(const float4 *)(wrow[t] + wstep * (ch * 4 + min(q, (kend >> 3) - 1)));      // (a short last chunk re-reads its last k-step: unused)
         }
         const int c = ch * 32 + c4 * 4;
         const bool cok = c < C;
@@ -2139,7 +2183,7 @@ __global__ __launch_bounds__(64 * NWV) void k_dwpw(const float *__restrict__ X, 
                 const float4 a = *(const float4 *)(ap + k);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const float4 b = *(const float4 *)(wrow[t] + ch * 32 + k);
+                    const float4 b = *(const float4 *)(wrow[t] + wstep * (ch * 4 + (k >> 3)));
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc[t], 0, 0, 0);
@@ -2149,7 +2193,7 @@ __global__ __launch_bounds__(64 * NWV) void k_dwpw(const float *__restrict__ X, 
         } else {
             float4 nb[NT];                                  // the next k-step's weights, requested before this step's MFMAs
 #pragma unroll
-            for (int t = 0; t < NT; ++t) nb[t] = *(const float4 *)(wrow[t] + ch * 32);
+            for (int t = 0; t < NT; ++t) nb[t] = *(const float4 *)(wrow[t] + wstep * (ch * 4));
             for (int k = 0; k < kend; k += 8) {
                 const float4 a = *(const float4 *)(ap + k);
                 float4 b[NT];
@@ -2157,7 +2201,7 @@ __global__ __launch_bounds__(64 * NWV) void k_dwpw(const float *__restrict__ X, 
                 for (int t = 0; t < NT; ++t) b[t] = nb[t];
                 if (k + 8 < kend) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) nb[t] = *(const float4 *)(wrow[t] + ch * 32 + k + 8);
+                    for (int t = 0; t < NT; ++t) nb[t] = *(const float4 *)(wrow[t] + wstep * (ch * 4 + (k >> 3) + 1));
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -2279,7 +2323,8 @@ __global__ __launch_bounds__(64 * NWV) void k_dwpw(const float *__restrict__ X, 
 template <int KS1, int NT2>     // K1 = 8 KS1 input channels, N2 = 32 NT2 output channels
 __global__ __launch_bounds__(256) void k_pwpw(const float *__restrict__ X, int ldx, const float *__restrict__ W1,
                                               const float *__restrict__ b1, int Cm, const float *__restrict__ W2,
-                                              const float *__restrict__ b2, float *__restrict__ Y, int ldy, int M) {
+                                              const float *__restrict__ b2, float *__restrict__ Y, int ldy, int M, int lw) {
+    // lw: W1 / W2 are LANE-ORDER copies (lane_weights: a wave's weight load is one contiguous KB instead of 32 rows x 32 B)
     constexpr int K1 = 8 * KS1;
     __shared__ float red_pp[4][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
@@ -2295,14 +2340,15 @@ __global__ __launch_bounds__(256) void k_pwpw(const float *__restrict__ X, int l
         for (int i = 0; i < 16; ++i) acc2[t][i] = 0.f;
     const float *w2row[NT2];
 #pragma unroll
-    for (int t = 0; t < NT2; ++t) w2row[t] = W2 + (size_t)(t * 32 + r) * Cm + 4 * hh;
+    for (int t = 0; t < NT2; ++t) w2row[t] = lw ? W2 + ((size_t)t * 64 + lane) * 4 : W2 + (size_t)(t * 32 + r) * Cm + 4 * hh;
     const int nchunks = Cm >> 5;
+    const size_t step1 = lw ? (size_t)nchunks * 256 : 8, step2 = lw ? (size_t)NT2 * 256 : 8;      // floats from one k-step's float4 to the next
     for (int ch = (wave + 4 - (blockIdx.x & 3)) & 3; ch < nchunks; ch += 4) {
         // second-convolution weights of the chunk's first k-steps: requested in front of the first convolution's MFMAs
         float4 nb[NT2];
 #pragma unroll
-        for (int t = 0; t < NT2; ++t) nb[t] = *(const float4 *)(w2row[t] + ch * 32);
-        const float *w1p = W1 + (size_t)(ch * 32 + r) * K1 + 4 * hh;
+        for (int t = 0; t < NT2; ++t) nb[t] = *(const float4 *)(w2row[t] + step2 * (ch * 4));
+        const float *w1p = lw ? W1 + ((size_t)ch * 64 + lane) * 4 : W1 + (size_t)(ch * 32 + r) * K1 + 4 * hh;
         f32x16 e;
 #pragma unroll
         for (int i = 0; i < 16; ++i) e[i] = 0.f;
@@ -2310,7 +2356,7 @@ __global__ __launch_bounds__(256) void k_pwpw(const float *__restrict__ X, int l
 #pragma unroll
         for (int p = 0; p < KS1; ++p) {
             const float4 b = wn;
-            if (p + 1 < KS1) wn = *(const float4 *)(w1p + 8 * (p + 1));
+            if (p + 1 < KS1) wn = *(const float4 *)(w1p + step1 * (p + 1));
             e = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, A1[p].x, e, 0, 0, 0);      // swapped: lane = pixel (k_pwr's order)
             e = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, A1[p].y, e, 0, 0, 0);
             e = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, A1[p].z, e, 0, 0, 0);
@@ -2333,7 +2379,7 @@ __global__ __launch_bounds__(256) void k_pwpw(const float *__restrict__ X, int l
             for (int t = 0; t < NT2; ++t) b[t] = nb[t];
             if (g < 3) {
 #pragma unroll
-                for (int t = 0; t < NT2; ++t) nb[t] = *(const float4 *)(w2row[t] + ch * 32 + 8 * (g + 1));
+                for (int t = 0; t < NT2; ++t) nb[t] = *(const float4 *)(w2row[t] + step2 * (ch * 4 + g + 1));
             }
 #pragma unroll
             for (int t = 0; t < NT2; ++t) {
@@ -2381,7 +2427,15 @@ static int launch_pwpw(SvcHandle *h, hipStream_t s, const float *X, int ldx, con
     if (h->seg_off >> h->seg_cur & 1u) return SVC_OK;
     ProfScope ps(h, SVC_K_PW, s);
     const dim3 grid((unsigned)ceil_div(M, 32));
-#define PWPW_ARGS X, ldx, L1.w.dev, L1.b.dev, L1.cout, L2.w.dev, L2.b.dev, Y, ldy, M
+    const float *W1 = L1.w.dev, *W2 = L2.w.dev;
+    int lw = 0;
+    if (h->sk_lane && !h->use_graph) {
+        int rc = lane_weights(h, s, L1.w.dev, L1.cin, L1.cin, L1.cout, &W1);
+        if (!rc) rc = lane_weights(h, s, L2.w.dev, L2.cin, L2.cin, L2.cout, &W2);
+        if (rc) return rc;
+        lw = 1;
+    }
+#define PWPW_ARGS X, ldx, W1, L1.b.dev, L1.cout, W2, L2.b.dev, Y, ldy, M, lw
     if (L1.cin == 64) {
         if (L2.cout == 64) k_pwpw<8, 2><<<grid, 256, 0, s>>>(PWPW_ARGS);
         else k_pwpw<8, 4><<<grid, 256, 0, s>>>(PWPW_ARGS);
@@ -2410,6 +2464,13 @@ static int launch_dwpw(SvcHandle *h, hipStream_t s, const float *X, const SvcLay
     const int pw = (W % 8 == 0 || W > 16) ? 8 : 16;          // 8x4 patches; 16x2 on the narrow 13-wide level
     const int tx = ceil_div(W, pw), ty = ceil_div(H, 32 / pw);
     dim3 grid((unsigned)(n * tx * ty), groups);
+    const float *Wpl = Lp.w.dev;                             // the project weights: lane-order copy where the knob allows
+    int lw_tiles = 0;
+    if (h->sk_lane && !h->use_graph && !Le2 && (C & 7) == 0) {
+        int rc = lane_weights(h, s, Lp.w.dev, C, C, Npad, &Wpl);
+        if (rc) return rc;
+        lw_tiles = tiles;
+    }
     if (Le2) {                                               // + the next block's expansion (dwpw_takes_expand has said yes)
         if (nt == 2) k_dwpw<2, 8, 4, true><<<grid, 256, 0, s>>>(X, H, W, C, Ld.w.dev, Ld.b.dev, Lp.w.dev, Lp.b.dev, N, Npad, R, ldr, Y, ldy,
                                                              Lp.relu6, tx, ty, Le2->w.dev, Le2->b.dev, Le2->cout, E2);
@@ -2418,7 +2479,7 @@ static int launch_dwpw(SvcHandle *h, hipStream_t s, const float *X, const SvcLay
         SVC_CHECK_LAUNCH();
         return SVC_OK;
     }
-#define DWPW_ARGS X, H, W, C, Ld.w.dev, Ld.b.dev, Lp.w.dev, Lp.b.dev, N, Npad, R, ldr, Y, ldy, Lp.relu6, tx, ty
+#define DWPW_ARGS X, H, W, C, Ld.w.dev, Ld.b.dev, Wpl, Lp.b.dev, N, Npad, R, ldr, Y, ldy, Lp.relu6, tx, ty, nullptr, nullptr, 0, nullptr, lw_tiles
 #define DWPW_CASE(NTv)                                                                    \
     case NTv:                                                                             \
         if (pw == 8) k_dwpw<NTv, 8, 4><<<grid, 256, 0, s>>>(DWPW_ARGS);                   \
@@ -3366,6 +3427,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->dwpw_min_px = atoi(env);
     env = getenv("SVC_DWPWX");
     if (env) h->dwpwx = atoi(env) != 0;
+    env = getenv("SVC_SK_LANE");
+    if (env) h->sk_lane = atoi(env) != 0;
     env = getenv("SVC_PWPW");
     if (env) h->pwpw = atoi(env) != 0;
     env = getenv("SVC_SEG_OFF");
@@ -3521,6 +3584,7 @@ extern "C" int svc_destroy(SvcHandle *h) {
     h->tail_offsets.release();
     h->tail_ring_cnt.release();
     h->cgb_part.release();
+    for (auto &kv : h->lane_w) kv.second.release();
     for (auto &kv : h->tail_delta) kv.second.release();
     h->stem_wt.release();
     h->shot_blob.release();

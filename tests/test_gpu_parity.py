@@ -124,6 +124,7 @@ def test_saliency_batch_and_chunk_independence(engine, shape):
     {'SVC_FRONT': '0'},                                     # LANCZOS, features.0 and features.1 as three kernels instead of k_front
     {'SVC_CHUNK': '5'},                                     # ragged chunks of the batch
     {'SVC_DWPWX': '1'},                                     # the next block's expansion inside k_dwpw's launch instead of its own k_pwr launch
+    {'SVC_SK_LANE': '0'},                                   # split-K layers read the [N][K] weight matrix instead of its lane-order copy
     {'SVC_PWPW': '0'},                                      # the skip branches' two 1x1 convolutions as two launches instead of k_pwpw
     {'SVC_CGB': '1'},                                       # 8x13-level blocks as k_cgb (expansion in LDS, channel groups; DESIGN 5, not adopted)
 ])

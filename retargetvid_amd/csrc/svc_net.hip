@@ -2324,7 +2324,7 @@ template <int KS1, int NT2>     // K1 = 8 KS1 input channels, N2 = 32 NT2 output
 __global__ __launch_bounds__(256) void k_pwpw(const float *__restrict__ X, int ldx, const float *__restrict__ W1,
                                               const float *__restrict__ b1, int Cm, const float *__restrict__ W2,
                                               const float *__restrict__ b2, float *__restrict__ Y, int ldy, int M, int lw) {
-    // lw: W1 / W2 are LANE-ORDER copies (lane_weights: a wave's weight load is one contiguous KB instead of 32 rows x 32 B)
+    // lw: W2 is a LANE-ORDER copy (lane_weights: a wave's weight load is one contiguous KB instead of 32 rows x 32 B)
     constexpr int K1 = 8 * KS1;
     __shared__ float red_pp[4][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
@@ -2342,13 +2342,13 @@ __global__ __launch_bounds__(256) void k_pwpw(const float *__restrict__ X, int l
 #pragma unroll
     for (int t = 0; t < NT2; ++t) w2row[t] = lw ? W2 + ((size_t)t * 64 + lane) * 4 : W2 + (size_t)(t * 32 + r) * Cm + 4 * hh;
     const int nchunks = Cm >> 5;
-    const size_t step1 = lw ? (size_t)nchunks * 256 : 8, step2 = lw ? (size_t)NT2 * 256 : 8;      // floats from one k-step's float4 to the next
+    const size_t step2 = lw ? (size_t)NT2 * 256 : 8;       // floats from one k-step's float4 to the next
     for (int ch = (wave + 4 - (blockIdx.x & 3)) & 3; ch < nchunks; ch += 4) {
         // second-convolution weights of the chunk's first k-steps: requested in front of the first convolution's MFMAs
         float4 nb[NT2];
 #pragma unroll
         for (int t = 0; t < NT2; ++t) nb[t] = *(const float4 *)(w2row[t] + step2 * (ch * 4));
-        const float *w1p = lw ? W1 + ((size_t)ch * 64 + lane) * 4 : W1 + (size_t)(ch * 32 + r) * K1 + 4 * hh;
+        const float *w1p = W1 + (size_t)(ch * 32 + r) * K1 + 4 * hh;
         f32x16 e;
 #pragma unroll
         for (int i = 0; i < 16; ++i) e[i] = 0.f;
@@ -2356,7 +2356,7 @@ __global__ __launch_bounds__(256) void k_pwpw(const float *__restrict__ X, int l
 #pragma unroll
         for (int p = 0; p < KS1; ++p) {
             const float4 b = wn;
-            if (p + 1 < KS1) wn = *(const float4 *)(w1p + step1 * (p + 1));
+            if (p + 1 < KS1) wn = *(const float4 *)(w1p + 8 * (p + 1));
             e = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, A1[p].x, e, 0, 0, 0);      // swapped: lane = pixel (k_pwr's order)
             e = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, A1[p].y, e, 0, 0, 0);
             e = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, A1[p].z, e, 0, 0, 0);
@@ -2430,8 +2430,9 @@ static int launch_pwpw(SvcHandle *h, hipStream_t s, const float *X, int ldx, con
     const float *W1 = L1.w.dev, *W2 = L2.w.dev;
     int lw = 0;
     if (h->sk_lane && !h->use_graph) {
-        int rc = lane_weights(h, s, L1.w.dev, L1.cin, L1.cin, L1.cout, &W1);
-        if (!rc) rc = lane_weights(h, s, L2.w.dev, L2.cin, L2.cin, L2.cout, &W2);
+        // (the SECOND matrix only: the first one's loads run one step ahead of their MFMAs, and in [Cm][K1] order three of
+        // four hit the line the one before them fetched -- in lane order every one is an L2 round trip: 44 -> 57 us at K1 = 160)
+        int rc = lane_weights(h, s, L2.w.dev, L2.cin, L2.cin, L2.cout, &W2);
         if (rc) return rc;
         lw = 1;
     }

@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(256) void k_pw16(const float *__restrict__ X, int l
 // order (deterministic), every wave finishing four of the sixteen accumulator rows.
 // --------------------------------------------------------------------------------------
 #ifndef SK_DEPTH
-#define SK_DEPTH 2     // k-steps k_pw_sk keeps in flight per wave (measured round 4: 2 / 4 / 6 -> pw class 1.442 / 1.437 / 1.476 ms: not the limiter)
+#define SK_DEPTH 2     // k-steps k_pw_sk keeps in flight per wave (round 4, [N][K] weights: 2 / 4 / 6 -> pw class 1.442 / 1.437 / 1.476 ms; lane-order weights: 2 / 3 / 4 -> the pass 1.383 / 1.385 / 1.388 ms alone, 1.020 / 1.026 / 1.028 shared)
 #endif
 // LW (round 4): the weights come from a LANE-ORDER copy of the matrix (lane_weights below): element ((k-step, column tile), lane)
 // = the float4 that lane feeds into the tile's four MFMAs of the step, so a wave's load is one contiguous KB (8 cache lines,

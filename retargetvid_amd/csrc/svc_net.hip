@@ -836,11 +836,20 @@ __global__ __launch_bounds__(256) void k_pwr(const float *__restrict__ X, int ld
     const int m0 = blockIdx.x * 128 + wave * 32;
     const int n0 = blockIdx.y * (32 * ntw);
     const int ncols = min(32 * ntw, Npad - n0);            // multiple of 32, at most 128
-    // activations of this lane's pixel: every k-step in flight at once
-    const float *xp = X + (size_t)min(m0 + r, M - 1) * ldx + 4 * hh;
-    float4 A[KS];
+    // activations of the wave's 32 pixels: every load in flight at once -- requested in WHOLE LINES (round 4: eight lanes per
+    // row and 128-byte block, 8 cache lines per load; a lane asking for its own MFMA operands touches 32 lines per load, a
+    // quarter of each, and these loads were three quarters of the lines the kernel touches) and handed to the MFMA layout
+    // (a lane = one pixel, k = 8p + 4hh ..) through the wave's epilogue slab, once, behind the weight staging
+    constexpr int NB = KS / 4;                              // blocks of 32 input channels (K is 64, 96, 128 or 160)
+    static_assert(KS % 4 == 0, "K must be a multiple of 32");
+    const int lrow = lane >> 3, lc4 = (lane & 7) * 4;
+    float4 G[NB][4];
 #pragma unroll
-    for (int p = 0; p < KS; ++p) A[p] = *(const float4 *)(xp + 8 * p);
+    for (int j = 0; j < 4; ++j) {
+        const float *xr = X + (size_t)min(m0 + lrow + 8 * j, M - 1) * ldx + lc4;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) G[b][j] = *(const float4 *)(xr + 32 * b);
+    }
     // weight chunk and bias chunk -> LDS (coalesced float4 rows)
     constexpr int K4 = K / 4;
     for (int i = tid; i < ncols * K4; i += 256) {
@@ -848,6 +857,18 @@ __global__ __launch_bounds__(256) void k_pwr(const float *__restrict__ X, int ld
         *(float4 *)(wch + row * WS + c4 * 4) = *(const float4 *)(Wt + (size_t)(n0 + row) * ldw + c4 * 4);
     }
     if (tid < ncols) bch[tid] = (bias && n0 + tid < N) ? bias[n0 + tid] : 0.f;
+    float4 A[KS];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(float4 *)(slab + (lrow + 8 * j) * PWR_SLAB + lc4) = G[b][j];
+        __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the slab is private to the wave
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) A[4 * b + q] = *(const float4 *)(slab + r * PWR_SLAB + 8 * q + 4 * hh);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();                    // the next block overwrites the slab
+    }
     __syncthreads();
     if (m0 >= M) return;
     // Every load of this wave has landed (the barrier above waited for the weight chunk, requested after the

@@ -395,6 +395,7 @@ struct FrontArgs {
     int hks, vks;
     const float *lut;               // [3][256]
     const float *Wstem, *bstem;     // [32 out][32 taps], [32]
+    const float *Wstem_l, *Wp_l;    // lane-order copies of Wstem and Wp (lane_weights): a wave's weight load is one contiguous KB
     const float *Wd, *bd;           // [9][32], [32]
     const float *Wp, *bp;           // [16][32], [16]
     float *Y;                       // [n][OH][OW][16]
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
     float4 wv[4];                                               // features.0 weights of this lane's output channel: requested two phases ahead
 #pragma unroll
-    for (int q = 0; q < 4; ++q) wv[q] = *(const float4 *)(A.Wstem + r * 32 + 8 * q + 4 * hh);
+    for (int q = 0; q < 4; ++q) wv[q] = *(const float4 *)(A.Wstem_l + (q * 64 + lane) * 4);
     __syncthreads();
     // 3. vertical pass + normalisation LUT
     if (col_ok) {
@@ -561,7 +562,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     //    from six columns per halo row (18 LDS reads for four outputs instead of 36: the phase is bound by LDS bandwidth)
     float4 wq[4];                                               // project weights: requested now, used behind the depthwise phase
 #pragma unroll
-    for (int q = 0; q < 4; ++q) wq[q] = r < 16 ? *(const float4 *)(A.Wp + r * 32 + 8 * q + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < 4; ++q) {
+        wq[q] = *(const float4 *)(A.Wp_l + (q * 64 + lane) * 4);
+        if (r >= 16) wq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     {
         const float4 b = *(const float4 *)(A.bd + c4 * 4);
         const int oy = tid >> 5, ox = ((tid >> 3) & 3) * 4;
@@ -1650,11 +1654,11 @@ static inline unsigned blocks256(size_t total) { return (unsigned)((total + 255)
 
 // Lane-order copy of a weight matrix for k_pw_sk<.., true>: out[((st * tiles + tile) * 64 + lane)] (float4) =
 // W[tile * 32 + (lane & 31)][8 st + 4 (lane >> 5) .. + 3] -- what the lane loads in k-step st for column tile `tile`.
-__global__ void k_lane_weights(const float *__restrict__ Wt, int ldw, int nsteps, int tiles, int Npad, float4 *__restrict__ out) {
+__global__ void k_lane_weights(const float *__restrict__ Wt, int ldw, int nsteps, int tiles, int nrows, float4 *__restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)nsteps * tiles * 64) return;
     const int lane = (int)(i & 63), tile = (int)((i >> 6) % tiles), st = (int)((i >> 6) / tiles);
-    out[i] = *(const float4 *)(Wt + (size_t)min(tile * 32 + (lane & 31), Npad - 1) * ldw + 8 * st + 4 * (lane >> 5));
+    out[i] = *(const float4 *)(Wt + (size_t)min(tile * 32 + (lane & 31), nrows - 1) * ldw + 8 * st + 4 * (lane >> 5));     // rows beyond the matrix repeat its last one
 }
 
 // the copy is made on the stream of the first launch that needs it (ordered in front of that launch) and kept with the handle
@@ -1663,7 +1667,7 @@ static int lane_weights(SvcHandle *h, hipStream_t s, const float *Wt, int ldw, i
     auto it = h->lane_w.find(key);
     if (it == h->lane_w.end()) {
         DevBuf b;
-        const int nsteps = K >> 3, tiles = Npad >> 5;
+        const int nsteps = K >> 3, tiles = (Npad + 31) >> 5;
         int rc = b.ensure((size_t)nsteps * tiles * 64 * sizeof(float4));
         if (rc) return rc;
         k_lane_weights<<<blocks256((size_t)nsteps * tiles * 64), 256, 0, s>>>(Wt, ldw, nsteps, tiles, Npad, (float4 *)b.p);
@@ -3080,6 +3084,8 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
                 A.hb = (const int *)p->hb.p; A.hk = (const int *)p->hk.p; A.vb = (const int *)p->vb.p; A.vk = (const int *)p->vk.p;
                 A.hks = p->hks; A.vks = p->vks; A.lut = (const float *)p->lut.p;
                 A.Wstem = (const float *)h->stem_wt.p; A.bstem = Lstem.b.dev;
+                RC(lane_weights(h, s, (const float *)h->stem_wt.p, 32, 32, 32, &A.Wstem_l));
+                RC(lane_weights(h, s, Lp.w.dev, 32, 32, 16, &A.Wp_l));
                 A.Wd = Ld.w.dev; A.bd = Ld.b.dev; A.Wp = Lp.w.dev; A.bp = Lp.b.dev;
                 A.Y = y; A.in_dbg = h->keep_input ? IN : nullptr;
                 A.nr_cap = p->fr_nr; A.nc_cap = p->fr_nc;

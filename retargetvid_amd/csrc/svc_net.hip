@@ -2300,10 +2300,12 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 8))
         }
         const int tiles2 = Ce2 >> 5;
         for (int tile = wave; tile < tiles2; tile += NWV) {
-            const float *wr = We2 + (size_t)(tile * 32 + r) * K2 + 4 * hh;
+            // (lw_tiles: We2 too is a lane-order copy, [k-step][tile][lane])
+            const float *wr = lw_tiles ? We2 + ((size_t)tile * 64 + lane) * 4 : We2 + (size_t)(tile * 32 + r) * K2 + 4 * hh;
+            const size_t wst2 = lw_tiles ? (size_t)tiles2 * 256 : 8;
             float4 wv[KS2];
 #pragma unroll
-            for (int p = 0; p < KS2; ++p) wv[p] = *(const float4 *)(wr + 8 * p);
+            for (int p = 0; p < KS2; ++p) wv[p] = *(const float4 *)(wr + wst2 * p);
             f32x16 a2;
 #pragma unroll
             for (int i = 0; i < 16; ++i) a2[i] = 0.f;
@@ -2492,16 +2494,18 @@ static int launch_dwpw(SvcHandle *h, hipStream_t s, const float *X, const SvcLay
     dim3 grid((unsigned)(n * tx * ty), groups);
     const float *Wpl = Lp.w.dev;                             // the project weights: lane-order copy where the knob allows
     int lw_tiles = 0;
-    if (h->sk_lane && !h->use_graph && !Le2 && (C & 7) == 0) {
+    const float *We2l = Le2 ? Le2->w.dev : nullptr;
+    if (h->sk_lane && !h->use_graph && (C & 7) == 0) {
         int rc = lane_weights(h, s, Lp.w.dev, C, C, Npad, &Wpl);
+        if (!rc && Le2) rc = lane_weights(h, s, Le2->w.dev, Le2->cin, Le2->cin, Le2->cout, &We2l);
         if (rc) return rc;
         lw_tiles = tiles;
     }
     if (Le2) {                                               // + the next block's expansion (dwpw_takes_expand has said yes)
-        if (nt == 2) k_dwpw<2, 8, 4, true><<<grid, 256, 0, s>>>(X, H, W, C, Ld.w.dev, Ld.b.dev, Lp.w.dev, Lp.b.dev, N, Npad, R, ldr, Y, ldy,
-                                                             Lp.relu6, tx, ty, Le2->w.dev, Le2->b.dev, Le2->cout, E2);
-        else k_dwpw<3, 8, 4, true><<<grid, 256, 0, s>>>(X, H, W, C, Ld.w.dev, Ld.b.dev, Lp.w.dev, Lp.b.dev, N, Npad, R, ldr, Y, ldy,
-                                                        Lp.relu6, tx, ty, Le2->w.dev, Le2->b.dev, Le2->cout, E2);
+        if (nt == 2) k_dwpw<2, 8, 4, true><<<grid, 256, 0, s>>>(X, H, W, C, Ld.w.dev, Ld.b.dev, Wpl, Lp.b.dev, N, Npad, R, ldr, Y, ldy,
+                                                             Lp.relu6, tx, ty, We2l, Le2->b.dev, Le2->cout, E2, lw_tiles);
+        else k_dwpw<3, 8, 4, true><<<grid, 256, 0, s>>>(X, H, W, C, Ld.w.dev, Ld.b.dev, Wpl, Lp.b.dev, N, Npad, R, ldr, Y, ldy,
+                                                        Lp.relu6, tx, ty, We2l, Le2->b.dev, Le2->cout, E2, lw_tiles);
         SVC_CHECK_LAUNCH();
         return SVC_OK;
     }

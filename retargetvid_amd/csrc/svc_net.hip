@@ -1661,7 +1661,7 @@ __global__ void k_lane_weights(const float *__restrict__ Wt, int ldw, int nsteps
     out[i] = *(const float4 *)(Wt + (size_t)min(tile * 32 + (lane & 31), nrows - 1) * ldw + 8 * st + 4 * (lane >> 5));     // rows beyond the matrix repeat its last one
 }
 
-// the copy is made on the stream of the first launch that needs it (ordered in front of that launch) and kept with the handle
+// the copy is made on the stream of the first launch that needs it (ordered in front of that launch, and waited for) and kept with the handle
 static int lane_weights(SvcHandle *h, hipStream_t s, const float *Wt, int ldw, int K, int Npad, const float **out) {
     const auto key = std::make_tuple((const void *)Wt, ldw, K, Npad);
     auto it = h->lane_w.find(key);
@@ -1672,6 +1672,9 @@ static int lane_weights(SvcHandle *h, hipStream_t s, const float *Wt, int ldw, i
         if (rc) return rc;
         k_lane_weights<<<blocks256((size_t)nsteps * tiles * 64), 256, 0, s>>>(Wt, ldw, nsteps, tiles, Npad, (float4 *)b.p);
         SVC_CHECK_LAUNCH();
+        // once per matrix and handle, on the first (eager: SVC_GRAPH captures from the second sighting on) pass that needs it:
+        // finished before any other stream can be handed the copy
+        SVC_HIP(hipStreamSynchronize(s));
         it = h->lane_w.emplace(key, b).first;
     }
     *out = (const float *)it->second.p;
@@ -1730,7 +1733,7 @@ static int launch_pw_ex(SvcHandle *h, hipStream_t s, const float *X, int ldx, co
     if (!ups && h->pw_sk && K >= 256 && rb_nom * tiles <= h->pw_sk_max) {   // long K, few workgroups: split K over the four waves
         const int tn = (tiles % 2 == 0) ? 2 : 1;
         dim3 g(ceil_div(M, 32), ceil_div(tiles, tn));
-        if (h->sk_lane && !h->use_graph && (K & 7) == 0) {         // (not under SVC_GRAPH=1: the copy is allocated on first use)
+        if (h->sk_lane && (K & 7) == 0) {
             const float *Wl = nullptr;
             int rc = lane_weights(h, s, Wt, ldw, K, Npad, &Wl);
             if (rc) return rc;
@@ -2456,7 +2459,7 @@ static int launch_pwpw(SvcHandle *h, hipStream_t s, const float *X, int ldx, con
     const dim3 grid((unsigned)ceil_div(M, 32));
     const float *W1 = L1.w.dev, *W2 = L2.w.dev;
     int lw = 0;
-    if (h->sk_lane && !h->use_graph) {
+    if (h->sk_lane) {
         // (the SECOND matrix only: the first one's loads run one step ahead of their MFMAs, and in [Cm][K1] order three of
         // four hit the line the one before them fetched -- in lane order every one is an L2 round trip: 44 -> 57 us at K1 = 160)
         int rc = lane_weights(h, s, L2.w.dev, L2.cin, L2.cin, L2.cout, &W2);
@@ -2495,7 +2498,7 @@ static int launch_dwpw(SvcHandle *h, hipStream_t s, const float *X, const SvcLay
     const float *Wpl = Lp.w.dev;                             // the project weights: lane-order copy where the knob allows
     int lw_tiles = 0;
     const float *We2l = Le2 ? Le2->w.dev : nullptr;
-    if (h->sk_lane && !h->use_graph && (C & 7) == 0) {
+    if (h->sk_lane && (C & 7) == 0) {
         int rc = lane_weights(h, s, Lp.w.dev, C, C, Npad, &Wpl);
         if (!rc && Le2) rc = lane_weights(h, s, Le2->w.dev, Le2->cin, Le2->cin, Le2->cout, &We2l);
         if (rc) return rc;

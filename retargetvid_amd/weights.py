@@ -237,26 +237,28 @@ def make_reference_init_state_dict(seed=7, bn_stats=None):
     return sd
 
 
-def make_trained_like_state_dict(golden_dir):
+def make_trained_like_state_dict(golden_dir, variant=1):
     """The TRAINED-LIKE checkpoint: the reference-initialised one (seed 7, BatchNorm statistics calibrated by the reference
     model: tests/golden/unisal_golden2.npz) with its last decoder stage (skip_4x, post_upsampling_2, adaptation_salicon,
     smoothing_salicon) replaced by tensors the REFERENCE model was fitted to in the build container
     (tools/make_golden_unisal3.py -> tests/golden/unisal_golden3.npz, keys tl/<name>): peaky maps like a trained saliency
     network's -- ~440 points above the threshold, ~7 pixels per grey level next to it (the luminance-carrier checkpoint: ~45,
-    the reference-initialised one: ~500)."""
+    the reference-initialised one: ~500).  variant=2: a second fit (`tl2`, tests/golden/unisal_golden4.npz: another seed, skip_2x and
+    upsampling_2 fitted as well, narrower targets), so that the parity claims on peaky maps do not rest on one checkpoint."""
     import os
+    name = 'unisal_golden3.npz' if variant == 1 else 'unisal_golden4.npz'
     g2 = np.load(os.path.join(golden_dir, 'unisal_golden2.npz'))
-    g3 = np.load(os.path.join(golden_dir, 'unisal_golden3.npz'))
+    g3 = np.load(os.path.join(golden_dir, name))
     sd = make_reference_init_state_dict(7, {k[3:]: g2[k] for k in g2.files if k.startswith('bn/')})
     n = 0
     for k in g3.files:
         if k.startswith('tl/'):
             if k[3:] not in sd or sd[k[3:]].shape != g3[k].shape:
-                raise KeyError('unisal_golden3.npz: %s is not a tensor of the static SALICON slice' % k)
+                raise KeyError('%s: %s is not a tensor of the static SALICON slice' % (name, k))
             sd[k[3:]] = np.asarray(g3[k], np.float32)
             n += 1
     if n == 0:
-        raise KeyError('unisal_golden3.npz holds no tl/ tensors')
+        raise KeyError('%s holds no tl/ tensors' % name)
     return sd
 
 

@@ -24,9 +24,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def test_trained_like_checkpoint_windows_within_one_px_and_iou_within_1e4(golden_dir):
+@pytest.mark.parametrize('variant', [1, 2])
+def test_trained_like_checkpoint_windows_within_one_px_and_iou_within_1e4(golden_dir, variant):
     from tools import iou_parity
-    sd = weights.make_trained_like_state_dict(golden_dir)
+    sd = weights.make_trained_like_state_dict(golden_dir, variant=variant)
     eng = ops.Engine(sd)
     try:
         for best in (False, True):
@@ -43,14 +44,14 @@ def _video(n, seed, trans):
     return dict(fr=30.0, frame_count=n, w=640, h=360, frames=synth.blob_frames(n, 360, 640, seed=seed), trans_inds=trans)
 
 
-@pytest.mark.parametrize('ck', ['ri', 'tl'])
+@pytest.mark.parametrize('ck', ['ri', 'tl', 'tl2'])
 def test_oracle_tail_and_host_stages_on_the_gpus_own_maps_reproduce_its_windows(ck, golden_dir):
     """Every stage behind the saliency maps (threshold, cluster filter, blend, CLOSE, centres -- bit-exact on the device;
     empty-centre fill, focus stability, interpolation, low-pass, LOESS / Savitzky-Golay, boxes -- native host code) against
     the oracle, on the maps the GPU itself produced: identical windows, both parameter sets."""
     torch.set_num_threads(8)
-    if ck == 'tl':
-        sd = weights.make_trained_like_state_dict(golden_dir)
+    if ck in ('tl', 'tl2'):
+        sd = weights.make_trained_like_state_dict(golden_dir, variant=1 if ck == 'tl' else 2)
     else:
         g = np.load(os.path.join(golden_dir, 'unisal_golden2.npz'))
         sd = weights.make_reference_init_state_dict(7, {k[3:]: g[k] for k in g.files if k.startswith('bn/')})

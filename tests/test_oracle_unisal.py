@@ -2,6 +2,8 @@
 (tests/golden/unisal_golden.npz, made by tools/make_golden_unisal.py) and of Pillow."""
 import os
 
+import pytest
+
 import numpy as np
 import torch
 
@@ -88,20 +90,21 @@ def test_forward_matches_reference_model_without_carrier_all_geometries(golden_d
     assert np.ptp(g['u8_ri_16x9_0']) > 100
 
 
-def test_forward_matches_reference_model_on_the_trained_like_checkpoint(golden_dir):
+@pytest.mark.parametrize('variant', [1, 2])
+def test_forward_matches_reference_model_on_the_trained_like_checkpoint(golden_dir, variant):
     """tests/golden/unisal_golden3.npz (tools/make_golden_unisal3.py): the reference model with its last decoder stage FITTED
     to blob targets -- peaky maps like a trained network's -- at the three geometries, every frame."""
     from retargetvid_amd import weights
     torch.set_num_threads(4)
-    g = np.load(os.path.join(golden_dir, 'unisal_golden3.npz'))
-    sd = weights.make_trained_like_state_dict(golden_dir)
+    g = np.load(os.path.join(golden_dir, 'unisal_golden3.npz' if variant == 1 else 'unisal_golden4.npz'))
+    sd = weights.make_trained_like_state_dict(golden_dir, variant=variant)
     for gname in ('16x9', '4x3', 'port'):
         frames = g['frames_' + gname]
         h, w = frames.shape[1:3]
         taps = {}
         maps = U.saliency_u8(sd, frames, taps)
         for i in range(frames.shape[0]):
-            tag = 'tl_%s_%d' % (gname, i)
+            tag = '%s_%s_%d' % ('tl' if variant == 1 else 'tl2', gname, i)
             t = taps['frames'][i]
             lp = torch.log_softmax(t['pre'].reshape(1, -1), 1).reshape(h, w).numpy()
             assert np.abs(lp - g['logp_' + tag]).max() < 1e-4, tag               # the log-softmax spans ~40 here (a peaky map)

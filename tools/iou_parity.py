@@ -22,8 +22,8 @@ def checkpoint(kind):
         return weights.make_synthetic_state_dict(0)
     if kind == 'nc':
         return weights.make_synthetic_state_dict(3, carrier=False)
-    if kind == 'tl':                                      # trained-like: the reference model fitted to blob targets (golden3)
-        return weights.make_trained_like_state_dict(os.path.join(ROOT, 'tests', 'golden'))
+    if kind in ('tl', 'tl2'):                             # trained-like: the reference model fitted to blob targets (golden3 / golden4)
+        return weights.make_trained_like_state_dict(os.path.join(ROOT, 'tests', 'golden'), variant=1 if kind == 'tl' else 2)
     g = np.load(os.path.join(ROOT, 'tests', 'golden', 'unisal_golden2.npz'))
     return weights.make_reference_init_state_dict(7, {k[3:]: g[k] for k in g.files if k.startswith('bn/')})
 

@@ -493,7 +493,7 @@ def main():
     c3 = None
     if os.environ.get('BENCH_CONFIG3', '1') != '0' and not plain:
         try:
-            c3 = config3_job(world, rank, dist_on, dev, sd, int(os.environ.get('BENCH_CONFIG3_LANES', 8)), rccl_init_s)
+            c3 = config3_job(world, rank, dist_on, dev, sd, int(os.environ.get('BENCH_CONFIG3_LANES', 12)), rccl_init_s)
         except Exception as e:                                 # the headline line must not depend on the extra job
             c3 = dict(error=repr(e))
     if rank == 0:

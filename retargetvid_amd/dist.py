@@ -85,7 +85,7 @@ def read_boxes(path, frame_count):
     return b
 
 
-def crop_job(make_video, frame_counts, names, CP, ratios, out_dir=None, workers=8, crop_fn=None, run_name='run',
+def crop_job(make_video, frame_counts, names, CP, ratios, out_dir=None, workers=12, crop_fn=None, run_name='run',
              replace_existing=True):
     """A whole multi-video job on however many ranks there are (BASELINE config 3's shape): videos are
     sharded over the ranks by frame count, every rank crops its share (``crop_fn``, default

@@ -761,7 +761,7 @@ def smart_vid_crop_ratios(video_path, CP, ratios, engine=None, verbose=False, st
     return out
 
 
-def crop_videos(videos, CP, ratios=None, workers=8, state_dict=None, seed=0, stream_batch=0, packed=None, shot_net=None,
+def crop_videos(videos, CP, ratios=None, workers=12, state_dict=None, seed=0, stream_batch=0, packed=None, shot_net=None,
                 stats=None):
     """Many videos on one GPU.  Default (``packed``, whenever the cluster filter is on): the job-level scheduler of
     retargetvid_amd/scheduler.py -- ``workers`` lanes (engine + HIP stream), the selected frames of consecutive videos

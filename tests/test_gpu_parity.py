@@ -157,6 +157,32 @@ def test_saliency_kernel_families_agree(engine, synthetic_sd, knobs):
 
 
 @pytest.mark.parametrize('shape', [(140, 250), (187, 250), (250, 140)])
+def test_lane_order_weight_copies_are_bit_identical(engine, synthetic_sd, shape):
+    """Round 4 (default on): k_pw_sk, k_dwpw, k_pwpw and k_front read their weights from lane-order copies of the matrices (a wave's
+    load = 8 whole cache lines instead of 32 quarter-used ones).  Same values in the same order: the maps and the decoder tap equal
+    those of the [N][K] reads (SVC_SK_LANE=0) bit for bit, at the three geometries."""
+    h, w = shape
+    NH, NW = U.get_optimal_out_size((h, w))
+    fr = torch.from_numpy(synth.blob_frames(5, h, w, seed=3 * h + w)).cuda()
+    maps = engine.saliency(fr).cpu().numpy()
+    tap = engine.tap(ops.TAP_DEC, 4, (NH // 8, NW // 8, 64))
+    old = os.environ.get('SVC_SK_LANE')
+    os.environ['SVC_SK_LANE'] = '0'
+    try:
+        other = ops.Engine(synthetic_sd)
+    finally:
+        if old is None:
+            os.environ.pop('SVC_SK_LANE', None)
+        else:
+            os.environ['SVC_SK_LANE'] = old
+    try:
+        assert np.array_equal(other.saliency(fr).cpu().numpy(), maps)
+        assert np.array_equal(other.tap(ops.TAP_DEC, 4, (NH // 8, NW // 8, 64)), tap)
+    finally:
+        other.close()
+
+
+@pytest.mark.parametrize('shape', [(140, 250), (187, 250), (250, 140)])
 def test_expansion_inside_the_previous_blocks_launch_is_bit_identical(engine, synthetic_sd, shape):
     """Round 4 (SVC_DWPWX=1; off by default: it shortens a lone pass and lengthens the pipelined step): blocks 8-13
     compute the NEXT block's 1x1 expansion inside their depthwise+project launch (k_dwpw<.., XE>) with k_pwr's k order: maps and

@@ -136,16 +136,9 @@ struct SvcHandle {
     DevBuf stem_wt;                    // stem weights transposed to [32 out][32 taps, 27 used] for the MFMA stem
     int smooth_mfma = 1;               // 41x41 smoothing phases as a GEMM on the matrix cores (SVC_SMOOTH_MFMA=0: the FMA kernel)
     int stem_mfma = 1;                 // features.0 as MFMA im2col tiles (SVC_STEM_MFMA=0: the FMA kernel k_stem)
-    bool stem_fused = false;           // features.0 computed inside the kernel of backbone block 1 (SVC_STEM_FUSED=1); measured equal to k_stem + block 1 at B=32 (146 vs 151 us), 218 MB less HBM traffic per 32 frames
     bool front = true;                 // LANCZOS + features.0 + features.1 as one kernel, k_front (SVC_FRONT=0: three kernels)
-    bool use_graph = false;            // repeated passes (same buffers and size) replay a captured hipGraph (SVC_GRAPH=1)
-    std::map<std::tuple<const void *, void *, int, int, int, const void *>, hipGraphExec_t> graphs;
     bool keep_input = false;           // ... which then also writes the normalised network input for svc_debug_tap(SVC_TAP_INPUT) (SVC_KEEP_INPUT=1)
     bool dwpw = true;                  // depthwise 3x3 fused into the following 1x1 project (SVC_DWPW=0: two kernels)
-    bool dwpwx = false;                // k_dwpw also computes the NEXT block's 1x1 expansion where the tile is complete in one workgroup (SVC_DWPWX=1).
-                                       // Measured: a lone pass -47 us (pw class 1.414 -> 1.367 ms), the pipelined step +1.7 % (the expansion's MFMAs
-                                       // then run under k_dwpw's 184 registers, two workgroups per CU, where k_pwr's 40-register waves co-resided
-                                       // with other streams' kernels): off by default
     bool pwpw = true;                  // the skip branches' two 1x1 convolutions (ReLU6 between) as one launch, k_pwpw: the intermediate tensor stays in registers (SVC_PWPW=0: two launches)
     unsigned seg_off = 0;              // MEASUREMENT AID (SVC_SEG_OFF=bitmask): stages of the network pass whose launches are skipped -- the maps are then garbage; tools/time_segments.py prices a stage by leaving it out.  Stages: 0 front, 1 blocks 2-3, 2 blocks 4-7, 3 blocks 8-14, 4 blocks 15-17, 5 features.18 + skips + post_cnn, 6 upsampling block 1, 7 upsampling block 2, 8 adaptation / smoothing / quantisation
     int seg_cur = 0;                   // stage forward_chunk is in
@@ -153,8 +146,6 @@ struct SvcHandle {
     int dwpw_min_px = 400;             // ... on levels with at least this many pixels per frame; the 8x13 level has too few patches (SVC_DWPW_MIN_PX)
     int dw_tile = 42;                  // stride-1 depthwise: outputs per thread as TX*10+TY (SVC_DW_TILE: 21, 22, 41, 42, 44; 0 = one output per thread)
     int prim_pt = 2;                   // legacy Prim (k_prim_pt): smallest points-per-thread variant (SVC_PRIM_PT: 2, 4, 8, 16)
-    bool cgb = false;                  // 8x13-level inverted-residual blocks as k_cgb (channel-group fused block; SVC_CGB=1: round-3 experiment)
-    DevBuf cgb_part;                   // ... its per-group partial sums
     int tail_prio = 0;                 // SVC_TAIL_PRIO=1: s_setprio 3 in k_tail_front / k_tail_back (measured: no effect on the pipelined bench or config 3)
     int tail_merge = 1;                // a round's kernels as two fused launches, k_tail_front / k_tail_back (SVC_TAIL_MERGE=0: one launch per stage, for per-kernel profiles)
     int tree_par = 1;                  // data-parallel hierarchy k_tree_par for maps of up to 4352 points (SVC_TREE_PAR=0: the serial builder k_tree)

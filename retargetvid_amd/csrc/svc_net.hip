@@ -1640,8 +1640,6 @@ int svc_net_release(SvcHandle *h) {
         delete p;
         h->plan = nullptr;
     }
-    for (auto &kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
-    h->graphs.clear();
     for (auto &kv : h->cvtabs) kv.second.release();
     h->cvtabs.clear();
     return SVC_OK;
@@ -1672,7 +1670,7 @@ static int lane_weights(SvcHandle *h, hipStream_t s, const float *Wt, int ldw, i
         if (rc) return rc;
         k_lane_weights<<<blocks256((size_t)nsteps * tiles * 64), 256, 0, s>>>(Wt, ldw, nsteps, tiles, Npad, (float4 *)b.p);
         SVC_CHECK_LAUNCH();
-        // once per matrix and handle, on the first (eager: SVC_GRAPH captures from the second sighting on) pass that needs it:
+        // once per matrix and handle, on the first pass that needs it:
         // finished before any other stream can be handed the copy
         SVC_HIP(hipStreamSynchronize(s));
         it = h->lane_w.emplace(key, b).first;
@@ -1791,231 +1789,6 @@ static int launch_pw(SvcHandle *h, hipStream_t s, const float *X, int ldx, const
     return launch_pw_ex(h, s, X, ldx, L.w.dev, L.cin, L.cin, L.b.dev, L.relu6, L.cout, R, ldr, Y, ldy, M, n, nullptr);
 }
 
-// --------------------------------------------------------------------------------------
-// k_cgb: a whole inverted-residual block of the 8x13 level (expand -> depthwise -> project, MobileNetV2.py:26-83) with the
-// 6x expanded tensor kept on chip, parallel over CHANNEL GROUPS (round 3 experiment, SVC_CGB=1).
-// At 8x13 a frame has 104 pixels: a layer is one wave of workgroups, and the un-fused block writes and re-reads 25 MB of
-// expansion per 32 frames through three launches.  Here a workgroup = (frame, group of 128 expanded channels):
-//   1. the frame's input [px][Cin] -> LDS (rows padded to 128 pixels);
-//   2. expand: wave w = pixel tile w (32 pixels), 4 channel tiles, K = Cin, weights straight from L2; ReLU6; the
-//      128 x 128 tile is parked in LDS over the wave's own input rows;
-//   3. depthwise 3x3 + ReLU6 over the 8x13 grid for the group's channels (LDS -> LDS);
-//   4. project partial: [128 px x 128 ch] x [128 ch x Cout] -> partial sums of the block's output, written per group;
-// k_cgb_sum adds the groups' partials in group order (deterministic), the bias and the residual.
-// --------------------------------------------------------------------------------------
-#ifndef CGB_SKIP
-#define CGB_SKIP 0          // timing experiments only: bit 1 expand loop, 2 depthwise, 4 project loop left out
-#endif
-#define CGB_GC 128          // expanded channels per group
-#define CGB_XS 164          // LDS row stride (floats) of the input / expansion rows: max(Cin, 128) + 4
-#define CGB_DS 132          // LDS row stride of the depthwise output rows
-struct CgbArgs {
-    const float *X; int Cin, Cexp, Cout, H, W, n;
-    const float *We, *be, *Wd, *bd, *Wp;
-    float *part;            // [groups][n][H*W][Cout]
-};
-
-template <int NCO>          // column tiles (of 32 output channels) per project pass
-__global__ __launch_bounds__(256) void k_cgb(const CgbArgs A) {
-    extern __shared__ float sm_cgb[];
-    float *XE = sm_cgb, *D = sm_cgb + 128 * CGB_XS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-    const int g = blockIdx.x, f = blockIdx.y, npx = A.H * A.W, Cin = A.Cin;
-    const int ch0 = g * CGB_GC, nval = min(CGB_GC, A.Cexp - ch0), nct = nval >> 5;
-    // 1. input rows (pixels >= npx: zeros); a frame's rows are contiguous in memory: batches of eight float4 per thread, all
-    // loads of a batch issued before the first LDS store (one memory round trip per batch, not per element)
-    const float *xf = A.X + (size_t)f * npx * Cin;
-    const int c4n = Cin >> 2, nin = npx * c4n;
-    for (int i0 = tid; i0 < ((CGB_SKIP & 16) ? 256 : 128 * c4n); i0 += 256 * 8) {
-        float4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 256 * u;
-            v[u] = i < nin ? *(const float4 *)(xf + 4 * (size_t)i) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 256 * u;
-            if (i < 128 * c4n) {
-                const int px = i / c4n, c4 = i - px * c4n;
-                *(float4 *)(XE + px * CGB_XS + 4 * c4) = v[u];
-            }
-        }
-    }
-    __syncthreads();
-    // 2. expand: acc[ct] = W[ch0 + 32 ct + .][k] x X[32 wave + .][k]; a lane ends with 16 channels of pixel 32 wave + r
-    {
-        f32x16 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-        const float *xp = XE + (wave * 32 + r) * CGB_XS + 4 * hh;
-        const float *wp = A.We + (size_t)(ch0 + r) * Cin + 4 * hh;
-        const int nst = Cin >> 3;
-        float4 b = *(const float4 *)xp, a[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) a[t] = *(const float4 *)(wp + (size_t)min(t, nct - 1) * 32 * Cin);
-        for (int st = 0; st < ((CGB_SKIP & 1) ? 1 : nst); ++st) {
-            const float4 bc = b;
-            float4 ac[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) ac[t] = a[t];
-            const int sn = min(st + 1, nst - 1);
-            b = *(const float4 *)(xp + 8 * sn);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) a[t] = *(const float4 *)(wp + (size_t)min(t, nct - 1) * 32 * Cin + 8 * sn);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (t >= nct) continue;
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].x, bc.x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].y, bc.y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].z, bc.z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].w, bc.w, acc[t], 0, 0, 0);
-            }
-        }
-        // ReLU6(acc + bias) -> the wave's own rows of XE, now [px][128 channels of the group]
-        float *ep = XE + (wave * 32 + r) * CGB_XS;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (t >= nct) continue;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = t * 32 + 8 * q + 4 * hh;
-                const float4 bv = *(const float4 *)(A.be + ch0 + c);
-                float4 v = make_float4(acc[t][4 * q] + bv.x, acc[t][4 * q + 1] + bv.y, acc[t][4 * q + 2] + bv.z, acc[t][4 * q + 3] + bv.w);
-                v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
-                v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
-                *(float4 *)(ep + c) = v;
-            }
-        }
-    }
-    __syncthreads();
-    // 3. depthwise 3x3 pad 1 + ReLU6 (taps in the order ky, kx, out-of-image taps contribute nothing: as k_dw)
-    {
-        const int q = tid & 31, c = 4 * q;
-        if (c < nval) {
-            float4 w9[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) w9[t] = *(const float4 *)(A.Wd + (size_t)t * A.Cexp + ch0 + c);
-            const float4 bv = *(const float4 *)(A.bd + ch0 + c);
-            // every tap is read (from a clamped position) and an out-of-image tap's weight is zero: fmaf(x, 0, acc) = acc for
-            // the finite x >= 0 in here, so the sums are those of the skipping form, without branches around the LDS reads
-            for (int px = tid >> 5; px < ((CGB_SKIP & 2) ? 8 : npx); px += 8) {
-                const int oy = px / A.W, ox = px - oy * A.W;
-                float4 x[9];
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int iy = min(max(oy - 1 + ky, 0), A.H - 1), ix = min(max(ox - 1 + kx, 0), A.W - 1);
-                        x[ky * 3 + kx] = *(const float4 *)(XE + (iy * A.W + ix) * CGB_XS + c);
-                    }
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const bool in = (unsigned)(oy - 1 + ky) < (unsigned)A.H && (unsigned)(ox - 1 + kx) < (unsigned)A.W;
-                        const float4 w = w9[ky * 3 + kx], xv = x[ky * 3 + kx];
-                        acc.x = fmaf(xv.x, in ? w.x : 0.f, acc.x); acc.y = fmaf(xv.y, in ? w.y : 0.f, acc.y);
-                        acc.z = fmaf(xv.z, in ? w.z : 0.f, acc.z); acc.w = fmaf(xv.w, in ? w.w : 0.f, acc.w);
-                    }
-                acc.x = fminf(fmaxf(acc.x + bv.x, 0.f), 6.f); acc.y = fminf(fmaxf(acc.y + bv.y, 0.f), 6.f);
-                acc.z = fminf(fmaxf(acc.z + bv.z, 0.f), 6.f); acc.w = fminf(fmaxf(acc.w + bv.w, 0.f), 6.f);
-                *(float4 *)(D + px * CGB_DS + c) = acc;
-            }
-        }
-        // rows of padding pixels feed MFMA columns that are never stored; keep them finite
-        for (int i = tid; i < (128 - npx) * (CGB_GC / 4); i += 256) {
-            const int px = npx + i / (CGB_GC / 4), c4 = i % (CGB_GC / 4);
-            *(float4 *)(D + px * CGB_DS + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    __syncthreads();
-    // 4. project partial over the group's channels, NCO column tiles at a time
-    {
-        const float *dp = D + (wave * 32 + r) * CGB_DS + 4 * hh;
-        const int nst = nval >> 3, px = wave * 32 + r;
-        float *yp = A.part + (((size_t)g * A.n + f) * npx + px) * A.Cout;
-        for (int co0 = 0; co0 < A.Cout; co0 += 32 * NCO) {
-            f32x16 acc[NCO];
-#pragma unroll
-            for (int t = 0; t < NCO; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-            const float *wp = A.Wp + (size_t)(co0 + r) * A.Cexp + ch0 + 4 * hh;
-            float4 b = *(const float4 *)dp, a[NCO];
-#pragma unroll
-            for (int t = 0; t < NCO; ++t) a[t] = *(const float4 *)(wp + (size_t)t * 32 * A.Cexp);
-            for (int st = 0; st < ((CGB_SKIP & 4) ? 1 : nst); ++st) {
-                const float4 bc = b;
-                float4 ac[NCO];
-#pragma unroll
-                for (int t = 0; t < NCO; ++t) ac[t] = a[t];
-                const int sn = min(st + 1, nst - 1);
-                b = *(const float4 *)(dp + 8 * sn);
-#pragma unroll
-                for (int t = 0; t < NCO; ++t) a[t] = *(const float4 *)(wp + (size_t)t * 32 * A.Cexp + 8 * sn);
-#pragma unroll
-                for (int t = 0; t < NCO; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].x, bc.x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].y, bc.y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].z, bc.z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].w, bc.w, acc[t], 0, 0, 0);
-                }
-            }
-            if (px < ((CGB_SKIP & 8) ? 1 : npx)) {
-#pragma unroll
-                for (int t = 0; t < NCO; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *(float4 *)(yp + co0 + t * 32 + 8 * q + 4 * hh) =
-                            make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
-            }
-        }
-    }
-}
-
-// out = bias + sum over the groups (in group order) [+ residual]
-__global__ __launch_bounds__(256) void k_cgb_sum(const float *__restrict__ part, int groups, size_t per_group, const float *__restrict__ bias,
-                                                 const float *__restrict__ R, float *__restrict__ Y, int Cout) {
-    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i4 * 4 >= per_group) return;
-    const int co = (int)((i4 * 4) % (size_t)Cout);
-    float4 v = *(const float4 *)(part + i4 * 4);
-    for (int g = 1; g < groups; ++g) {
-        const float4 p = *(const float4 *)(part + (size_t)g * per_group + i4 * 4);
-        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-    }
-    const float4 b = *(const float4 *)(bias + co);
-    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-    if (R) { const float4 rv = *(const float4 *)(R + i4 * 4); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
-    *(float4 *)(Y + i4 * 4) = v;
-}
-
-static int launch_cgb(SvcHandle *h, hipStream_t s, const float *X, int n, int H, int W, int Cin, const SvcLayer &Le, const SvcLayer &Ld,
-                      const SvcLayer &Lp, const float *R, float *Y) {
-    if (h->seg_off >> h->seg_cur & 1u) return SVC_OK;
-    ProfScope ps(h, SVC_K_PW, s);
-    const int Cexp = Le.cout, Cout = Lp.cout, npx = H * W, groups = (Cexp + CGB_GC - 1) / CGB_GC;
-    const size_t per_group = (size_t)n * npx * Cout;
-    int rc = h->cgb_part.ensure((size_t)groups * per_group * sizeof(float));
-    if (rc) return rc;
-    CgbArgs A;
-    A.X = X; A.Cin = Cin; A.Cexp = Cexp; A.Cout = Cout; A.H = H; A.W = W; A.n = n;
-    A.We = Le.w.dev; A.be = Le.b.dev; A.Wd = Ld.w.dev; A.bd = Ld.b.dev; A.Wp = Lp.w.dev;
-    A.part = (float *)h->cgb_part.p;
-    const size_t lds = (size_t)(128 * CGB_XS + 128 * CGB_DS) * sizeof(float);
-    if (h->lds_attr_done.insert((const void *)k_cgb<5>).second)
-        SVC_HIP(hipFuncSetAttribute((const void *)k_cgb<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-    k_cgb<5><<<dim3((unsigned)groups, (unsigned)n), 256, lds, s>>>(A);
-    SVC_CHECK_LAUNCH();
-    k_cgb_sum<<<blocks256(per_group / 4), 256, 0, s>>>((const float *)h->cgb_part.p, groups, per_group, Lp.b.dev, R, Y, Cout);
-    SVC_CHECK_LAUNCH();
-    return SVC_OK;
-}
-
 static int launch_dw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer &L, float *Y, int n, int H, int W,
                      int stride) {
     if (h->seg_off >> h->seg_cur & 1u) return SVC_OK;
@@ -2071,31 +1844,20 @@ static int launch_dw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer
 #define IRB_STAMP(i)   // phase stamps of k_irb: defined by tools/micro/irb_phases.hip only (no code in the product)
 #endif
 
-// XE (round 4): the NEXT block's 1x1 expansion in the same launch.  The project's output tile -- 32 pixels x N = 32 NT channels,
-// complete in this workgroup (one output-channel group) -- is the whole input of the next block's expand GEMM for those
-// pixels (a 1x1 convolution: no halo), so after the K partials are summed the tile is parked in LDS (over the dead depthwise
-// slabs), every wave takes a quarter of the 6 N expansion columns with the weights straight from L2 (A operand) and the tile's
-// rows resident in registers (B operand; the k order of k_pwr, so the sums are bit-identical to the separate kernel), and
-// writes ReLU6(. + bias) through its transposition slab.  One launch, one prologue and one read of the block's output less per
-// block; what the launch adds is the expansion's MFMA time with every SIMD busy (blocks 8-13 at 16x26: DESIGN.md 5).
-template <int NT, int PW, int NWV, bool XE = false>     // NWV = waves per workgroup = ways of the K split (8 was measured: no gain); two waves per SIMD: the NT = 5 instances sit at 256 registers
+template <int NT, int PW, int NWV>     // NWV = waves per workgroup = ways of the K split (8 was measured: no gain); two waves per SIMD: the NT = 5 instances sit at 256 registers
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_dwpw(const float *__restrict__ X, int H, int W, int C,
                                               const float *__restrict__ Wd, const float *__restrict__ bd,
                                               const float *__restrict__ Wp, const float *__restrict__ bp, int N,
                                               int Npad, const float *__restrict__ R, int ldr, float *__restrict__ Y,
-                                              int ldy, int relu6, int tiles_x, int tiles_y,
-                                              const float *__restrict__ We2 = nullptr, const float *__restrict__ be2 = nullptr,
-                                              int Ce2 = 0, float *__restrict__ E2 = nullptr, int lw_tiles = 0) {
+                                              int ldy, int relu6, int tiles_x, int tiles_y, int lw_tiles) {
     // lw_tiles > 0: Wp is the LANE-ORDER copy of the project weights (lane_weights: one contiguous KB per wave load instead of
     // 32 rows x 32 B; lw_tiles = its column tiles) -- the project-weight loads were more than half of the cache lines this
     // kernel touches
     constexpr int PH = 32 / PW;
-    // one LDS block: the waves' depthwise slabs [NWV][32 x IRB_ES], then the K partials [NWV][16][64].  XE re-uses it once both are
-    // dead: the finished tile over the first slabs, the expansion's per-wave transposition slabs over the rest (no LDS on top)
+    // one LDS block: the waves' depthwise slabs [NWV][32 x IRB_ES], then the K partials [NWV][16][64]
     __shared__ float smem_dwpw[NWV * 32 * IRB_ES + NWV * 16 * 64];
     float (*Dw)[32 * IRB_ES] = (float (*)[32 * IRB_ES])smem_dwpw;
     float (*red)[16][64] = (float (*)[16][64])(smem_dwpw + NWV * 32 * IRB_ES);
-    float *xslab = smem_dwpw + (NWV * 32 * IRB_ES + NWV * 16 * 64 - NWV * 32 * PWR_SLAB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     int bid = blockIdx.x;
     const int tx = bid % tiles_x;
@@ -2257,84 +2019,24 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 8))
         if (wave >= 4) continue;                            // (8-wave form: the upper waves only contribute partials)
         const int g = wave;
         const int col = n0 + t * 32 + 8 * g + 4 * hh;
-        if (!XE && (col >= N || !live)) continue;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (col < N && live) {
-            v = make_float4(red[0][4 * g][lane], red[0][4 * g + 1][lane], red[0][4 * g + 2][lane], red[0][4 * g + 3][lane]);
+        if (col >= N || !live) continue;
+        float4 v = make_float4(red[0][4 * g][lane], red[0][4 * g + 1][lane], red[0][4 * g + 2][lane], red[0][4 * g + 3][lane]);
 #pragma unroll
-            for (int q = 1; q < NWV; ++q) {
-                v.x += red[q][4 * g][lane]; v.y += red[q][4 * g + 1][lane];
-                v.z += red[q][4 * g + 2][lane]; v.w += red[q][4 * g + 3][lane];
-            }
-            const float4 bv = *(const float4 *)(bp + col);
-            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-            if (R) {
-                const float4 rv = *(const float4 *)(R + pix * ldr + col);
-                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-            }
-            if (relu6) {
-                v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
-                v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
-            }
-            *(float4 *)(Y + pix * ldy + col) = v;
+        for (int q = 1; q < NWV; ++q) {
+            v.x += red[q][4 * g][lane]; v.y += red[q][4 * g + 1][lane];
+            v.z += red[q][4 * g + 2][lane]; v.w += red[q][4 * g + 3][lane];
         }
-        // XE: the finished tile stays on chip: [32 pixels][N + 4] over the depthwise slabs (every wave is past its chunk loop:
-        // the barrier above), zeros for pixels outside the image
-        if (XE) *(float4 *)(&Dw[0][0] + r * (NT * 32 + 4) + t * 32 + 8 * g + 4 * hh) = v;
-    }
-    if constexpr (XE) {
-        static_assert(NWV == 4, "the expansion splits its columns over four waves");
-        constexpr int K2 = NT * 32, KS2 = K2 / 8, YS = K2 + 4;
-        static_assert(32 * YS <= NWV * 32 * IRB_ES + NWV * 16 * 64 - NWV * 32 * PWR_SLAB, "the tile must end where the transposition slabs begin");
-        __syncthreads();
-        const float *yt = &Dw[0][0] + r * YS + 4 * hh;
-        float4 yb[KS2];
-#pragma unroll
-        for (int p = 0; p < KS2; ++p) yb[p] = *(const float4 *)(yt + 8 * p);
-        float *slab = xslab + wave * (32 * PWR_SLAB);
-        const int srow = lane >> 3, sc = (lane & 7) * 4;    // store role: rows srow + 8 it, channels sc .. sc + 3 of the tile
-        size_t spix[4];
-        bool slive[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = srow + 8 * it, sy = y0 + row / PW, sx = x0 + row % PW;
-            slive[it] = sy < H && sx < W;
-            spix[it] = ((size_t)f * H + min(sy, H - 1)) * W + min(sx, W - 1);
+        const float4 bv = *(const float4 *)(bp + col);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (R) {
+            const float4 rv = *(const float4 *)(R + pix * ldr + col);
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
         }
-        const int tiles2 = Ce2 >> 5;
-        for (int tile = wave; tile < tiles2; tile += NWV) {
-            // (lw_tiles: We2 too is a lane-order copy, [k-step][tile][lane])
-            const float *wr = lw_tiles ? We2 + ((size_t)tile * 64 + lane) * 4 : We2 + (size_t)(tile * 32 + r) * K2 + 4 * hh;
-            const size_t wst2 = lw_tiles ? (size_t)tiles2 * 256 : 8;
-            float4 wv[KS2];
-#pragma unroll
-            for (int p = 0; p < KS2; ++p) wv[p] = *(const float4 *)(wr + wst2 * p);
-            f32x16 a2;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) a2[i] = 0.f;
-#pragma unroll
-            for (int p = 0; p < KS2; ++p) {
-                a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[p].x, yb[p].x, a2, 0, 0, 0);       // swapped: lane = pixel (k_pwr's order)
-                a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[p].y, yb[p].y, a2, 0, 0, 0);
-                a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[p].z, yb[p].z, a2, 0, 0, 0);
-                a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[p].w, yb[p].w, a2, 0, 0, 0);
-            }
-#pragma unroll
-            for (int g2 = 0; g2 < 4; ++g2)
-                *(float4 *)(slab + r * PWR_SLAB + 8 * g2 + 4 * hh) = make_float4(a2[4 * g2], a2[4 * g2 + 1], a2[4 * g2 + 2], a2[4 * g2 + 3]);
-            __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): the slab is private to the wave
-            __builtin_amdgcn_wave_barrier();
-            const float4 bv = *(const float4 *)(be2 + tile * 32 + sc);
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                float4 v = *(const float4 *)(slab + (srow + 8 * it) * PWR_SLAB + sc);
-                if (!slive[it]) continue;
-                v.x = fminf(fmaxf(v.x + bv.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y + bv.y, 0.f), 6.f);
-                v.z = fminf(fmaxf(v.z + bv.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w + bv.w, 0.f), 6.f);
-                *(float4 *)(E2 + spix[it] * (size_t)Ce2 + tile * 32 + sc) = v;
-            }
-            __builtin_amdgcn_wave_barrier();                // the next tile overwrites the slab
+        if (relu6) {
+            v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
+            v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
         }
+        *(float4 *)(Y + pix * ldy + col) = v;
     }
 }
 
@@ -2479,14 +2181,8 @@ static int launch_pwpw(SvcHandle *h, hipStream_t s, const float *X, int ldx, con
     return SVC_OK;
 }
 
-// Can the next block's expansion ride in this block's k_dwpw launch?  (one output-channel group, N = 64 or 96, 8x4 patches)
-static bool dwpw_takes_expand(const SvcHandle *h, const SvcLayer &Lp, const SvcLayer &Le2, int W) {
-    return h->dwpwx && (Lp.cout == 64 || Lp.cout == 96) && Lp.cout / 32 <= std::min(5, h->dwpw_max_nt) && Le2.cin == Lp.cout &&
-           (Le2.cout % 32) == 0 && Le2.relu6 && !Lp.relu6 && (W % 8 == 0 || W > 16);
-}
-
 static int launch_dwpw(SvcHandle *h, hipStream_t s, const float *X, const SvcLayer &Ld, const SvcLayer &Lp, const float *R,
-                       int ldr, float *Y, int ldy, int n, int H, int W, const SvcLayer *Le2 = nullptr, float *E2 = nullptr) {
+                       int ldr, float *Y, int ldy, int n, int H, int W) {
     if (h->seg_off >> h->seg_cur & 1u) return SVC_OK;
     ProfScope ps(h, SVC_K_PW, s);
     const int C = Ld.cout, N = Lp.cout, Npad = (N + 31) / 32 * 32, tiles = Npad / 32;
@@ -2497,22 +2193,12 @@ static int launch_dwpw(SvcHandle *h, hipStream_t s, const float *X, const SvcLay
     dim3 grid((unsigned)(n * tx * ty), groups);
     const float *Wpl = Lp.w.dev;                             // the project weights: lane-order copy where the knob allows
     int lw_tiles = 0;
-    const float *We2l = Le2 ? Le2->w.dev : nullptr;
     if (h->sk_lane && (C & 7) == 0) {
         int rc = lane_weights(h, s, Lp.w.dev, C, C, Npad, &Wpl);
-        if (!rc && Le2) rc = lane_weights(h, s, Le2->w.dev, Le2->cin, Le2->cin, Le2->cout, &We2l);
         if (rc) return rc;
         lw_tiles = tiles;
     }
-    if (Le2) {                                               // + the next block's expansion (dwpw_takes_expand has said yes)
-        if (nt == 2) k_dwpw<2, 8, 4, true><<<grid, 256, 0, s>>>(X, H, W, C, Ld.w.dev, Ld.b.dev, Wpl, Lp.b.dev, N, Npad, R, ldr, Y, ldy,
-                                                             Lp.relu6, tx, ty, We2l, Le2->b.dev, Le2->cout, E2, lw_tiles);
-        else k_dwpw<3, 8, 4, true><<<grid, 256, 0, s>>>(X, H, W, C, Ld.w.dev, Ld.b.dev, Wpl, Lp.b.dev, N, Npad, R, ldr, Y, ldy,
-                                                        Lp.relu6, tx, ty, We2l, Le2->b.dev, Le2->cout, E2, lw_tiles);
-        SVC_CHECK_LAUNCH();
-        return SVC_OK;
-    }
-#define DWPW_ARGS X, H, W, C, Ld.w.dev, Ld.b.dev, Wpl, Lp.b.dev, N, Npad, R, ldr, Y, ldy, Lp.relu6, tx, ty, nullptr, nullptr, 0, nullptr, lw_tiles
+#define DWPW_ARGS X, H, W, C, Ld.w.dev, Ld.b.dev, Wpl, Lp.b.dev, N, Npad, R, ldr, Y, ldy, Lp.relu6, tx, ty, lw_tiles
 #define DWPW_CASE(NTv)                                                                    \
     case NTv:                                                                             \
         if (pw == 8) k_dwpw<NTv, 8, 4><<<grid, 256, 0, s>>>(DWPW_ARGS);                   \
@@ -2567,14 +2253,13 @@ struct IrbGeom {
 // CIN / CE / COUT > 0 fix the channel counts at compile time (the MobileNetV2 blocks this kernel serves have six
 // distinct shapes): strides, trip counts and the slice bookkeeping fold to constants, which matters because the
 // kernel is bound by instruction issue.  0 = take them from the arguments (any other shape).
-template <int S, int TOH, int TOW, bool EXPAND, bool STEM = false, int CIN = 0, int CE = 0, int COUT = 0>
+template <int S, int TOH, int TOW, bool EXPAND, int CIN = 0, int CE = 0, int COUT = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRB_WAVES, 8))) void k_irb(const float *__restrict__ X, int H, int W, int Cin_,
                                              const float *__restrict__ We, const float *__restrict__ be, int Ce_,
                                              const float *__restrict__ Wd, const float *__restrict__ bd,
                                              const float *__restrict__ Wp, const float *__restrict__ bp, int Cout_,
                                              int CoutP_, const float *__restrict__ R, float *__restrict__ Y, int ldy_,
-                                             int OH, int OW, int tiles_x, int tiles_y,
-                                             const float *__restrict__ Ws, const float *__restrict__ bs) {
+                                             int OH, int OW, int tiles_x, int tiles_y) {
     const int Cin = CIN > 0 ? CIN : Cin_, Ce = CE > 0 ? CE : Ce_, Cout = COUT > 0 ? COUT : Cout_;
     const int CoutP = COUT > 0 ? (COUT + 31) / 32 * 32 : CoutP_, ldy = COUT > 0 ? COUT : ldy_;
     using G = IrbGeom<S, TOH, TOW>;
@@ -2587,7 +2272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRB_WAVES, 
     // expand tile of the wave) instead of being staged in LDS and re-read for every chunk: no Xs array (11 - 14 KB less LDS:
     // four workgroups per CU instead of three where the rest fits in 40 KB), no prologue fill, 3 - 4 ds_read_b128 less per
     // chunk and wave.  Same values, same k order: bit-identical.
-    constexpr bool XREG = IRB_XREG && EXPAND && !STEM && CIN > 0 && CIN <= 32 && (CIN % 8) == 0;
+    constexpr bool XREG = IRB_XREG && EXPAND && CIN > 0 && CIN <= 32 && (CIN % 8) == 0;
     float *Xs = sm_irb;                                     // [NPX][XS]   (not with XREG)
     float *E = EXPAND ? Xs + (XREG ? 0 : NPX * XS) : Xs;    // [NPX][IRB_ES]   (t=1: XS == IRB_ES, E is Xs)
     float *D = E + NPX * IRB_ES;                            // [NOUT][IRB_ES]
@@ -2629,64 +2314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRB_WAVES, 
         const int k = ch * 32 + k4 * 4;
         return (q < wp_n && row < CoutP && k < Ce) ? *(const float4 *)(Wp + (size_t)row * Ce + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    if constexpr (STEM) {
-        // features.0 fused in (t = 1 block only): X is the network input [2H][2W][3]; the 3x3 stride-2 stem
-        // conv of the halo tile runs here as one 32x32x32 MFMA tile per wave (K = 27 taps, zero-padded to 32)
-        // and its ReLU6 output is what the block would otherwise have read back from memory.  Scratch lives
-        // in arrays that are not yet in use: the input patch in D, the stem weights in the Wp slice, the
-        // im2col rows in E itself (a wave overwrites only the rows its own MFMA has consumed).
-        constexpr int PR = 2 * G::IH + 1, PCW = 2 * IW + 1, PRS = 64;      // patch rows, pixel columns, row stride
-        static_assert(PCW * 3 <= PRS && PR * PRS <= NOUT * IRB_ES, "stem patch must fit the D array");
-        float *Pin = D, *Bs = Wps;
-        const int HI = 2 * H, WI = 2 * W, py0 = 2 * iy0 - 1, px0 = 2 * ix0 - 1;
-        const float *xin = X + (size_t)f * HI * WI * 3;
-        for (int idx = tid; idx < PR * PCW * 3; idx += 256) {
-            const int pr = idx / (PCW * 3), rem = idx - pr * (PCW * 3), pc = rem / 3;
-            const int y = py0 + pr, x = px0 + pc;
-            float v = 0.f;
-            if ((unsigned)y < (unsigned)HI && (unsigned)x < (unsigned)WI) v = xin[((long long)y * WI + px0) * 3 + rem];
-            Pin[pr * PRS + rem] = v;
-        }
-        for (int idx = tid; idx < 32 * 32; idx += 256) {
-            const int co = idx >> 5, k = idx & 31;
-            Bs[co * IRB_ES + k] = k < 27 ? Ws[k * 32 + co] : 0.f;
-        }
-        if (wd_mine) *(float4 *)(Wds + wd_t * 32 + wd_c4 * 4) = load_wd(0);
-        __syncthreads();
-        {   // im2col: thread = fixed tap k (column of A), pixels tid/32, tid/32 + 8, ...
-            const int k = tid & 31, t = k / 3, ci = k - 3 * t, ky = t / 3, kx = t - 3 * ky;
-            const float *src = Pin + ky * PRS + kx * 3 + ci;
-            for (int px = tid >> 5; px < NPX; px += 8) {
-                const int hy = px / IW, hx = px - hy * IW;
-                E[px * IRB_ES + k] = k < 27 ? src[hy * (2 * PRS) + hx * 6] : 0.f;
-            }
-        }
-        __syncthreads();
-        f32x16 e;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) e[i] = 0.f;
-        const float *ap = E + (wave * 32 + r) * IRB_ES + 4 * hh;
-        const float *bq = Bs + r * IRB_ES + 4 * hh;
-#pragma unroll
-        for (int k = 0; k < 32; k += 8) {
-            const float4 a = *(const float4 *)(ap + k);
-            const float4 b = *(const float4 *)(bq + k);
-            e = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, e, 0, 0, 0);
-            e = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, e, 0, 0, 0);
-            e = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, e, 0, 0, 0);
-            e = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, e, 0, 0, 0);
-        }
-        const float bv = bs[r];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int rr = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            const int hy = rr / IW, hx = rr - hy * IW;
-            if (rr < NPX) {
-                const bool in = (unsigned)(iy0 + hy) < (unsigned)H && (unsigned)(ix0 + hx) < (unsigned)W;
-                E[rr * IRB_ES + r] = in ? fminf(fmaxf(e[i] + bv, 0.f), 6.f) : 0.f;
-            }
-        }
-    } else {
+    {
         // 1. input halo and the first weight slices -> LDS (zeros outside the image)
         const float *xf = X + (size_t)f * H * W * Cin;
         if (!XREG)
@@ -2982,41 +2610,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRB_WAVES, 
 }
 
 static int launch_irb(SvcHandle *h, hipStream_t s, const float *X, int n, int H, int W, int Cin, const SvcLayer *Le,
-                      const SvcLayer &Ld, const SvcLayer &Lp, int stride, const float *R, float *Y,
-                      const SvcLayer *Lstem = nullptr) {
+                      const SvcLayer &Ld, const SvcLayer &Lp, int stride, const float *R, float *Y) {
     if (h->seg_off >> h->seg_cur & 1u) return SVC_OK;
     ProfScope ps(h, SVC_K_PW, s);
     const int Ce = Ld.cout, Cout = Lp.cout, CoutP = (Cout + 31) / 32 * 32;
     const int OH = H / stride, OW = W / stride;
-#define IRB_LAUNCH(S_, TOH_, TOW_, EXP_) IRB_LAUNCH3(S_, TOH_, TOW_, EXP_, false, 0, 0, 0)
-#define IRB_LAUNCH2(S_, TOH_, TOW_, EXP_, STEM_) IRB_LAUNCH3(S_, TOH_, TOW_, EXP_, STEM_, 0, 0, 0)
-#define IRB_LAUNCH3(S_, TOH_, TOW_, EXP_, STEM_, CI_, CE_, CO_)                                                      \
+#define IRB_LAUNCH(S_, TOH_, TOW_, EXP_) IRB_LAUNCH3(S_, TOH_, TOW_, EXP_, 0, 0, 0)
+#define IRB_LAUNCH3(S_, TOH_, TOW_, EXP_, CI_, CE_, CO_)                                                             \
     do {                                                                                                             \
         const int tx = ceil_div(OW, TOW_), ty = ceil_div(OH, TOH_);                                                  \
-        const size_t lds = IrbGeom<S_, TOH_, TOW_>::lds_floats(Cin, CoutP, EXP_, Ce, IRB_XREG && EXP_ && !(STEM_) && (CI_) > 0 && (CI_) <= 32 && ((CI_) % 8) == 0) * 4; \
-        auto kfn = k_irb<S_, TOH_, TOW_, EXP_, STEM_, CI_, CE_, CO_>;                                                \
+        const size_t lds = IrbGeom<S_, TOH_, TOW_>::lds_floats(Cin, CoutP, EXP_, Ce, IRB_XREG && EXP_ && (CI_) > 0 && (CI_) <= 32 && ((CI_) % 8) == 0) * 4; \
+        auto kfn = k_irb<S_, TOH_, TOW_, EXP_, CI_, CE_, CO_>;                                                       \
         /* tiles of the 96-channel blocks need more than the default 64 KB of dynamic LDS; the attribute is per  */  \
         /* device, so the once-flag lives in the handle (one handle = one device), not in the process            */  \
         if (h->lds_attr_done.insert((const void *)kfn).second)                                                       \
             SVC_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024)); \
         kfn<<<dim3((unsigned)(n * tx * ty)), 256, lds, s>>>(                                                          \
             X, H, W, Cin, EXP_ ? Le->w.dev : nullptr, EXP_ ? Le->b.dev : nullptr, Ce, Ld.w.dev, Ld.b.dev, Lp.w.dev,   \
-            Lp.b.dev, Cout, CoutP, R, Y, Cout, OH, OW, tx, ty, STEM_ ? Lstem->w.dev : nullptr,                       \
-            STEM_ ? Lstem->b.dev : nullptr);                                                                         \
+            Lp.b.dev, Cout, CoutP, R, Y, Cout, OH, OW, tx, ty);                                                       \
     } while (0)
     const bool fixed = h->irb_fixed;
-    if (!Le && Lstem) IRB_LAUNCH2(1, 8, 8, false, true);
-    else if (!Le && fixed && Cin == 32 && Ce == 32 && Cout == 16) IRB_LAUNCH3(1, 8, 8, false, false, 32, 32, 16);
+    if (!Le && fixed && Cin == 32 && Ce == 32 && Cout == 16) IRB_LAUNCH3(1, 8, 8, false, 32, 32, 16);
     else if (!Le) IRB_LAUNCH(1, 8, 8, false);
-    else if (stride == 2 && fixed && Cin == 16 && Ce == 96 && Cout == 24) IRB_LAUNCH3(2, 4, 8, true, false, 16, 96, 24);
-    else if (stride == 2 && fixed && Cin == 24 && Ce == 144 && Cout == 32) IRB_LAUNCH3(2, 4, 8, true, false, 24, 144, 32);
+    else if (stride == 2 && fixed && Cin == 16 && Ce == 96 && Cout == 24) IRB_LAUNCH3(2, 4, 8, true, 16, 96, 24);
+    else if (stride == 2 && fixed && Cin == 24 && Ce == 144 && Cout == 32) IRB_LAUNCH3(2, 4, 8, true, 24, 144, 32);
     else if (stride == 2) IRB_LAUNCH(2, 4, 8, true);
-    else if (fixed && Cin == 24 && Ce == 144 && Cout == 24) IRB_LAUNCH3(1, 8, 8, true, false, 24, 144, 24);
-    else if (fixed && Cin == 32 && Ce == 192 && Cout == 32) IRB_LAUNCH3(1, 8, 8, true, false, 32, 192, 32);
-    else if (fixed && Cin == 32 && Ce == 192 && Cout == 64) IRB_LAUNCH3(1, 8, 8, true, false, 32, 192, 64);
+    else if (fixed && Cin == 24 && Ce == 144 && Cout == 24) IRB_LAUNCH3(1, 8, 8, true, 24, 144, 24);
+    else if (fixed && Cin == 32 && Ce == 192 && Cout == 32) IRB_LAUNCH3(1, 8, 8, true, 32, 192, 32);
+    else if (fixed && Cin == 32 && Ce == 192 && Cout == 64) IRB_LAUNCH3(1, 8, 8, true, 32, 192, 64);
     else IRB_LAUNCH(1, 8, 8, true);
 #undef IRB_LAUNCH
-#undef IRB_LAUNCH2
 #undef IRB_LAUNCH3
     SVC_CHECK_LAUNCH();
     return SVC_OK;
@@ -3034,7 +2657,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     float *IN = p->buf(B_IN), *P[2] = {p->buf(B_P0), p->buf(B_P1)}, *E0 = p->buf(B_E0), *E1 = p->buf(B_E1);
     // the front of the network (LANCZOS, features.0, features.1) as one kernel where a tile's resampling arrays fit in LDS
     const int fr_lds = front_lds_bytes();
-    const bool front = h->front && h->stem_mfma && !h->stem_fused && h->fuse_max >= 1 && p->fr_ok;
+    const bool front = h->front && h->stem_mfma && h->fuse_max >= 1 && p->fr_ok;
     p->last_front = front;
     h->seg_cur = 0;
     auto seg_on = [&]() { return !(h->seg_off >> h->seg_cur & 1u); };   // SVC_SEG_OFF (measurement aid): see svc_internal.h
@@ -3049,10 +2672,8 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
                                              (const float *)p->lut.p, p->lz_rows, p->lz_tile_cap);
         SVC_CHECK_LAUNCH();
     }
-    // stem: on its own, or inside the kernel of backbone block 1 (which then reads the network input directly)
     const SvcLayer &Lstem = next();
-    const bool stem_fused = h->stem_fused && h->fuse_max >= 1;
-    if (!stem_fused && !front && seg_on()) {
+    if (!front && seg_on()) {
         ProfScope ps(h, SVC_K_STEM, s);
         if (h->stem_mfma) {
             const int tx = ceil_div(W, STEM_TW), ty = ceil_div(H, STEM_TH);
@@ -3065,7 +2686,6 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
         SVC_CHECK_LAUNCH();
     }
     int cur = 0;
-    const float *pre_exp = nullptr;                          // the current block's expansion, if the previous block's launch has computed it
     // backbone blocks 1..17  (MobileNetV2.py:111-136)
     static const int T[7] = {1, 6, 6, 6, 6, 6, 6}, Cc[7] = {16, 24, 32, 64, 96, 160, 320}, Nn[7] = {1, 2, 3, 4, 3, 3, 1},
                      Ss[7] = {1, 2, 2, 2, 1, 2, 1};
@@ -3106,39 +2726,17 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
                 const SvcLayer *Le = (t != 1) ? &next() : nullptr;
                 const SvcLayer &Ld = next();
                 const SvcLayer &Lp = next();
-                const bool with_stem = stem_fused && idx == 1;
-                RC(launch_irb(h, s, with_stem ? IN : x, n, H, W, inp, Le, Ld, Lp, dws, res ? x : nullptr, y,
-                              with_stem ? &Lstem : nullptr));
-            } else if (h->cgb && t != 1 && dws == 1 && !tap && H * W <= 128 && inp % 8 == 0 && inp <= 160 && (inp * t) % 64 == 0 &&
-                       oup % 160 == 0) {
-                const SvcLayer &Le = next();
-                const SvcLayer &Ld = next();
-                RC(launch_cgb(h, s, x, n, H, W, inp, Le, Ld, next(), res ? x : nullptr, y));
+                RC(launch_irb(h, s, x, n, H, W, inp, Le, Ld, Lp, dws, res ? x : nullptr, y));
             } else {
                 const float *dwin = x;
                 if (t != 1) {
-                    const SvcLayer &Le = next();
-                    if (pre_exp) dwin = pre_exp;              // the previous block's launch has computed this expansion (XE)
-                    else {
-                        RC(launch_pw(h, s, x, inp, Le, nullptr, 0, E0, inp * t, n * H * W, n));
-                        dwin = E0;
-                    }
+                    RC(launch_pw(h, s, x, inp, next(), nullptr, 0, E0, inp * t, n * H * W, n));
+                    dwin = E0;
                 }
-                pre_exp = nullptr;
                 const SvcLayer &Ld = next();
                 if (h->dwpw && dws == 1 && H * W >= h->dwpw_min_px) {
                     const SvcLayer &Lp = next();
-                    // the next block's expansion in the same launch: this block keeps its resolution and is not a tap, the next
-                    // block exists, expands, and takes this same path (un-fused, depthwise + project as k_dwpw)
-                    const SvcLayer *Le2 = nullptr;
-                    float *e2 = nullptr;
-                    if (!tap && idx + 1 <= 17 && idx + 1 > h->fuse_max && li < h->layers.size() && h->layers[li].kind == SvcLayer::PW &&
-                        dwpw_takes_expand(h, Lp, h->layers[li], W)) {
-                        Le2 = &h->layers[li];
-                        e2 = (dwin == E0) ? E1 : E0;          // not the buffer this launch reads
-                    }
-                    RC(launch_dwpw(h, s, dwin, Ld, Lp, res ? x : nullptr, oup, y, oup, n, H, W, Le2, e2));
-                    pre_exp = e2;
+                    RC(launch_dwpw(h, s, dwin, Ld, Lp, res ? x : nullptr, oup, y, oup, n, H, W));
                 } else {
                     RC(launch_dw(h, s, dwin, Ld, E1, n, H, W, dws));
                     RC(launch_pw(h, s, E1, inp * t, next(), res ? x : nullptr, oup, y, oup, n * OH * OW, n));
@@ -3304,37 +2902,6 @@ static int saliency_impl(SvcHandle *h, const uint8_t *frames, int n, int height,
         int m = std::min(h->plan->nb, n - i);
         const uint8_t *fr = frames + i * fin;
         uint8_t *mp = maps + i * fout;
-        // SVC_GRAPH=1: a pass with the same buffers, size and workspace as an earlier one replays that pass's launches as a
-        // hipGraph (captured on the second sighting: the first runs eagerly, so one-time work -- function attributes,
-        // the constant prior maps -- stays out of the graph).  Profiled passes and the null stream always launch directly.
-        if (h->use_graph && h->prof_class < 0 && s) {
-            const auto key = std::make_tuple((const void *)fr, (void *)mp, m, height * 256 + thr, width, (const void *)h->plan->ws.p);
-            auto it = h->graphs.find(key);
-            if (it != h->graphs.end() && it->second) {
-                SVC_HIP(hipGraphLaunch(it->second, s));
-                h->plan->last_n = m;
-                continue;
-            }
-            if (it != h->graphs.end()) {                    // second sighting: capture, instantiate, launch
-                hipGraph_t g = nullptr;
-                SVC_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                const int rc = forward_chunk(h, fr, m, mp, s, thr);
-                const hipError_t e = hipStreamEndCapture(s, &g);
-                if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-                SVC_HIP(e);
-                hipGraphExec_t ex = nullptr;
-                SVC_HIP(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
-                (void)hipGraphDestroy(g);
-                it->second = ex;
-                SVC_HIP(hipGraphLaunch(ex, s));
-                continue;
-            }
-            if (h->graphs.size() >= 64) {                   // a stream of ever-new buffers: stop caching
-                for (auto &kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
-                h->graphs.clear();
-            }
-            h->graphs.emplace(key, nullptr);
-        }
         RC(forward_chunk(h, fr, m, mp, s, thr));
     }
     return SVC_OK;
@@ -3448,20 +3015,14 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->smooth_mfma = atoi(env);
     env = getenv("SVC_STEM_MFMA");
     if (env) h->stem_mfma = atoi(env);
-    env = getenv("SVC_STEM_FUSED");
-    if (env) h->stem_fused = atoi(env) != 0;
     env = getenv("SVC_FRONT");
     if (env) h->front = atoi(env) != 0;
-    env = getenv("SVC_GRAPH");
-    if (env) h->use_graph = atoi(env) != 0;
     env = getenv("SVC_KEEP_INPUT");
     if (env) h->keep_input = atoi(env) != 0;
     env = getenv("SVC_DWPW");
     if (env) h->dwpw = atoi(env) != 0;
     env = getenv("SVC_DWPW_MIN_PX");
     if (env) h->dwpw_min_px = atoi(env);
-    env = getenv("SVC_DWPWX");
-    if (env) h->dwpwx = atoi(env) != 0;
     env = getenv("SVC_SK_LANE");
     if (env) h->sk_lane = atoi(env) != 0;
     env = getenv("SVC_PWPW");
@@ -3478,8 +3039,6 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env && atoi(env) > 0) h->prim_pt = atoi(env);
     env = getenv("SVC_TAIL_PRIO");
     if (env) h->tail_prio = atoi(env);
-    env = getenv("SVC_CGB");
-    if (env) h->cgb = atoi(env) != 0;
     env = getenv("SVC_TAIL_MERGE");
     if (env) h->tail_merge = atoi(env);
     env = getenv("SVC_TREE_PAR");
@@ -3618,7 +3177,6 @@ extern "C" int svc_destroy(SvcHandle *h) {
     h->tail_ws.release();
     h->tail_offsets.release();
     h->tail_ring_cnt.release();
-    h->cgb_part.release();
     for (auto &kv : h->lane_w) kv.second.release();
     for (auto &kv : h->tail_delta) kv.second.release();
     h->stem_wt.release();

@@ -119,14 +119,11 @@ def test_saliency_batch_and_chunk_independence(engine, shape):
     {'SVC_FUSE_MAX': '13'},                                 # every block that can be fused is
     {'SVC_SPLIT_UP': '0'},                                  # decoder: up-sample + concatenate + one GEMM (the reference's order)
     {'SVC_IRB_FIXED': '0'},                                 # generic (run-time shaped) fused block instead of the fixed-shape instances
-    {'SVC_STEM_MFMA': '0', 'SVC_SMOOTH_MFMA': '0'},          # features.0 and the 41x41 smoothing as FMA kernels                                 # features.0 as the FMA kernel
-    {'SVC_STEM_FUSED': '1'},                                # features.0 inside the kernel of block 1 (MFMA im2col form)
+    {'SVC_STEM_MFMA': '0', 'SVC_SMOOTH_MFMA': '0'},          # features.0 and the 41x41 smoothing as FMA kernels
     {'SVC_FRONT': '0'},                                     # LANCZOS, features.0 and features.1 as three kernels instead of k_front
     {'SVC_CHUNK': '5'},                                     # ragged chunks of the batch
-    {'SVC_DWPWX': '1'},                                     # the next block's expansion inside k_dwpw's launch instead of its own k_pwr launch
     {'SVC_SK_LANE': '0'},                                   # split-K layers read the [N][K] weight matrix instead of its lane-order copy
     {'SVC_PWPW': '0'},                                      # the skip branches' two 1x1 convolutions as two launches instead of k_pwpw
-    {'SVC_CGB': '1'},                                       # 8x13-level blocks as k_cgb (expansion in LDS, channel groups; DESIGN 5, not adopted)
 ])
 def test_saliency_kernel_families_agree(engine, synthetic_sd, knobs):
     """Every kernel family that can serve a layer (selected by shape at run time, forced here through
@@ -182,35 +179,6 @@ def test_lane_order_weight_copies_are_bit_identical(engine, synthetic_sd, shape)
         other.close()
 
 
-@pytest.mark.parametrize('shape', [(140, 250), (187, 250), (250, 140)])
-def test_expansion_inside_the_previous_blocks_launch_is_bit_identical(engine, synthetic_sd, shape):
-    """Round 4 (SVC_DWPWX=1; off by default: it shortens a lone pass and lengthens the pipelined step): blocks 8-13
-    compute the NEXT block's 1x1 expansion inside their depthwise+project launch (k_dwpw<.., XE>) with k_pwr's k order: maps and
-    taps are bit-identical to the default path (the expansion as its own launch), at the three geometries (the 4:3 and portrait
-    levels have other patch counts and ragged edges)."""
-    h, w = shape
-    NH, NW = U.get_optimal_out_size((h, w))
-    fr = torch.from_numpy(synth.blob_frames(5, h, w, seed=h + w)).cuda()
-    maps = engine.saliency(fr).cpu().numpy()
-    taps = [engine.tap(ops.TAP_FEAT2X, 4, (NH // 16, NW // 16, 160)), engine.tap(ops.TAP_DEC, 4, (NH // 8, NW // 8, 64))]
-    old = os.environ.get('SVC_DWPWX')
-    os.environ['SVC_DWPWX'] = '1'
-    try:
-        other = ops.Engine(synthetic_sd)
-    finally:
-        if old is None:
-            os.environ.pop('SVC_DWPWX', None)
-        else:
-            os.environ['SVC_DWPWX'] = old
-    try:
-        assert np.array_equal(other.saliency(fr).cpu().numpy(), maps)
-        taps0 = [other.tap(ops.TAP_FEAT2X, 4, (NH // 16, NW // 16, 160)), other.tap(ops.TAP_DEC, 4, (NH // 8, NW // 8, 64))]
-        for a, b in zip(taps, taps0):
-            assert np.array_equal(a, b)
-    finally:
-        other.close()
-
-
 @pytest.mark.parametrize('shape', [(140, 250), (187, 250), (250, 140), (360, 640), (97, 131)])
 def test_front_kernel_bit_identical_to_three_kernels(engine, synthetic_sd, shape):
     """k_front (LANCZOS + features.0 + features.1 in one kernel) keeps the operation order of the three kernels it
@@ -241,43 +209,6 @@ def test_front_kernel_bit_identical_to_three_kernels(engine, synthetic_sd, shape
     for a, b in zip(taps, taps0):
         assert np.array_equal(a, b)
     assert np.array_equal(maps, maps0)
-
-
-def test_graph_replay_matches_direct_launches(engine, synthetic_sd):
-    """SVC_GRAPH=1: the third and later passes over the same buffers replay a captured hipGraph; same maps as direct
-    launches, also after the input frames change in place and after a pass with other buffers in between."""
-    fr = torch.from_numpy(synth.blob_frames(6, 140, 250, seed=33)).cuda()
-    fr2 = torch.from_numpy(synth.blob_frames(6, 140, 250, seed=34)).cuda()
-    ref, ref2 = engine.saliency(fr), engine.saliency(fr2)
-    old = os.environ.get('SVC_GRAPH')
-    os.environ['SVC_GRAPH'] = '1'
-    try:
-        other = ops.Engine(synthetic_sd)
-    finally:
-        if old is None:
-            os.environ.pop('SVC_GRAPH', None)
-        else:
-            os.environ['SVC_GRAPH'] = old
-    try:
-        buf = fr.clone()
-        out = torch.empty((6, 140, 250), dtype=torch.uint8, device='cuda')
-        st = torch.cuda.Stream()
-        torch.cuda.synchronize()
-        with torch.cuda.stream(st):
-            for i in range(4):                               # eager, capture + launch, replay, replay
-                other.saliency(buf, out=out)
-                st.synchronize()
-                assert torch.equal(out, ref), i
-            buf.copy_(fr2)                                   # same buffers, new content: the replay must see it
-            other.saliency(buf, out=out)
-            st.synchronize()
-            assert torch.equal(out, ref2)
-            assert torch.equal(other.saliency(fr), ref)      # other buffers: a direct pass
-            other.saliency(buf, out=out)
-            st.synchronize()
-            assert torch.equal(out, ref2)
-    finally:
-        other.close()
 
 
 def test_blend_chain_carried_over_between_calls(engine, golden_dir):

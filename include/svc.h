@@ -250,6 +250,23 @@ int svc_debug_tap(SvcHandle *h, int which, int frame, float *out_host, size_t ca
  * (k_front), 0 when as three (SVC_FRONT=0, or a source size whose tiles do not fit in LDS).  bench.py uses it to
  * attribute features.1's FLOPs to the right kernel class. */
 int svc_front_fused(const SvcHandle *h);
+/* svc_matrix_pipe: which matrix pipe the handle's 1x1-convolution GEMMs (the `pw` kernel class) run on: 0 = fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32: exact f32 products, rounds 1-4), 6 = split-bf16 operands on v_mfma_f32_32x32x16_bf16 (every f32
+ * operand as three bf16 planes = its 24 significant bits, six plane pairs per product, f32 accumulation: csrc/svc_net.hip,
+ * "Split-bf16 operands").  Chosen when the handle is created (environment SVC_MX=f32 | bf16x6; default f32 -- bf16x6 is
+ * opt-in: faster and within the per-tap tolerances, but its maps were not bit-reproducible run to run with several streams
+ * sharing the chip); bench.py
+ * reports it as roofline.matrix_pipe.  No interface of the reference corresponds to it (its arithmetic type is f32 either way). */
+int svc_matrix_pipe(const SvcHandle *h);
+/* svc_threshold_census: the regime diagnostic of the threshold (no counterpart in the reference; smartVidCrop.py:1050-1059 only
+ * thresholds).  out[0] = maps that went through svc_saliency_thresholded_u8 on this handle since the last reset, out[1..3] = how
+ * many pixels of their UN-thresholded u8 maps sat at t - 1, t and t + 1 (t = the threshold passed to the call).  Two correct
+ * fp32 implementations of the network differ by one grey level on ~0.3 % of the pixels; how many pixels that moves across
+ * the threshold -- and with them points into or out of the clustering -- is this density.  Measured boundary:
+ * ~7 pixels per level and map (trained-like checkpoints) or ~45 (the carrier checkpoint): crop windows identical to the
+ * oracle's; ~500 (reference-initialised weights): 21 % of the windows differ by more than a pixel.  Synchronises the device.
+ * reset != 0 clears the counters. */
+int svc_threshold_census(SvcHandle *h, unsigned long long *out /* [4] */, int reset);
 
 #ifdef __cplusplus
 }

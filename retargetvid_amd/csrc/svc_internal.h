@@ -118,9 +118,15 @@ struct SvcHandle {
     unsigned depth_slot = 0;
     hipEvent_t depth_ev[8] = {};       // recorded behind the upload of a slot; waited on before the slot is rewritten
     std::map<std::tuple<const void *, int, int, int>, DevBuf> lane_w;   // split-K layers' weights in lane order (svc_net.hip: lane_weights), keyed by (matrix, row stride, K, padded N)
+    std::map<std::tuple<const void *, int, int, int>, DevBuf> x3_w;     // split-bf16 copies of weight matrices (svc_net.hip: x3_weights), keyed by (matrix, row stride, K, 2 * padded N + order)
+    int mx = 0;                        // matrix pipe of the 1x1-convolution GEMMs: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32: the default, rounds 1-4), 6 = split-bf16 operands, six plane pairs on v_mfma_f32_32x32x16_bf16 (SVC_MX=bf16x6: OPT-IN.  Faster -- a pass 1.42 -> 1.24 ms alone, 1.01 -> 0.87 ms with four passes sharing the chip -- and within every per-tap tolerance, but with several streams sharing the chip the maps were not bit-reproducible run to run: 1 - 6 % of the passes had 16 pixels of one kernel one grey level off, cause not found: DESIGN.md 5)
+    unsigned irb_mx = 0x1b;            // ... which of k_irb's five fixed-shape instances take that form for their expand GEMM (bit = block 2, 3, 4, 5-6, 7; SVC_IRB_MX).  Measured per instance against the fp32 form, us per pass alone / shared: -17 / -11, -12 / -7, +11 / +11 (block 4: Cin = 24 pads its second step, two halo tiles per wave: 36 spilled registers), -11 / -4, -10 / -6: block 4 stays fp32
+    unsigned mx_mask = 0xff;           // ... and which kernel families: bit 0 k_pwr, 1 k_irb, 2 k_dwpw, 3 k_pw_sk, 4 k_pwpw (SVC_MX_MASK; for A/B timing)
     bool sk_lane = true;               // k_pw_sk reads its weights from the lane-order copy: a wave's load is 1 KB contiguous instead of 32 rows x 32 B (SVC_SK_LANE=0: from the [N][K] matrix)
     std::set<const void *> lds_attr_done;   // kernels whose dynamic-LDS limit has been raised on this handle's device
     int chunk = 32;                    // frames per network pass
+    DevBuf census;                     // threshold census (svc_threshold_census): [4] u64 totals, then [chunk][4] u32 per-frame counts of the last pass
+    unsigned long long census_maps = 0;
     int pw_min_wg = 1024;              // k_pw narrows its column tile until the grid has this many workgroups (SVC_PW_MIN_WG)
     bool pw_sk = true;                 // split-K pointwise kernel for long-K small-M layers (SVC_PW_SK=0 disables)
     int pw_tr = 2;                     // k_pw with swapped MFMA operands (a lane owns one pixel, float4 epilogue): 0 never, 1 always, 2 for wave tiles of 2+ column tiles and up-sample-add launches (single-tile launches store whole 128 B lines with the scalar form)
@@ -143,7 +149,7 @@ struct SvcHandle {
     unsigned seg_off = 0;              // MEASUREMENT AID (SVC_SEG_OFF=bitmask): stages of the network pass whose launches are skipped -- the maps are then garbage; tools/time_segments.py prices a stage by leaving it out.  Stages: 0 front, 1 blocks 2-3, 2 blocks 4-7, 3 blocks 8-14, 4 blocks 15-17, 5 features.18 + skips + post_cnn, 6 upsampling block 1, 7 upsampling block 2, 8 adaptation / smoothing / quantisation
     int seg_cur = 0;                   // stage forward_chunk is in
     int dwpw_max_nt = 5;               // output-channel tiles (32 columns each) per k_dwpw workgroup: fewer = more workgroups, the depthwise part redone per group (SVC_DWPW_NT)
-    int dwpw_min_px = 400;             // ... on levels with at least this many pixels per frame; the 8x13 level has too few patches (SVC_DWPW_MIN_PX)
+    int dwpw_min_px = 400;             // ... on levels with at least this many pixels per frame; the 8x13 level has too few patches (SVC_DWPW_MIN_PX; 100 when the split-bf16 pipe is on: the fused kernel then wins on that level too, -18 us per shared pass)
     int dw_tile = 42;                  // stride-1 depthwise: outputs per thread as TX*10+TY (SVC_DW_TILE: 21, 22, 41, 42, 44; 0 = one output per thread)
     int prim_pt = 2;                   // legacy Prim (k_prim_pt): smallest points-per-thread variant (SVC_PRIM_PT: 2, 4, 8, 16)
     int tail_prio = 0;                 // SVC_TAIL_PRIO=1: s_setprio 3 in k_tail_front / k_tail_back (measured: no effect on the pipelined bench or config 3)

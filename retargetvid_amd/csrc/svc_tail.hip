@@ -28,8 +28,17 @@
 #include "hdb_tree.h"
 #include "svc_internal.h"
 
+#ifndef TB
 #define TB 1024                 // threads per frame workgroup
+#endif
 #define NW16 (TB / 64)          // wavefronts per workgroup
+// What the kernels below assume of TB, stated once (round 4's TB = 512 build did not terminate: three block reductions read
+// sixteen per-wavefront slots whatever NW16 was, i.e. the other parity's stale minima): the per-wavefront slots of a block
+// reduction are read back as slot[lane & (NW16 - 1)] and reduced inside a row of 16 lanes, so NW16 must be a power of two of
+// at most 16; k_prim_lvl's rounds run on LVL_WORKERS = 4 wavefronts.  Every launch below uses TB, and the fused kernels
+// refuse to run under any other block size (tail_block_ok).
+static_assert(TB % 64 == 0 && (NW16 & (NW16 - 1)) == 0 && NW16 >= 4 && NW16 <= 16,
+              "the tail kernels need 4, 8 or 16 wavefronts per workgroup");
 #define RING_R 20               // ring table radius for core distances
 #define RING_R1 4                // radius walked by the one-thread-per-point phase
 #define DEPTH_SLOT 4096          // maps per svc_cluster_center call
@@ -620,7 +629,7 @@ __device__ __forceinline__ void prim_regs32(const uint32_t *__restrict__ core_g,
         __syncthreads();
         // second level: lanes 0..15 of every row hold one slot each; row minimum by DPP, the winner's
         // payload by readlane
-        const uint4 t = sl[lane & 15];
+        const uint4 t = sl[lane & (NW16 - 1)];
         uint32_t k2 = t.x;
         k2 = dpp_min_u32<0x111, 0xF>(k2);
         k2 = dpp_min_u32<0x112, 0xF>(k2);
@@ -1055,7 +1064,7 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
         parity ^= 1;
         if (lane == 0) red[wave] = best;
         __syncthreads();
-        uint32_t k2 = red[lane & 15];
+        uint32_t k2 = red[lane & (NW16 - 1)];
         k2 = dpp_min_u32<0x111, 0xF>(k2);
         k2 = dpp_min_u32<0x112, 0xF>(k2);
         k2 = dpp_min_u32<0x114, 0xF>(k2);
@@ -1478,7 +1487,7 @@ __device__ __forceinline__ void prim_lvl_big_body(const TailArgs &A) {
         parity ^= 1;
         if (lane == 0) red[wave] = best;
         __syncthreads();
-        uint32_t k2 = red[lane & 15];
+        uint32_t k2 = red[lane & (NW16 - 1)];
         k2 = dpp_min_u32<0x111, 0xF>(k2);
         k2 = dpp_min_u32<0x112, 0xF>(k2);
         k2 = dpp_min_u32<0x114, 0xF>(k2);

@@ -143,6 +143,20 @@ class Engine:
         """True when the last saliency call ran LANCZOS + features.0 + features.1 as the one kernel k_front."""
         return bool(self.lib.svc_front_fused(self._h))
 
+    def threshold_census(self, reset=False):
+        """-> dict(maps, below, at, above, pixels_per_grey_level): pixels of the un-thresholded maps at t - 1 / t / t + 1 over
+        the maps this engine produced through saliency(threshold=t) since the last reset (svc_threshold_census: the regime
+        diagnostic of the threshold; synchronises)."""
+        out = (ctypes.c_uint64 * 4)()
+        _lib.check(self.lib.svc_threshold_census(self._h, ctypes.cast(out, ctypes.c_void_p), 1 if reset else 0))
+        maps, lo, at, hi = (int(v) for v in out)
+        return dict(maps=maps, below=lo, at=at, above=hi, pixels_per_grey_level=((lo + at + hi) / (3.0 * maps) if maps else None))
+
+    def matrix_pipe(self):
+        """'f32' (fp32 MFMA) or 'bf16x6' (split-bf16 operands, six plane pairs on the bf16 MFMA): what the handle's 1x1
+        convolutions run on (svc_matrix_pipe; environment SVC_MX when the engine is created)."""
+        return 'bf16x6' if self.lib.svc_matrix_pipe(self._h) == 6 else 'f32'
+
     def argsort_u32(self, keys):
         """Test door: the device's emulation of numpy's default argsort on uint32 keys -> int32 order."""
         keys = np.ascontiguousarray(keys, np.uint32)

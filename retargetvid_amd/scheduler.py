@@ -45,11 +45,28 @@ def lane_streams(dev, n):
     return pool[:n]
 
 
-class _Video:
-    __slots__ = ('idx', 'video', 'plan', 'lane', 'row0', 'xy', 'remaining', 'maps', 'pos', 'done')
+def lane_rows_for(videos, CP, lanes, cap=4096):
+    """Rows (selected frames) of a lane's frame and map storage for this job: what its share of the job needs (twice, so that
+    an uneven split does not force a replacement), never less than a chunk's worth, never more than ``cap``; a job of
+    callables (videos built on demand: sizes unknown) gets ``cap``.  A video longer than this still gets its own storage
+    (_Lane._alloc takes the larger of the two)."""
+    n = []
+    for v in videos:
+        if callable(v):
+            return cap
+        fc = int(v.get('frame_count', 0) or len(v['frames']))
+        n.append(fc // max(1, int(CP['skip'])) + 3)
+    if not n:
+        return 128
+    return int(min(cap, max(128, 2 * (sum(n) // max(1, lanes) + 1))))
 
-    def __init__(self, idx, video, plan):
+
+class _Video:
+    __slots__ = ('idx', 'video', 'plan', 'lane', 'row0', 'xy', 'remaining', 'maps', 'pos', 'done', 'sink', 'ready')
+
+    def __init__(self, idx, video, plan, sink):
         self.idx, self.video, self.plan = idx, video, plan
+        self.sink = sink                   # the result list of the job this video belongs to (a straggler of a failed job never writes into the next job's)
         self.xy = np.full((plan['n_sel'], 2), np.nan)
         self.remaining = plan['n_sel']
         self.pos = 0                       # next selected frame to take in
@@ -102,7 +119,8 @@ class _Lane:
             self.drain()
             self._alloc(geom[0], geom[1], plan['n_sel'])
         v.lane, v.row0 = self, self.rows_in
-        v.maps = self.maps[v.row0:v.row0 + plan['n_sel']]
+        self.sched.lane_of[v.idx] = self.k
+        v.maps = self.maps[v.row0:v.row0 + plan['n_sel']]         # a VIEW of the lane's storage until the video's last centre has arrived (_dispatch clones it then)
         slot = self.next_slot
         self.next_slot += 1
         self.videos[slot] = v
@@ -172,6 +190,13 @@ class _Lane:
         f0 = self.frames_done
         # rows of this call: up to (not including) the row of the next frame the network has not seen
         R = int(self.row_of_frame[f0 + k]) if f0 + k < self.frames_in else self.rows_in
+        # Rows that carry no frame (the all-zero last map of every read batch, videos of one selected frame, read_batch = 1)
+        # can pile up between two frames: a call takes at most what the tail's storage holds, the rest goes to the next
+        # call(s) -- a degenerate video costs calls, it does not abort the job
+        limit = 2 * sc.chunk + 64
+        if R - self.rows_called > limit:
+            R = self.rows_called + limit
+            k = int(np.searchsorted(self.row_of_frame[f0:f0 + k], R))    # frames whose rows are inside the call
         n_rows = R - self.rows_called
         self.pipe.slot_for(n_rows)                                   # (checks that the rows fit the storage)
         with torch.cuda.stream(self.stream):
@@ -272,18 +297,35 @@ class JobScheduler:
         self.out = [None] * len(self.videos)
         self.next_idx = 0
         self.futures = []
+        self.lane_of = {}                                     # video -> lane (for the per-lane threshold census below)
         self.n_chunks = self.n_net_frames = 0
         self.host_s = dict(plan=0.0, intake=0.0, enqueue_net=0.0, enqueue_tail=0.0, wait=0.0, dispatch=0.0)
         t0 = time.perf_counter()
         lanes = [_Lane(self, e, s, k) for k, (e, s) in enumerate(zip(self.engines, self.streams))]
-        with torch.cuda.device(self.dev):
-            live = list(lanes)
-            while live:
-                live = [ln for ln in live if ln.step()]
-            for ln in lanes:                                  # every lane's last call is enqueued before any is waited for
-                ln.flush()
-            for ln in lanes:
-                ln.finish()
+        for e in self.engines:
+            e.threshold_census(reset=True)
+        t0 = time.perf_counter()
+        try:
+            with torch.cuda.device(self.dev):
+                live = list(lanes)
+                while live:
+                    live = [ln for ln in live if ln.step()]
+                for ln in lanes:                              # every lane's last call is enqueued before any is waited for
+                    ln.flush()
+                for ln in lanes:
+                    ln.finish()
+        except BaseException:
+            # the feeder failed (a bad video in plan_video, rows that do not fit): no host-stage task of this job may still be
+            # running when the caller sees the error -- the scheduler is reused for the next job
+            for f in self.futures:
+                f.cancel()
+            for f in self.futures:
+                try:
+                    f.result()
+                except BaseException:
+                    pass
+            torch.cuda.synchronize(self.dev)
+            raise
         t1 = time.perf_counter()
         err = None
         for f in self.futures:
@@ -297,6 +339,13 @@ class JobScheduler:
         missing = [i for i, o in enumerate(self.out) if o is None]
         if missing:
             raise RuntimeError('JobScheduler: videos %r were never completed' % (missing[:8],))
+        # the regime diagnostic (smartVidCrop.after_ingest): the threshold is fused into the network here, so the figure is the
+        # lane engine's census over this job -- every video of a lane reports that lane's mean
+        ppl = [e.threshold_census(reset=True)['pixels_per_grey_level'] for e in self.engines]
+        for i, o in enumerate(self.out):
+            v = ppl[self.lane_of[i]] if i in self.lane_of else None
+            for ratio in o:
+                o[ratio][1]['pixels_per_grey_level_at_threshold'] = None if v is None else round(float(v), 2)
         self.stats = dict(videos=len(self.videos), chunks=self.n_chunks, network_frames=self.n_net_frames,
                           mean_chunk_fill=self.n_net_frames / max(1, self.n_chunks) / self.chunk,
                           seconds_device_side=t1 - t0, seconds_host_stage_drain=t2 - t1, lanes=len(lanes),
@@ -313,10 +362,11 @@ class JobScheduler:
         with torch.cuda.stream(lane.stream):
             v = self.videos[i]() if callable(self.videos[i]) else self.videos[i]
             plan = S.plan_video(v, self.CP, engine=lane.eng, shot_net=self.shot_net)
-        return _Video(i, v, plan)
+        return _Video(i, v, plan, self.out)
 
     def _dispatch(self, lane, gids, xy):
         """Centres of finished maps -> their videos; a video whose last centre arrived goes to the host-stage pool."""
+        import torch
         if len(gids) == 0:
             return
         t = time.perf_counter()
@@ -330,12 +380,19 @@ class JobScheduler:
             if v.remaining == 0 and not v.done:
                 v.done = True
                 del lane.videos[int(slot)]
+                # the video's filtered maps leave the lane's storage: a result that is kept does not keep rows x h x w bytes
+                # (and whatever storage drain() has replaced since) alive, and results of different videos do not alias
+                with torch.cuda.stream(lane.stream):
+                    v.maps = v.maps.clone()
+                    v.ready = torch.cuda.Event()
+                    v.ready.record(lane.stream)               # _finish_video waits for the copy before anything reads it
                 self.futures.append(self.pool.submit(self._finish_video, v))
         self.host_s['dispatch'] += time.perf_counter() - t
 
     def _finish_video(self, v):
         """Host stages of one video (pool thread)."""
         S.sc_init_time()
+        v.ready.synchronize()              # the video's own copy of its maps is complete (made on the lane's stream; read on any)
         VD = S._LazySmaps(S._ingest_dict(v.plan, v.maps, xy_stream=v.xy))
         out = {}
         base = None
@@ -346,5 +403,5 @@ class JobScheduler:
                 out[ratio] = base
             else:
                 out[ratio] = S.other_ratio(base, cp)
-        self.out[v.idx] = out
+        v.sink[v.idx] = out
         v.video = None                     # the frames are not needed any more

@@ -253,8 +253,11 @@ class _HostFeed:
                 if self.used[slot]:
                     self.copy_stream.wait_event(self.consumed[slot])    # the device slot's previous reader is done
                 if direct:
-                    for j, f in enumerate(part):
-                        self.staged[slot][j].copy_(src[f], non_blocking=True)
+                    if len(part) > 1 and part[-1] - part[0] == len(part) - 1 and all(part[j + 1] == part[j] + 1 for j in range(len(part) - 1)):
+                        self.staged[slot][:len(part)].copy_(src[part[0]:part[0] + len(part)], non_blocking=True)     # a run of consecutive frames: one copy
+                    else:
+                        for j, f in enumerate(part):
+                            self.staged[slot][j].copy_(src[f], non_blocking=True)
                 else:
                     self.staged[slot][:len(part)].copy_(self.pinned[slot][:len(part)], non_blocking=True)
                 self.copied[slot].record(self.copy_stream)
@@ -309,12 +312,14 @@ def _small_frames(engine, frames, idx, sal_h, sal_w, dev):
         if getattr(frames, 'accepts_device_index', False):
             return engine.resize_frames(frames.select(idx, index=device_index(engine, idx, dev)).to(dev).contiguous(), sal_h, sal_w)
         return engine.resize_frames(frames.select(idx).to(dev).contiguous(), sal_h, sal_w)
-    host = frames if torch.is_tensor(frames) else np.asarray(frames)
-    if (host.dtype not in (np.uint8, torch.uint8)) or host.ndim != 4 or host.shape[3] != 3:
-        raise TypeError('frames must be uint8 [n,h,w,3] RGB')
     feed = getattr(engine, '_host_feed', None)
     if feed is None:
         feed = engine._host_feed = _HostFeed(engine)
+    if not torch.is_tensor(frames) and hasattr(frames, 'pinned') and hasattr(frames, 'rows'):   # selected frames in pinned host memory (synth.HostSelectedVideo)
+        return feed.downscale(frames.pinned, frames.rows(idx), sal_h, sal_w)
+    host = frames if torch.is_tensor(frames) else np.asarray(frames)
+    if (host.dtype not in (np.uint8, torch.uint8)) or host.ndim != 4 or host.shape[3] != 3:
+        raise TypeError('frames must be uint8 [n,h,w,3] RGB')
     return feed.downscale(host, idx, sal_h, sal_w)
 
 
@@ -372,7 +377,8 @@ def _ingest_dict(plan, smaps, xy_stream=None):
     """The dict the ingest hands on (the reference's vid_data after ingest_pickle, smartVidCrop.py:826-836)."""
     vd = dict(smaps_dev=smaps, segmentation=plan['seg'], segmentation_sel=plan['seg_sel'], true_inds=plan['true_inds'],
               inds_to_orig=plan['map2orig'], fr=plan['fr'], fc=plan['n_frames'], fc_sel=plan['n_sel'], h_orig=plan['h'],
-              w_orig=plan['w'], h_process=plan['sal_h'], w_process=plan['sal_w'])
+              w_orig=plan['w'], h_process=plan['sal_h'], w_process=plan['sal_w'],
+              n_net_maps=int(plan['n_sel'] - np.count_nonzero(plan['zero_map'])))     # maps the network writes (the rest stay all-zero: the off-by-one)
     if plan['trans_probs'] is not None:
         vd['trans_probs'] = plan['trans_probs']
     if xy_stream is not None:
@@ -507,8 +513,9 @@ def blend_flags(fc_sel, segmentation_sel):
 class _LazySmaps(dict):
     """VD dict whose 'smaps' ([H,W,n] u8, the reference's layout) is materialised from the device
     only when somebody asks for it, and whose 'bbs' list is made from the array 'bbs_np' on first access (0.4 ms of
-    Python per video and ratio that the multi-video job never needs).  The lazy keys answer `in`, get(), keys(), items(),
-    iteration, dict(VD) and pickling like keys that are present: a caller of the reference gets a plain dict with both."""
+    Python per video and ratio that the multi-video job never needs).  The lazy keys answer `in`, get(), keys(), len() and
+    iteration like keys that are present WITHOUT building their values; [], get(), items(), values(), dict(VD) and pickling
+    build them: a caller of the reference gets a plain dict with both."""
     _LAZY = {'smaps': 'smaps_dev', 'bbs': 'bbs_np'}
 
     def __missing__(self, key):
@@ -532,8 +539,13 @@ class _LazySmaps(dict):
     def get(self, key, default=None):
         return self[key] if key in self else default
 
+    def _pending(self):
+        """Lazy key names that would appear on materialisation (no value is built)."""
+        return [k for k, src in self._LAZY.items() if not dict.__contains__(self, k) and dict.__contains__(self, src)]
+
     def keys(self):
-        return dict.keys(self._materialise())
+        """Key NAMES only: the lazy keys are reported without building their values (a device-to-host copy of every map)."""
+        return list(dict.keys(self)) + self._pending()
 
     def items(self):
         return dict.items(self._materialise())
@@ -542,10 +554,13 @@ class _LazySmaps(dict):
         return dict.values(self._materialise())
 
     def __iter__(self):
-        return dict.__iter__(self._materialise())
+        return iter(self.keys())
 
     def __len__(self):
-        return dict.__len__(self._materialise())
+        return dict.__len__(self) + len(self._pending())
+
+    def __bool__(self):
+        return dict.__len__(self) > 0
 
     def copy(self):
         return _LazySmaps(dict.copy(self))
@@ -650,7 +665,14 @@ def after_ingest(VD, CP, engine, verbose=False):
 
     maps = VD['smaps_dev']
     t = time.perf_counter()
+    ppl = VD.get('pixels_per_grey_level_at_threshold')
     if 'xy_stream' not in VD:
+        # the regime diagnostic (include/svc.h: svc_threshold_census): pixels of the raw maps at t - 1, t, t + 1 per map and level
+        tt = int(CP['t_threshold'])
+        if maps.numel() and 1 <= tt <= 254:
+            near = ((maps >= tt - 1) & (maps <= tt + 1)).sum()
+            n_net = max(1, int(VD.get('n_net_maps', VD['fc_sel'])))
+            ppl = float(near.item()) / (3.0 * n_net)
         engine.threshold_(maps, CP['t_threshold'])
     sc_register_time(t, '_thresh')                     # (enqueue time; the stream is synchronised by the D2H below)
 
@@ -706,6 +728,12 @@ def after_ingest(VD, CP, engine, verbose=False):
     results['info'] = ' (%dx%d)->(%dx%d)->(%dx%d)->(%dx%d)\n' % (
         VD['h_orig'], VD['w_orig'], VD['h_process'], VD['w_process'], VD['h_final'], VD['w_final'],
         VD['fbb_h'], VD['fbb_w'])
+    # NOT a key of the reference's results: how many pixels of a raw saliency map sit on each of the three grey levels around
+    # t_threshold (mean per map).  Two correct fp32 implementations of the network differ by one grey level on ~0.3 % of the
+    # pixels; ~7 - 45 pixels per level keep the crop windows identical to the reference CPU path's, ~500 (a checkpoint whose
+    # maps are flat around the threshold) make a fifth of them differ by more than a pixel.  The multi-video
+    # job reports the figure of the lane's engine over the job so far (the threshold is fused into the network there).
+    results['pixels_per_grey_level_at_threshold'] = None if ppl is None else round(float(ppl), 2)
     results['params'] = ''.join(' %-18s : %s\n' % (k, str(v)) for k, v in CP.items())
     results['mean_sal_score'] = VD['mean_sal_score']
     results['mean_sal_score_t'] = CP['t_sal']
@@ -782,7 +810,11 @@ def crop_videos(videos, CP, ratios=None, workers=12, state_dict=None, seed=0, st
         packed = bool(CP['clust_filt'])
     if packed:
         from . import scheduler as _sched
-        js = _sched.JobScheduler(CP, ratios, lanes=max(1, int(workers)), state_dict=state_dict, seed=seed, shot_net=shot_net)
+        # no more lanes than videos (a lane = an engine: weights, workspace, 0.6 GB of frame and map rows), and a lane's rows
+        # sized by the job where that is known without building the videos
+        lanes = max(1, min(int(workers), len(videos) or 1))
+        js = _sched.JobScheduler(CP, ratios, lanes=lanes, state_dict=state_dict, seed=seed, shot_net=shot_net,
+                                 lane_rows=_sched.lane_rows_for(videos, CP, lanes))
         try:
             out = js.run(videos)
             if stats is not None:

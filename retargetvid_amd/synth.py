@@ -125,6 +125,26 @@ class ResidentBlobVideo:
         return self.frames[torch.as_tensor(rows, dtype=torch.int64).pin_memory().to(self.frames.device, non_blocking=True)]
 
 
+class HostSelectedVideo:
+    """The frames a run will select, in PINNED HOST memory (uint8 [k,h,w,3]): the "decoded frames live on the host" case of
+    BASELINE config 3 without a decoder -- every selected frame crosses PCIe inside the job, through smartVidCrop._HostFeed
+    (pinned source: copied from where it lies, then down-scaled on the device).  Built from a ResidentBlobVideo (one
+    device-to-host copy, outside any timed region).  ``rows(idx)``: positions of the frame numbers idx in ``pinned``."""
+
+    def __init__(self, resident):
+        import torch
+        self.n, self.h, self.w = resident.n, resident.h, resident.w
+        self.row = resident.row
+        self.pinned = torch.empty(tuple(resident.frames.shape), dtype=torch.uint8).pin_memory()
+        self.pinned.copy_(resident.frames)
+
+    def __len__(self):
+        return self.n
+
+    def rows(self, idx):
+        return [self.row[int(i)] for i in idx]
+
+
 def retargetvid_cuts(vid, n):
     """The synthetic shot starts of video `vid` (n frames) in the RetargetVid-shaped job of bench.py's config 3,
     tools/run_config3.py and the tests: 0-3 cuts at seeded positions.  -> trans_inds (smartVidCrop.py:560-573)."""

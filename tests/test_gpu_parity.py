@@ -39,7 +39,7 @@ def _check_tail(engine, maps, flags, CP):
         if dx[i] is None:
             assert np.isnan(xy[i]).all()
         else:
-            assert xy[i, 0] == dx[i] and xy[i, 1] == dy[i]          # exact: integer sums / count in float64
+            assert xy[i, 0] == dx[i] and xy[i, 1] == dy[i]          # equal to the ORACLE's centre (integer sums / count in float64); the reference's KMeans(n_clusters=1) agrees with that mean within 1e-12 px, not bit for bit (tests/test_oracle_tail.py)
     return stats.cpu().numpy()
 
 
@@ -564,8 +564,11 @@ _TAPS = (('feat_4x', 'TAP_FEAT4X', 8, 64), ('feat_2x', 'TAP_FEAT2X', 16, 160), (
 _TOL = {'nc': (8e-5, 8e-6, 1e-3), 'ri': (4e-4, 6e-5, 1e-2), 'tl': (4e-4, 6e-5, 2e-3), 'tl2': (4e-4, 6e-5, 2e-3)}
 
 
-@pytest.mark.parametrize('ck', ['nc', 'ri', 'tl', 'tl2'])
-def test_network_every_layer_every_frame_three_geometries(ck, golden_dir):
+@pytest.mark.parametrize('ck,pipe', [('nc', 'f32'), ('ri', 'f32'), ('tl', 'f32'), ('tl2', 'f32'), ('ri', 'bf16x6'), ('tl', 'bf16x6')])
+def test_network_every_layer_every_frame_three_geometries(ck, pipe, golden_dir):
+    """Every tap of every frame at three geometries against the oracle AND the reference model's own goldens, per checkpoint family.
+    pipe = 'bf16x6': the same gates, tolerances unchanged, with the 1x1 convolutions on the bf16 matrix pipe with split operands
+    (SVC_MX=bf16x6: opt-in, csrc/svc_net.hip "Split-bf16 operands"), on the two checkpoints with realistic activations."""
     from retargetvid_amd import weights
     g = np.load(os.path.join(golden_dir, {'tl': 'unisal_golden3.npz', 'tl2': 'unisal_golden4.npz'}.get(ck, 'unisal_golden2.npz')))
     if ck in ('tl', 'tl2'):                            # trained-like: the reference model fitted to blob targets (peaky maps); two fits
@@ -575,7 +578,16 @@ def test_network_every_layer_every_frame_three_geometries(ck, golden_dir):
     else:
         sd = weights.make_reference_init_state_dict(7, {k[3:]: g[k] for k in g.files if k.startswith('bn/')})
     atol_f, mean_f, u8_frac = _TOL[ck]
-    eng = ops.Engine(sd)
+    old_mx = os.environ.get('SVC_MX')
+    os.environ['SVC_MX'] = pipe
+    try:
+        eng = ops.Engine(sd)
+    finally:
+        if old_mx is None:
+            os.environ.pop('SVC_MX', None)
+        else:
+            os.environ['SVC_MX'] = old_mx
+    assert eng.matrix_pipe() == pipe
     try:
         for gname in ('16x9', '4x3', 'port'):
             frames = g['frames_' + gname]
@@ -677,3 +689,41 @@ def test_new_tail_kernels_equal_the_round2_kernels_on_random_maps():
     finally:
         old.close()
         new.close()
+
+
+def test_split_bf16_pipe_is_opt_in_and_reproducible_on_one_stream(engine, synthetic_sd, golden_dir):
+    """SVC_MX=bf16x6 (opt-in; the default is the fp32 matrix pipe): the golden gates of test_saliency_against_oracle_and_reference_golden
+    with tolerances unchanged, bit-identical maps run after run and whatever the batch ON ONE STREAM (with several streams sharing
+    the chip they were not: tools/soak_network_concurrent.py, DESIGN.md 5 -- which is why it is not the default)."""
+    assert engine.matrix_pipe() == 'f32'
+    old = os.environ.get('SVC_MX')
+    os.environ['SVC_MX'] = 'bf16x6'
+    try:
+        mx = ops.Engine(synthetic_sd)
+    finally:
+        if old is None:
+            os.environ.pop('SVC_MX', None)
+        else:
+            os.environ['SVC_MX'] = old
+    try:
+        assert mx.matrix_pipe() == 'bf16x6'
+        g = np.load(os.path.join(golden_dir, 'unisal_golden.npz'))
+        frames = g['frames']
+        maps = mx.saliency(torch.from_numpy(frames).cuda()).cpu().numpy()
+        taps = {}
+        ref = U.saliency_u8(synthetic_sd, frames, taps)
+        t = taps['frames'][0]
+        for which, shape, key in [(ops.TAP_FEAT4X, (32, 52, 64), 'feat_4x'), (ops.TAP_FEAT2X, (16, 26, 160), 'feat_2x'),
+                                  (ops.TAP_POSTCNN, (8, 13, 256), 'post_cnn'), (ops.TAP_DEC, (32, 52, 64), 'dec')]:
+            r = t[key][0].permute(1, 2, 0).numpy()
+            assert np.abs(mx.tap(which, 0, shape) - r).max() <= 2e-4 * np.abs(r).max(), key
+        assert np.abs(mx.tap(ops.TAP_PRE, 0, (140, 250)) - t['pre'][0].numpy()).max() < 1e-4
+        for r8 in (ref, g['smaps_u8']):
+            d = np.abs(np.transpose(maps, (1, 2, 0)).astype(int) - r8.astype(int))
+            assert d.max() <= 1 and (d > 0).mean() < 1e-3
+        fr = torch.from_numpy(synth.blob_frames(40, 140, 250, seed=9)).cuda()
+        full = mx.saliency(fr)
+        assert torch.equal(mx.saliency(fr), full)
+        assert torch.equal(mx.saliency(fr[33:40]), full[33:40]) and torch.equal(mx.saliency(fr[3:4])[0], full[3])
+    finally:
+        mx.close()

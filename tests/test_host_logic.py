@@ -308,3 +308,45 @@ def test_plan_video_bookkeeping_for_the_scheduler():
         S.plan_video(dict(video, trans_inds=[7]), CP)
     with pytest.raises(ValueError):
         S.plan_video(dict(video, trans_inds=None), CP)              # no shots and no shot network
+
+
+def test_lazy_result_dict_reports_lazy_keys_without_building_them():
+    """VD of the multi-video job: 'smaps' / 'bbs' are built on demand; len(), iteration, keys(), `in` and bool() must not
+    trigger the device-to-host copy of every map (advisor, round 4)."""
+    from retargetvid_amd import smartVidCrop as S
+
+    class FakeMaps:
+        built = 0
+
+        def permute(self, *a):
+            FakeMaps.built += 1
+            return self
+
+        def cpu(self):
+            return self
+
+        def numpy(self):
+            return np.zeros((2, 3, 1), np.uint8)
+
+    vd = S._LazySmaps({'fc': 7, 'smaps_dev': FakeMaps(), 'bbs_np': np.array([[0, 0, 9, 9]])})
+    assert len(vd) == 5 and bool(vd) and 'smaps' in vd and 'bbs' in vd
+    assert sorted(vd) == sorted(['fc', 'smaps_dev', 'bbs_np', 'smaps', 'bbs']) and sorted(vd.keys()) == sorted(vd)
+    assert FakeMaps.built == 0 and not dict.__contains__(vd, 'bbs')
+    assert vd['bbs'] == [[0, 0, 9, 9]] and FakeMaps.built == 0
+    assert vd['smaps'].shape == (2, 3, 1) and FakeMaps.built == 1
+    assert len(vd) == 5 and dict(vd)['smaps'].shape == (2, 3, 1)
+
+
+def test_lane_rows_follow_the_job():
+    from retargetvid_amd import scheduler
+    CP = S_init()
+    vids = [{'frame_count': 600, 'frames': None}] * 10
+    assert scheduler.lane_rows_for(vids[:3], CP, 12) == 128                 # 3 videos of ~103 rows over 12 lanes: the floor
+    assert scheduler.lane_rows_for(vids * 40, CP, 4) == 4096                # capped
+    assert 128 < scheduler.lane_rows_for(vids * 4, CP, 4) < 4096
+    assert scheduler.lane_rows_for([lambda: None], CP, 4) == 4096           # sizes unknown
+
+
+def S_init():
+    from retargetvid_amd import smartVidCrop as S
+    return S.sc_init_crop_params()

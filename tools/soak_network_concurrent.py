@@ -1,0 +1,60 @@
+"""Run-to-run reproducibility of the NETWORK with several passes sharing the chip: N engines on N streams push the same 32 frames
+ITERS times; every pass's maps (and, on a mismatch, the taps of the differing frame) are compared with a single-stream reference.
+python tools/soak_network_concurrent.py [N] [ITERS]    (GPU box; SVC_MX / SVC_MX_MASK select the matrix pipe)"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from retargetvid_amd import ops, synth, scheduler
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+fr = torch.from_numpy(synth.blob_frames(32, 140, 250, seed=0)).cuda()
+TAPS = [('feat4x', ops.TAP_FEAT4X, (32, 52, 64)), ('feat2x', ops.TAP_FEAT2X, (16, 26, 160)), ('feat1x', ops.TAP_FEAT1X, (8, 13, 1296)),
+        ('postcnn', ops.TAP_POSTCNN, (8, 13, 256)), ('dec', ops.TAP_DEC, (32, 52, 64)), ('pre', ops.TAP_PRE, (140, 250))]
+engs = [ops.Engine(seed=0) for _ in range(N)]
+# BURN=kind[:blocks[:iters]]: a register-only MFMA burner (tools/micro/bf16_burner.hip; kind 0 bf16, 1 f16, 2 f32) on two extra streams beside every pass
+BURN = os.environ.get('BURN')
+if BURN:
+    import ctypes
+    bl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'micro', 'libbf16_burner.so'))
+    bl.burn_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    bk = [int(v) for v in BURN.split(':')] + [512, 400][len(BURN.split(':')) - 1:]
+    bstreams = [torch.cuda.Stream() for _ in range(2)]
+sts = scheduler.lane_streams(torch.device('cuda', 0), N)
+ref = engs[0].saliency(fr).clone()
+reft = {f: [engs[0].tap(w, f, sh) for _, w, sh in TAPS] for f in range(32)}
+outs = [torch.empty_like(ref) for _ in range(N)]
+bad = 0
+for it in range(ITERS):
+    if BURN:
+        for bs in bstreams:
+            bl.burn_launch(ctypes.c_void_p(bs.cuda_stream), bk[1], bk[2], bk[0])
+    for i in range(N):
+        with torch.cuda.stream(sts[i]):
+            engs[i].saliency(fr, out=outs[i])
+    torch.cuda.synchronize()
+    for i in range(N):
+        if not torch.equal(outs[i], ref):
+            bad += 1
+            d = (outs[i] != ref)
+            frames = torch.nonzero(d.flatten(1).any(1)).flatten().tolist()
+            msg = []
+            for f in frames[:2]:
+                t = [engs[i].tap(w, f, sh) for _, w, sh in TAPS]
+                msg.append('frame %d: %d px; taps differing: %s' % (f, int(d[f].sum()), [(n, int((a != b).sum()), '%.1e' % float(np.abs(a - b).max()))
+                                                                                          for (n, _, _), a, b in zip(TAPS, t, reft[f]) if not np.array_equal(a, b)]))
+            print('iter %d engine %d: %s' % (it, i, '; '.join(msg)), flush=True)
+            if bad <= 4:
+                f = frames[0]
+                got = engs[i].tap(ops.TAP_PRE, f, (140, 250)).reshape(-1)
+                want = reft[f][5].reshape(-1)
+                idx = np.flatnonzero(got != want)
+                print('   pre: flat indices %s (mod 16 of the first: %d; byte offset in the buffer mod 128: %d)' % (idx.tolist(), idx[0] % 16, ((f * 35000 + idx[0]) * 4) % 128))
+                print('   got  %s' % np.array2string(got[idx], precision=4, max_line_width=250))
+                print('   want %s' % np.array2string(want[idx], precision=4, max_line_width=250))
+                # is the wrong data the reference's data of another place (a shifted / misplaced store)?
+                for k in range(len(idx)):
+                    w = np.flatnonzero(want == got[idx[k]])
+                    if len(w): print('   got[%d] equals want at flat index %s' % (idx[k], w[:4].tolist()))
+print('%d passes, %d with a map that differs from the reference' % (ITERS * N, bad))
+if os.environ.get('SVC_SD_POISON'):
+    print('LDS canary words the smoothing kernel found changed, per engine: %s' % [e.threshold_census()['maps'] for e in engs])

@@ -202,8 +202,13 @@ def config3_job(world, rank, dist_on, dev, sd, lanes, rccl_init_s, mode='residen
         sel = S._select_frames(counts[i], counts[i], cuts_of(i) + [counts[i]], CP['skip'], CP['read_batch'])[0]
         resident[i] = synth.ResidentBlobVideo(counts[i], sel, seed=vids[i], device=dev)
         n_sel_mine += len(sel)
-        if mode == 'host_fed':
-            resident[i] = synth.HostSelectedVideo(resident[i])
+    if mode == 'host_fed':                                            # one page-locked allocation, a slice per video
+        slab = torch.empty((n_sel_mine, 360, 640, 3), dtype=torch.uint8, pin_memory=True)
+        at = 0
+        for i in sorted(resident):
+            k_ = int(resident[i].frames.shape[0])
+            resident[i] = synth.HostSelectedVideo(resident[i], pinned=slab[at:at + k_])
+            at += k_
     torch.cuda.synchronize()
     gen_s = time.perf_counter() - t0
     if mode == 'shot_net':
@@ -336,12 +341,17 @@ def main():
             self.start = torch.cuda.Event(enable_timing=True)
             self.done = torch.cuda.Event(enable_timing=True)
             self.pending = False
+            # every slot works on its OWN batch (same generator, another seed): the maps of the batches in flight then hold
+            # different numbers of points (round-4 verdict: one batch fed every step of every slot, so every map had the same N);
+            # slot 0 keeps the batch of rounds 1-4 (the un-pipelined measurements and the CPU baseline use it)
+            k_ = len(slots_made) - 1
+            self.frames = frames if k_ == 0 else torch.from_numpy(synth.blob_frames(B, 360, 640, seed=100 + rank + 1000 * k_, **BENCH_BLOBS)).to(dev)
             self.pipe = pipeline.StreamPipeline(self.eng, CP, 140, 250, batch=B, stream=self.stream, timing=True, depth=DEPTH)
 
         def enqueue(self):
             with torch.cuda.stream(self.stream):
                 self.start.record(self.stream)
-                small = self.eng.resize_frames(frames, 140, 250)
+                small = self.eng.resize_frames(self.frames, 140, 250)
                 maps = self.eng.saliency(small, out=self.maps)
                 self.eng.threshold_(maps, CP['t_threshold'])
                 self.net_done.record(self.stream)
@@ -399,7 +409,7 @@ def main():
                 host_t['wait'] += time.perf_counter() - t0
                 take(k, res)
             t0 = time.perf_counter()
-            sl.pipe.submit_frames(frames, flags)
+            sl.pipe.submit_frames(sl.frames, flags)
             host_t['enqueue'] += time.perf_counter() - t0
         for k, sl in enumerate(slots):                         # every stream's last call is enqueued before any is waited for
             take(k, sl.pipe.flush())
@@ -479,10 +489,13 @@ def main():
         npts = np.zeros(B, np.int64)                              # (counter passes: nothing but warm-up + timed steps may run)
     else:
         with torch.cuda.stream(slots[0].stream):
-            m_ = eng.saliency(eng.resize_frames(frames, 140, 250))
-            eng.threshold_(m_, CP['t_threshold'])
-            _, st_ = eng.cluster_center_(m_, flags, CP, want_stats=True)
-        npts = st_[:, 0].cpu().numpy()
+            npl = []
+            for sl_ in slots:                                         # every slot's batch
+                m_ = eng.saliency(eng.resize_frames(sl_.frames, 140, 250))
+                eng.threshold_(m_, CP['t_threshold'])
+                _, st_ = eng.cluster_center_(m_, flags, CP, want_stats=True)
+                npl.append(st_[:, 0].cpu().numpy())
+        npts = np.concatenate(npl)
     dominant = max(per_class, key=lambda k: per_class[k][0])
     # BENCH_LIVE_PROFILE=1 also records the dominant class's events INSIDE the timed region (roofline.*_in_flight).  Off by
     # default: 76 event records per step on every stream cost 2-3 % of the step with four batches in flight (1.49 -> 1.45 ms)
@@ -526,6 +539,25 @@ def main():
         torch.distributed.all_gather(tl, torch.tensor([dt_local], dtype=torch.float64, device=dev))
         rank_fps = [B * args.steps / float(t.item()) for t in tl]
 
+    # rounds 1-4 fed ONE batch to every slot (every map of a step then held the same number of points): the same timed region that
+    # way, three repeats, for comparison across rounds (config.one_batch_for_every_slot)
+    same_batch = None
+    if not plain and P > 1:
+        own = [sl.frames for sl in slots]
+        for sl in slots:
+            sl.frames = frames
+        sb = []
+        for rep in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            run(args.steps)
+            barrier()
+            sb.append((time.perf_counter() - t0) / max(args.steps, 1) * 1e3)
+        for sl, fr_ in zip(slots, own):
+            sl.frames = fr_
+        sbm = sorted(sb)[1]
+        same_batch = dict(ms_per_step=round(sbm, 4), frames_per_s=round(world * B / sbm * 1e3, 1), ms_per_step_all=[round(v, 4) for v in sb],
+                          note='every slot on slot 0\'s batch, as in rounds 1-4 (1 640 - 2 057 points per map)')
     # the opt-in matrix pipe (SVC_MX=bf16x6), timed beside the default in the same run: the same timed region on engines created
     # with the variant, five repeats, median.  Reported under config.matrix_pipe_variant -- never as `value` (its maps were not
     # bit-reproducible run to run with several streams sharing the chip: DESIGN.md 5).
@@ -619,7 +651,8 @@ def main():
                         hbm_note='un-fused layer-wise fp32 traffic of the class (in + out + weights) / class time')
         roof['traffic'] = None
         try:
-            src = os.path.join('profiles', 'r04_pmc_traffic.json' if os.path.isfile(os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')) else 'r03_pmc_traffic.json')
+            src = next(os.path.join('profiles', f) for f in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json')
+                       if os.path.isfile(os.path.join(ROOT, 'profiles', f)))
             with open(os.path.join(ROOT, src)) as fp:
                 c = json.load(fp)['classes'][dominant]
             roof.update(traffic=c['hbm_bytes_per_launch'], traffic_per_step=c.get('hbm_bytes_per_step'),
@@ -683,9 +716,11 @@ def main():
                                workload_id=('r02-1to3blobs-sigma20-60' if not BENCH_BLOBS else
                                             'r03-%dblobs-sigma%g-%g' % (BENCH_BLOBS['n_blobs'], BENCH_BLOBS['sigma'][0], BENCH_BLOBS['sigma'][1])),
                                config3=c3, config3_host_fed=c3_host, config3_shot_net=c3_shot, matrix_pipe_variant=variant,
+                               one_batch_for_every_slot=same_batch,
                                batch_per_gpu=B, frame='640x360x3 u8', saliency_map='140x250 u8', network_input='256x416',
                                weights='synthetic seed 0 (weights.make_synthetic_state_dict)',
                                video_frames_per_s=round(value * CP['skip'], 1), batches_in_flight=P,
+                               distinct_batches='every slot steps through its own batch of 32 frames (same generator, seeds 100 + 1000 k); rounds 1-4 fed one batch to every slot',
                                parallelism='frames sharded, dp%d' % world,
                                world_size_seen_by_rccl=seen_world if dist_on else None,
                                per_rank_frames_per_s=[round(v, 1) for v in rank_fps],

@@ -120,6 +120,7 @@ struct SvcHandle {
     std::map<std::tuple<const void *, int, int, int>, DevBuf> lane_w;   // split-K layers' weights in lane order (svc_net.hip: lane_weights), keyed by (matrix, row stride, K, padded N)
     std::map<std::tuple<const void *, int, int, int>, DevBuf> x3_w;     // split-bf16 copies of weight matrices (svc_net.hip: x3_weights), keyed by (matrix, row stride, K, 2 * padded N + order)
     int mx = 0;                        // matrix pipe of the 1x1-convolution GEMMs: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32: the default, rounds 1-4), 6 = split-bf16 operands, six plane pairs on v_mfma_f32_32x32x16_bf16 (SVC_MX=bf16x6: OPT-IN.  Faster -- a pass 1.42 -> 1.24 ms alone, 1.01 -> 0.87 ms with four passes sharing the chip -- and within every per-tap tolerance, but with several streams sharing the chip the maps were not bit-reproducible run to run: 1 - 6 % of the passes had 16 pixels of one kernel one grey level off, cause not found: DESIGN.md 5)
+    int sd_excl = -1;                  // k_smooth_down_mfma alone on its CU (an LDS request nothing fits beside): -1 = when the split-bf16 pipe is on, 0 / 1 = never / always (SVC_SD_EXCL)
     unsigned irb_mx = 0x1b;            // ... which of k_irb's five fixed-shape instances take that form for their expand GEMM (bit = block 2, 3, 4, 5-6, 7; SVC_IRB_MX).  Measured per instance against the fp32 form, us per pass alone / shared: -17 / -11, -12 / -7, +11 / +11 (block 4: Cin = 24 pads its second step, two halo tiles per wave: 36 spilled registers), -11 / -4, -10 / -6: block 4 stays fp32
     unsigned mx_mask = 0xff;           // ... and which kernel families: bit 0 k_pwr, 1 k_irb, 2 k_dwpw, 3 k_pw_sk, 4 k_pwpw (SVC_MX_MASK; for A/B timing)
     bool sk_lane = true;               // k_pw_sk reads its weights from the lane-order copy: a wave's load is 1 KB contiguous instead of 32 rows x 32 B (SVC_SK_LANE=0: from the [N][K] matrix)

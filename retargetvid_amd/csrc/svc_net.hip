@@ -3258,7 +3258,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
             // shared a CU with workgroups of the bf16 kernels of OTHER streams (tools/soak_network_concurrent.py,
             // profiles/r05_mx_reproducibility.txt; cause not found: its LDS canaries stay intact).  Alone on the CU: 0 of 2 400 passes,
             // and the pass is no slower (the kernel is 2 % of it).
-            if (h->mx) {
+            if (h->sd_excl < 0 ? h->mx != 0 : h->sd_excl != 0) {
                 lds = std::max(lds, (size_t)150 * 1024);
                 if (h->lds_attr_done.insert((const void *)k_smooth_down_mfma).second)
                     SVC_HIP(hipFuncSetAttribute((const void *)k_smooth_down_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
@@ -3457,6 +3457,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     env = getenv("SVC_MX");
     if (env) h->mx = (!strcmp(env, "bf16x6") || !strcmp(env, "6")) ? 6 : 0;
     if (h->mx && !getenv("SVC_DWPW_MIN_PX")) h->dwpw_min_px = 100;
+    env = getenv("SVC_SD_EXCL");
+    if (env) h->sd_excl = atoi(env);
     env = getenv("SVC_IRB_MX");
     if (env) h->irb_mx = (unsigned)strtoul(env, nullptr, 0);
     env = getenv("SVC_MX_MASK");

@@ -782,7 +782,10 @@ __global__ __launch_bounds__(TB) void k_prim_big(TailArgs A, int n_min) {
 //   m > RING_R^2 (jumps between far-apart blobs): one node per round, then a rise -- the legacy algorithm's step.
 // Golden maps (N = 660 .. 2 980): 28 .. 81 rounds and 6 .. 15 rises per map instead of N - 1 steps.
 // --------------------------------------------------------------------------------------
-#define LVL_CAP 8192                   // points per map (above: k_prim_big)
+#ifndef LVL_CAP
+#define LVL_CAP 8192                   // points per map (above: k_prim_lvl_big)
+#endif
+static_assert(LVL_CAP % TB == 0, "k_prim_lvl keeps LVL_CAP / TB points per thread");
 #define LVL_PT (LVL_CAP / TB)
 #define LVL_TREE 0x80000000u
 #define LVL_NONE 0xFFFFFFFFu
@@ -2119,7 +2122,9 @@ __device__ __forceinline__ int cluster_phase(const TailArgs &A, uint8_t *ws, uin
 //     computation (one thread per element) at the very end.
 // Working arrays (16 bytes per edge) live in LDS for N <= ~6000 and in the frame's workspace above that.
 // --------------------------------------------------------------------------------------
+#ifndef SORT_LDS_BYTES
 #define SORT_LDS_BYTES (104 * 1024)
+#endif
 #define SORT_NONE 0xFFFFu
 #define SORT_SMALL 15            // ranges with hi - lo > 15 are partitioned (npsort_ref.SMALL_QUICKSORT)
 
@@ -2381,7 +2386,9 @@ __global__ __launch_bounds__(64) void k_tree(TailArgs A) {
 // Only the float64 stability sums stay serial per cluster (one wavefront per cluster: terms in parallel, additions in
 // the library's order), as in hdb::accumulate.  N - 1 serial union-find steps become ~15 block-wide passes.
 // --------------------------------------------------------------------------------------
+#ifndef TP_CAP
 #define TP_CAP 4352                     // points per map with everything in LDS
+#endif
 #define TP_CAP_BIG 8192                 // ... with the jump buffers, weights and order in the frame's workspace
 #define TP_CAP_HUGE 65025               // ... with every per-edge array there (L2-resident); LDS keeps the rank-maxima levels and the cluster tables
 #define TP_NONE 0xFFFFu
@@ -2403,7 +2410,10 @@ static size_t tp_lds_bytes(int hw, int mcs, int *cap_clusters, int *cap_clusters
     const size_t huge = hw > TP_CAP_BIG ? up((size_t)((hw + 256) / 16 + 16) * 2) + up(((size_t)hw / 256 + 32) * 2) + up(32 * 2) + 64 : 0;
     const size_t per_edge = std::max({small, big, huge});
     int cc = hdb::max_clusters(std::min(hw, TP_CAP_HUGE), mcs);
-    const size_t budget = 160 * 1024 - 4096;
+#ifndef TP_LDS_BUDGET
+#define TP_LDS_BUDGET (160 * 1024 - 4096)     // LDS a tail workgroup may ask for (experiment builds: 78 KB = two workgroups per CU)
+#endif
+    const size_t budget = TP_LDS_BUDGET;
     while (cc > 8 && per_edge + (size_t)cc * 48 + 512 > budget) cc /= 2;
     *cap_clusters = cc;
     const size_t total = per_edge + (size_t)cc * 48 + 512;

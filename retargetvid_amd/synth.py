@@ -131,11 +131,14 @@ class HostSelectedVideo:
     (pinned source: copied from where it lies, then down-scaled on the device).  Built from a ResidentBlobVideo (one
     device-to-host copy, outside any timed region).  ``rows(idx)``: positions of the frame numbers idx in ``pinned``."""
 
-    def __init__(self, resident):
+    def __init__(self, resident, pinned=None):
+        """pinned: a pinned uint8 tensor of the frames' shape to fill (a slice of one big allocation: page-locking 14.5 GB in 200
+        pieces takes 10 s, in one piece a few)."""
         import torch
         self.n, self.h, self.w = resident.n, resident.h, resident.w
         self.row = resident.row
-        self.pinned = torch.empty(tuple(resident.frames.shape), dtype=torch.uint8).pin_memory()
+        self.pinned = pinned if pinned is not None else torch.empty(tuple(resident.frames.shape), dtype=torch.uint8).pin_memory()
+        assert self.pinned.is_pinned() and tuple(self.pinned.shape) == tuple(resident.frames.shape)
         self.pinned.copy_(resident.frames)
 
     def __len__(self):

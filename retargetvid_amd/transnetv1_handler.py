@@ -74,20 +74,30 @@ class ShotTransNet:
     def predict_frames(self, frames):
         return self.predict_video(frames)
 
-    def predict_video(self, frames):
-        """[frames, 27, 48, 3] uint8 (NumPy or CUDA tensor) -> NumPy float32 [frames]."""
+    def predict_video(self, frames, keep=None):
+        """[frames, 27, 48, 3] uint8 (NumPy or CUDA tensor) -> NumPy float32 [frames].
+        keep=(a, b): only rows a .. b - 1 of the result are wanted (the caller drops the rest: the reference's call site predicts
+        an array of read_batch + overlap rows, most of them the zero tail behind a 600-frame video, and keeps the video's rows,
+        smartVidCrop.py:353-374).  A window's 50 outputs depend on that window's 100 frames alone, so only the windows whose
+        outputs fall into [a, b) are computed -- the kept rows are bit for bit those of the full computation, the others read 0."""
         assert len(frames.shape) == 4 and tuple(frames.shape[1:]) == (self.params.INPUT_HEIGHT, self.params.INPUT_WIDTH, 3), \
             ' [ShotTransNet] Input shape must be [frames, height, width, 3].'
         dev = torch.device('cuda', torch.cuda.current_device())
         t = frames if torch.is_tensor(frames) else torch.from_numpy(np.ascontiguousarray(frames, np.uint8))
         t = t.to(dev).contiguous()
         n = int(t.shape[0])
-        wi = torch.from_numpy(window_indices(n)).to(dev)
-        res = []
+        wi_all = window_indices(n)
+        k0, k1 = 0, len(wi_all)
+        if keep is not None:                                  # window k yields rows 50 k .. 50 k + 49
+            a, b = max(0, int(keep[0])), min(n, int(keep[1]))
+            k0, k1 = (a // 50, (b - 1) // 50 + 1) if b > a else (0, 0)
+        wi = torch.from_numpy(wi_all[k0:k1]).to(dev)
+        out = torch.zeros(len(wi_all) * 50, dtype=torch.float32, device=dev)
         for i in range(0, len(wi), self.windows_per_call):
             win = t[wi[i:i + self.windows_per_call].reshape(-1)].reshape(-1, 100, *t.shape[1:]).contiguous()
-            res.append(self.predict_raw_device(win)[:, 25:75].reshape(-1))
-        return torch.cat(res)[:n].cpu().numpy()
+            res = self.predict_raw_device(win)[:, 25:75].reshape(-1)
+            out[50 * (k0 + i):50 * (k0 + i) + res.numel()] = res
+        return out[:n].cpu().numpy()
 
 
 def window_indices(n):
@@ -177,6 +187,7 @@ def video_transition_probs(net, frames_small, fr, read_batch=2000, predict=None)
     batch -- and whose unused tail is zeros (smartVidCrop.py:258-260, :353-358, :369-374); rows overlap .. overlap + len of
     predict_frames' output are kept.  frames_small: [n, 27, 48, 3] uint8, CUDA tensor or NumPy.  -> NumPy float32 [n].
     `predict` replaces net.predict_frames (the tests pass the oracle)."""
+    own = predict is None                      # the device network: only the windows whose rows are kept are computed (predict_video's keep)
     predict = predict or net.predict_frames
     is_t = torch.is_tensor(frames_small)
     n = int(frames_small.shape[0])
@@ -192,7 +203,8 @@ def video_transition_probs(net, frames_small, fr, read_batch=2000, predict=None)
         if prev is not None and overlap > 0:
             arr[:overlap] = prev[size - overlap:]
         prev = arr
-        probs.append(np.asarray(predict(arr))[overlap:overlap + ln])
+        full = net.predict_video(arr, keep=(overlap, overlap + ln)) if own else predict(arr)
+        probs.append(np.asarray(full)[overlap:overlap + ln])
     return np.concatenate(probs).astype(np.float32) if probs else np.zeros(0, np.float32)
 
 

@@ -185,3 +185,18 @@ def test_packed_job_with_shot_detection_inside_equals_sequential_runs(net):
                 assert a[r][0]['bbs'] == b[r][0]['bbs'] and a[r][0]['dx'] == b[r][0]['dx']
     finally:
         eng.close()
+
+
+def test_only_the_windows_whose_rows_are_kept_are_computed(net):
+    """predict_video(keep=(a, b)): the reference's call site predicts read_batch + overlap rows per video (mostly the zero tail)
+    and keeps the video's rows; the windows behind them are skipped.  Kept rows: bit for bit those of the full computation."""
+    n, sd = net
+    arr = np.zeros((2025, 27, 48, 3), np.uint8)
+    arr[25:25 + 613] = _frames(613, 5)
+    dev = torch.from_numpy(arr).cuda()
+    full = n.predict_video(dev)
+    for a, b in ((25, 638), (0, 50), (49, 51), (600, 2025), (700, 700)):
+        part = n.predict_video(dev, keep=(a, b))
+        assert part.shape == full.shape and np.array_equal(part[a:b], full[a:b])
+    probs = Hd.video_transition_probs(n, torch.from_numpy(_frames(613, 5)).cuda(), 30.0, 2000)
+    assert np.array_equal(probs, full[25:638])

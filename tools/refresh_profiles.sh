@@ -4,8 +4,8 @@
 # a sys/hip/hsa trace.  TAG = round prefix of the file names (default r02).
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${TAG:-r04}
-export BENCH_CONFIG3=0          # the 200-video job is not part of the profiled steps
+TAG=${TAG:-r05}
+export BENCH_CONFIG3=0 BENCH_VARIANT=0          # the 200-video jobs and the opt-in pipe's timing are not part of the profiled steps
 O=$R/gpurun_out/profiles_new
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -28,7 +28,7 @@ python tools/pmc_sq_table.py $O/sq $O/${TAG}_pmc_sq_network.json > $O/${TAG}_pmc
 rm -rf $O/p4 $O/p1 $O/fetch $O/write $O/sq
 bash tools/trace_step.sh > $O/${TAG}_timeline_one_pass.txt 2>&1
 cp $O/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json      # bench.py reads roofline.traffic from here
-unset BENCH_CONFIG3
+unset BENCH_CONFIG3 BENCH_VARIANT
 python bench.py --cpu-sample 32 > $O/${TAG}_bench_line.json 2> $O/bench.err
 python bench.py --pipeline 1 --cpu-sample 0 > $O/${TAG}_bench_line_pipeline1.json 2>> $O/bench.err
 tail -1 $O/${TAG}_bench_line.json | cut -c1-600

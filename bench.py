@@ -558,17 +558,21 @@ def main():
         sbm = sorted(sb)[1]
         same_batch = dict(ms_per_step=round(sbm, 4), frames_per_s=round(world * B / sbm * 1e3, 1), ms_per_step_all=[round(v, 4) for v in sb],
                           note='every slot on slot 0\'s batch, as in rounds 1-4 (1 640 - 2 057 points per map)')
-    # the opt-in matrix pipe (SVC_MX=bf16x6), timed beside the default in the same run: the same timed region on engines created
-    # with the variant, five repeats, median.  Reported under config.matrix_pipe_variant -- never as `value` (its maps were not
-    # bit-reproducible run to run with several streams sharing the chip: DESIGN.md 5).
+    # the OTHER matrix pipe (SVC_MX=f32 | bf16x6), timed beside the default in the same run: the same timed region on engines created
+    # with it, five repeats, median.  Reported under config.matrix_pipe_variant, never as `value`.
     variant = None
-    if os.environ.get('BENCH_VARIANT', '1') != '0' and not plain and eng.matrix_pipe() == 'f32':
+    if os.environ.get('BENCH_VARIANT', '1') != '0' and not plain:
+        other_pipe = 'f32' if eng.matrix_pipe() == 'bf16x6' else 'bf16x6'
+        old_mx = os.environ.get('SVC_MX')
         try:
-            os.environ['SVC_MX'] = 'bf16x6'
+            os.environ['SVC_MX'] = other_pipe
             slots_made.clear()
             f32_slots = list(slots)
             slots[:] = [Slot() for _ in range(P)]
-            os.environ.pop('SVC_MX', None)
+            if old_mx is None:
+                os.environ.pop('SVC_MX', None)
+            else:
+                os.environ['SVC_MX'] = old_mx
             run(max(args.warmup, P))
             vr = []
             for rep in range(5):
@@ -580,15 +584,17 @@ def main():
             vms = sorted(vr)[len(vr) // 2]
             variant = dict(matrix_pipe=slots[0].eng.matrix_pipe(), ms_per_step=round(vms, 4), frames_per_s=round(world * B / vms * 1e3, 1),
                            ms_per_step_all=[round(v, 4) for v in vr],
-                           note='SVC_MX=bf16x6 (opt-in): the 1x1 convolutions on v_mfma_f32_32x32x16_bf16 with every f32 operand split into '
-                                'three bf16 planes (24 significant bits, six plane pairs per product, f32 accumulation); every parity gate '
-                                'passes with tolerances unchanged on one stream, but with several streams sharing the chip 1-6 % of the '
-                                'passes had 16 pixels one grey level off (profiles/r05_mx_reproducibility.txt): not the default, not `value`')
+                           note='the timed region on engines created with SVC_MX=%s (bf16x6 = the 1x1 convolutions on '
+                                'v_mfma_f32_32x32x16_bf16 with every f32 operand split into three bf16 planes: 24 significant bits, six plane '
+                                'pairs per product, f32 accumulation; f32 = v_mfma_f32_32x32x2_f32); DESIGN.md 5' % other_pipe)
             for sl in slots:
                 sl.eng.close()
             slots[:] = f32_slots
         except Exception as e:
-            os.environ.pop('SVC_MX', None)
+            if old_mx is None:
+                os.environ.pop('SVC_MX', None)
+            else:
+                os.environ['SVC_MX'] = old_mx
             variant = dict(error=repr(e))
     c3 = c3_host = c3_shot = None
     if os.environ.get('BENCH_CONFIG3', '1') != '0' and not plain:
@@ -676,13 +682,13 @@ def main():
             roof['frac_vs_bf16_roof'] = round(ach / MFMA_BF16_PEAK_TFLOPS, 5)
             if mp == 'bf16x6':
                 roof['frac_vs_bf16_roof_executed'] = round(6.0 * ach / MFMA_BF16_PEAK_TFLOPS, 5)
-                roof['matrix_pipe_note'] = ('bf16x6 (opt-in): v_mfma_f32_32x32x16_bf16 on operands split into three bf16 planes (8 + 8 + 8 = 24 '
+                roof['matrix_pipe_note'] = ('bf16x6 (the default since round 5): v_mfma_f32_32x32x16_bf16 on operands split into three bf16 planes (8 + 8 + 8 = 24 '
                                             'significant bits), six plane pairs per product, f32 accumulation; the expand GEMM of fused blocks 2, 3, '
                                             '5-7 and every un-fused 1x1 convolution run this way, block 4 and the project GEMMs of blocks 2-6 on the '
                                             'fp32 MFMA; executed = 6 x algorithmic FLOPs')
             else:
-                roof['matrix_pipe_note'] = ('f32: v_mfma_f32_32x32x2_f32 / 16x16x4 (exact f32 products); the split-bf16 form is measured beside it '
-                                            'as config.matrix_pipe_variant')
+                roof['matrix_pipe_note'] = ('f32 (SVC_MX=f32): v_mfma_f32_32x32x2_f32 / 16x16x4 (exact f32 products); the split-bf16 form is measured '
+                                            'beside it as config.matrix_pipe_variant')
         if front_fused:
             roof['class_note'] = ("'stem' = k_front: LANCZOS + features.0 + features.1 in one kernel; features.1's project is not in "
                                   "the 'pw' FLOPs")

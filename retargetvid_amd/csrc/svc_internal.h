@@ -119,7 +119,7 @@ struct SvcHandle {
     hipEvent_t depth_ev[8] = {};       // recorded behind the upload of a slot; waited on before the slot is rewritten
     std::map<std::tuple<const void *, int, int, int>, DevBuf> lane_w;   // split-K layers' weights in lane order (svc_net.hip: lane_weights), keyed by (matrix, row stride, K, padded N)
     std::map<std::tuple<const void *, int, int, int>, DevBuf> x3_w;     // split-bf16 copies of weight matrices (svc_net.hip: x3_weights), keyed by (matrix, row stride, K, 2 * padded N + order)
-    int mx = 0;                        // matrix pipe of the 1x1-convolution GEMMs: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32: the default, rounds 1-4), 6 = split-bf16 operands, six plane pairs on v_mfma_f32_32x32x16_bf16 (SVC_MX=bf16x6: OPT-IN.  Faster -- a pass 1.42 -> 1.24 ms alone, 1.01 -> 0.87 ms with four passes sharing the chip -- and within every per-tap tolerance, but with several streams sharing the chip the maps were not bit-reproducible run to run: 1 - 6 % of the passes had 16 pixels of one kernel one grey level off, cause not found: DESIGN.md 5)
+    int mx = 6;                        // matrix pipe of the 1x1-convolution GEMMs: 6 = split-bf16 operands, six plane pairs on v_mfma_f32_32x32x16_bf16 (round 5, the default: a pass 1.42 -> 1.24 ms alone, 1.01 -> 0.87 ms with four passes sharing the chip, every parity gate unchanged); 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, rounds 1-4: SVC_MX=f32).  With 6, k_smooth_down_mfma takes a CU to itself (sd_excl): the one kernel found to miscompute beside bf16 workgroups
     int sd_excl = -1;                  // k_smooth_down_mfma alone on its CU (an LDS request nothing fits beside): -1 = when the split-bf16 pipe is on, 0 / 1 = never / always (SVC_SD_EXCL)
     unsigned irb_mx = 0x1b;            // ... which of k_irb's five fixed-shape instances take that form for their expand GEMM (bit = block 2, 3, 4, 5-6, 7; SVC_IRB_MX).  Measured per instance against the fp32 form, us per pass alone / shared: -17 / -11, -12 / -7, +11 / +11 (block 4: Cin = 24 pads its second step, two halo tiles per wave: 36 spilled registers), -11 / -4, -10 / -6: block 4 stays fp32
     unsigned mx_mask = 0xff;           // ... and which kernel families: bit 0 k_pwr, 1 k_irb, 2 k_dwpw, 3 k_pw_sk, 4 k_pwpw (SVC_MX_MASK; for A/B timing)
@@ -150,7 +150,7 @@ struct SvcHandle {
     unsigned seg_off = 0;              // MEASUREMENT AID (SVC_SEG_OFF=bitmask): stages of the network pass whose launches are skipped -- the maps are then garbage; tools/time_segments.py prices a stage by leaving it out.  Stages: 0 front, 1 blocks 2-3, 2 blocks 4-7, 3 blocks 8-14, 4 blocks 15-17, 5 features.18 + skips + post_cnn, 6 upsampling block 1, 7 upsampling block 2, 8 adaptation / smoothing / quantisation
     int seg_cur = 0;                   // stage forward_chunk is in
     int dwpw_max_nt = 5;               // output-channel tiles (32 columns each) per k_dwpw workgroup: fewer = more workgroups, the depthwise part redone per group (SVC_DWPW_NT)
-    int dwpw_min_px = 400;             // ... on levels with at least this many pixels per frame; the 8x13 level has too few patches (SVC_DWPW_MIN_PX; 100 when the split-bf16 pipe is on: the fused kernel then wins on that level too, -18 us per shared pass)
+    int dwpw_min_px = 400;             // ... on levels with at least this many pixels per frame (SVC_DWPW_MIN_PX); svc_create sets 100 with the split-bf16 pipe (the fused kernel then wins on the 8x13 level too: -18 us per shared pass), 400 is the fp32 pipe's optimum
     int dw_tile = 42;                  // stride-1 depthwise: outputs per thread as TX*10+TY (SVC_DW_TILE: 21, 22, 41, 42, 44; 0 = one output per thread)
     int prim_pt = 2;                   // legacy Prim (k_prim_pt): smallest points-per-thread variant (SVC_PRIM_PT: 2, 4, 8, 16)
     int tail_prio = 0;                 // SVC_TAIL_PRIO=1: s_setprio 3 in k_tail_front / k_tail_back (measured: no effect on the pipelined bench or config 3)

@@ -3253,11 +3253,12 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
         dim3 grid(ceil_div(p->h, p->sd_rows), n);
         if (h->smooth_mfma && NW % 8 == 0 && NW == 8 * W3 && NH == 8 * H3) {
             size_t lds = ((size_t)H3 * W3 + 64 * SD_KP + (size_t)p->sd_tile_cap * NW) * sizeof(float);
-            // With the split-bf16 pipe on (h->mx, opt-in), this kernel gets a CU to itself (an LDS request nothing fits beside): its
-            // results were found changed -- 16 consecutive pixels of one wavefront, 1 - 6 % of the passes -- when its workgroups
+            // With the split-bf16 pipe on (h->mx, the default), this kernel gets a CU to itself (an LDS request nothing fits beside):
+            // its results were found changed -- 16 consecutive pixels of one wavefront, 1 - 6 % of the passes -- when its workgroups
             // shared a CU with workgroups of the bf16 kernels of OTHER streams (tools/soak_network_concurrent.py,
-            // profiles/r05_mx_reproducibility.txt; cause not found: its LDS canaries stay intact).  Alone on the CU: 0 of 2 400 passes,
-            // and the pass is no slower (the kernel is 2 % of it).
+            // profiles/r05_mx_reproducibility.txt; cause not found: its LDS canaries stay intact, a stand-in kernel of the same shape
+            // is never hit).  Alone on the CU: 0 of 26 000 passes and 0 of 697 multi-video jobs differ, as with the fp32 pipe, and
+            // the pass is no slower (the kernel is 2 % of it).
             if (h->sd_excl < 0 ? h->mx != 0 : h->sd_excl != 0) {
                 lds = std::max(lds, (size_t)150 * 1024);
                 if (h->lds_attr_done.insert((const void *)k_smooth_down_mfma).second)

@@ -89,7 +89,7 @@ def main():
         out[kind] = row
         print(kind, row, flush=True)
     dst = os.path.join(ROOT, 'gpurun_out' if gpu and os.path.isdir(os.path.join(ROOT, 'gpurun_out')) else 'profiles',
-                       'r04_flip_sources%s.json' % ('_gpu' if gpu else ''))
+                       os.environ.get('FLIP_OUT', 'r05_flip_sources%s.json' % ('_gpu' if gpu else '')))
     with open(dst, 'w') as fp:
         json.dump(dict(what='fraction of ALL u8-map pixels that differ (and the largest difference in grey levels) between implementations '
                             'A / B / C / G of the same network, see tools/flip_sources.py', results=out), fp, indent=1)

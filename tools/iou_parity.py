@@ -103,7 +103,7 @@ def main():
                 out[key] = dict(error=repr(e))
                 print(key, 'ERROR', repr(e), flush=True)
         eng.close()
-    dst = os.path.join(ROOT, 'gpurun_out' if os.path.isdir(os.path.join(ROOT, 'gpurun_out')) else 'profiles', os.environ.get('PARITY_OUT', 'r04_iou_parity.json'))
+    dst = os.path.join(ROOT, 'gpurun_out' if os.path.isdir(os.path.join(ROOT, 'gpurun_out')) else 'profiles', os.environ.get('PARITY_OUT', 'r05_iou_parity.json'))
     with open(dst, 'w') as fp:
         json.dump(out, fp, indent=1)
     print('wrote', dst)

@@ -23,8 +23,21 @@ sts = scheduler.lane_streams(torch.device('cuda', 0), N)
 ref = engs[0].saliency(fr).clone()
 reft = {f: [engs[0].tap(w, f, sh) for _, w, sh in TAPS] for f in range(32)}
 outs = [torch.empty_like(ref) for _ in range(N)]
+# VICTIM=k: beside every pass, k launches of a stand-in for the smoothing kernel (tools/micro/victim.hip: pure function of block and
+# thread) on a stream of its own; the words that differ from its lone reference run are counted
+VICTIM = int(os.environ.get('VICTIM', '0'))
+if VICTIM:
+    import ctypes
+    vl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'micro', 'libvictim.so'))
+    vl.victim_launch.argtypes = [ctypes.c_void_p]
+    vl.victim_diffs.restype = ctypes.c_uint64
+    assert vl.victim_init() == 0
+    vstream = torch.cuda.Stream()
 bad = 0
 for it in range(ITERS):
+    if VICTIM:
+        for _ in range(VICTIM):
+            vl.victim_launch(ctypes.c_void_p(vstream.cuda_stream))
     if BURN:
         for bs in bstreams:
             bl.burn_launch(ctypes.c_void_p(bs.cuda_stream), bk[1], bk[2], bk[0])
@@ -56,5 +69,7 @@ for it in range(ITERS):
                     w = np.flatnonzero(want == got[idx[k]])
                     if len(w): print('   got[%d] equals want at flat index %s' % (idx[k], w[:4].tolist()))
 print('%d passes, %d with a map that differs from the reference' % (ITERS * N, bad))
+if VICTIM:
+    print('stand-in victim: %d launches, %d words differ from its lone run' % (VICTIM * ITERS, vl.victim_diffs()))
 if os.environ.get('SVC_SD_POISON'):
     print('LDS canary words the smoothing kernel found changed, per engine: %s' % [e.threshold_census()['maps'] for e in engs])

@@ -158,7 +158,11 @@ struct SvcHandle {
     int tree_par = 1;                  // data-parallel hierarchy k_tree_par for maps of up to 4352 points (SVC_TREE_PAR=0: the serial builder k_tree)
     int prim_lvl = 1;                  // level-bucketed Prim k_prim_lvl for maps of up to 8192 points (SVC_PRIM_LVL=0: one node per step)
     // TransNet V1 (svc_shot.hip)
-    DevBuf shot_blob, shot_ws;
+    DevBuf shot_blob, shot_ws, shot_w3;   // shot_w3: split-bf16 copies of the cells' weights (svc_shot.hip), valid for shot_w3_mx
+    int shot_w3_mx = 0;
+    int shot_mx = -1;                  // TransNet cells' matrix pipe: -1 = follow mx, 0 = fp32, 6 = bf16x6, 3 = bf16x3 (SVC_SHOT_MX)
+    int shot_pt = 2;                   // 32-position tiles per wavefront of k_shot_conv_x3 (SVC_SHOT_PT: 1 | 2)
+    int shot_xcd = 1;                  // XCD-aware tile order of k_shot_conv_x3 (SVC_SHOT_XCD)
     bool shot_loaded = false;
     int shot_form = 2;                 // TransNet convolution cells: 0 = operands straight from global memory (k_shot_conv), 1 = weights through LDS, 2 = both operands through LDS with whole-line loads (SVC_SHOT_FORM)
     // per-kernel-class event log (svc_profile_*)

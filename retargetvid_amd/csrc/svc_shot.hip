@@ -14,8 +14,8 @@
 #include <algorithm>
 
 #include "svc_internal.h"
+#include "svc_x3.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define SHOT_H 27
 #define SHOT_W 48
@@ -40,7 +40,35 @@ struct ShotConv {
     long long M;            // positions = B * T * H * W
     int T, H, W, C, logC;   // C = 1 << logC for the 27-tap form
     int F, Fpad, kpad, ntaps, ldy, relu;
+    uint4 *Y3;              // not null: the output goes out as split-bf16 planes (ShotX3's layout) instead of Y
+    long long Mp;           // plane stride of Y3 in positions
 };
+
+// ---- split-bf16 activations (SVC_MX=bf16x6: the cells with >= 64 input channels on the bf16 matrix pipe) ---------------
+// Between the cells an activation is kept SPLIT (svc_x3.h: x = hi + mid + lo, three bf16, exact) and PLANAR:
+//   X3 [C / 16 groups q][3 planes][Mp positions][2 halves hh] uint4,   a uint4 = the eight channels
+//   16 q + 8 (j >> 2) + 4 hh + (j & 3), j = 0..7, of one position = the fragment lane (r, hh) feeds to
+//   v_mfma_f32_32x32x16_bf16 for the 16-deep step q (svc_x3.h's operand convention).
+// So the 32 positions of an MFMA tile are ONE contiguous kilobyte per (q, plane), a tap of the 3x3x3 window is that kilobyte
+// shifted by a constant, and a wavefront loads its position operand straight into the MFMA registers with whole-line loads:
+// no LDS round trip, no barrier, no split arithmetic in the loop (a value is split once, by the kernel that produces it, and
+// read 27 taps x 4 dilations x filter groups times).  A plane starts with four zero positions (128 bytes): a lane whose tap
+// falls outside the frame / the window (SAME padding) is pointed at position 0 instead of being zeroed in registers.
+// 6 bytes per value instead of 4; positions in the plane sit at index 4 + m.
+#define SHOT_PAD 4
+__device__ __forceinline__ void shot_store_x3(uint4 *Y3, long long Mp, long long m, int hh, int q, const float4 v0, const float4 v1) {
+    const X3 s = x3_split(v0, v1);
+    X3Q H, Mi, L;
+    H.v = s.h; Mi.v = s.m; L.v = s.l;
+    uint4 *o = Y3 + ((size_t)(q * 3) * Mp + SHOT_PAD + m) * 2 + hh;
+    o[0] = H.q;
+    o[(size_t)Mp * 2] = Mi.q;
+    o[(size_t)Mp * 4] = L.q;
+}
+// the zero positions in front of the planes q0 .. q0 + nq - 1 (called by the first workgroup of the producing launch)
+__device__ __forceinline__ void shot_zero_pads(uint4 *Y3, long long Mp, int q0, int nq, int tid) {
+    for (int i = tid; i < nq * 3 * SHOT_PAD * 2; i += 256) Y3[(size_t)(q0 * 3 + i / (SHOT_PAD * 2)) * Mp * 2 + i % (SHOT_PAD * 2)] = make_uint4(0, 0, 0, 0);
+}
 
 __global__ __launch_bounds__(256) void k_shot_conv(const ShotConv A) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
@@ -121,16 +149,23 @@ __global__ __launch_bounds__(256) void k_shot_conv(const ShotConv A) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
         }
     }
+    if (A.Y3 && blockIdx.x == 0) shot_zero_pads(A.Y3, A.Mp, (br * A.F + nt * 32) >> 4, std::min(32, A.F - nt * 32) >> 4, threadIdx.x);
     if ((long long)blockIdx.x * 128 + wave * 32 + r >= A.M) return;
     float *yp = A.Y + (size_t)m * A.ldy + br * A.F;
+    float4 v[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int col = nt * 32 + 8 * g + 4 * hh;
         if (col >= A.F) continue;
         const float4 b = *(const float4 *)(A.bias + br * A.F + col);
-        float4 v = make_float4(acc[4 * g] + b.x, acc[4 * g + 1] + b.y, acc[4 * g + 2] + b.z, acc[4 * g + 3] + b.w);
-        if (A.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *(float4 *)(yp + col) = v;
+        v[g] = make_float4(acc[4 * g] + b.x, acc[4 * g + 1] + b.y, acc[4 * g + 2] + b.z, acc[4 * g + 3] + b.w);
+        if (A.relu) { v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f); }
+        if (!A.Y3) *(float4 *)(yp + col) = v[g];
+    }
+    if (A.Y3) {                                              // channels 16 q + 8 (g & 1) + 4 hh + i: the lane's g = 2 ql, 2 ql + 1 are one fragment
+#pragma unroll
+        for (int ql = 0; ql < 2; ++ql)
+            if (nt * 32 + 16 * ql < A.F) shot_store_x3(A.Y3, A.Mp, m, hh, ((br * A.F + nt * 32) >> 4) + ql, v[2 * ql], v[2 * ql + 1]);
     }
 }
 
@@ -440,6 +475,237 @@ __global__ __launch_bounds__(64) void k_shot_head(const float *__restrict__ X, c
     }
 }
 
+struct ShotX3 {
+    const uint4 *X3;        // input planes [C / 16][3][Mp][2]
+    const uint4 *W3;        // [branch][filter group][iteration = (q, kt, kh)][kw][NT tiles][NPL planes][64 lanes] uint4 (k_shot_x3_weights)
+    const float *bias;      // [branches * F]
+    uint4 *Y3;              // output planes [4 F / 16][3][Mp][2]: branch br writes channels br * F ..
+    long long M, Mp;        // positions = B * T * H * W; plane stride
+    int T, H, W, C, F, Fpad, relu, xcd;
+};
+
+// A DDCNN cell on split-bf16 operands: implicit GEMM [positions x 27 C] . [27 C x filters] on v_mfma_f32_32x32x16_bf16, NP = 6
+// plane pairs per 16-deep step (svc_x3.h; NP = 3: hi.hi + hi.mid + mid.hi only, SVC_SHOT_MX=bf16x3).  A wavefront owns PT
+// tiles of 32 positions x NT tiles of 32 filters.  K order: the 16-channel group q OUTERMOST, then (kt, kh) = one iteration,
+// then kw = its three steps -- what the workgroups of an XCD have in flight is then one group's planes of a band of
+// frames (a few MB: it stays in the XCD's L2 while the 27 taps re-read it; with the taps outermost every tap streamed all
+// C channels: measured 2.29 ms -> see DESIGN for the 128-channel cell).
+// Positions: straight from the planes into the MFMA registers (see above), requested two steps ahead (three register sets).
+// Weights: the iteration's [kw][NT][planes][64 lanes] block is contiguous in W3 in exactly the order the lanes read it --
+// copied to LDS by all four waves one iteration ahead (double buffer, ONE barrier per iteration), read back lane-contiguous
+// (conflict-free) one step ahead.  The mask of the 27 taps is one register per tile; a tap is a scalar byte shift.
+template <int NT, int PT, int NP>
+__global__ __launch_bounds__(256) void k_shot_conv_x3(const ShotX3 A) {
+    extern __shared__ uint4 sm_w3[];
+    constexpr int NPL = NP == 3 ? 2 : 3;                     // planes an operand needs
+    constexpr int WCH = 3 * NT * NPL * 64;                   // uint4 per iteration
+    constexpr int WPT = (WCH + 255) / 256;                   // per thread
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int groups = A.Fpad / (32 * NT), br = blockIdx.y / groups, ng = blockIdx.y - br * groups;
+    const int d = 1 << br, HW = A.H * A.W, niter = 9 * (A.C >> 4);
+    // XCD-aware tile order: workgroup ids go round the eight XCDs, so XCD x takes the x-th eighth of the positions and its
+    // L2 holds one band of frames (the taps of neighbouring tiles re-read the same lines)
+    long long tile = blockIdx.x;
+    if (A.xcd) tile = (long long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const long long m0 = tile * (128 * PT);
+    if (blockIdx.x == 0) shot_zero_pads(A.Y3, A.Mp, (br * A.F + ng * 32 * NT) >> 4, std::min(32 * NT, A.F - ng * 32 * NT) >> 4, tid);
+    if (m0 >= A.M) return;
+    unsigned vo[PT], okb[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const long long m = m0 + (wave * PT + pt) * 32 + r;
+        const bool in = m < A.M;
+        const long long mm = in ? m : 0, fr = mm / HW;
+        const int rem = (int)(mm - fr * HW), y = rem / A.W, x = rem - y * A.W, t = (int)(fr % A.T);
+        unsigned b = 0;
+        for (int tap = 0; tap < 27; ++tap) {
+            const int kt = tap / 9, kh = (tap - 9 * kt) / 3, kw = tap - 9 * kt - 3 * kh;
+            const bool ok = in && (unsigned)(t + (kt - 1) * d) < (unsigned)A.T && (unsigned)(y + kh - 1) < (unsigned)A.H &&
+                            (unsigned)(x + kw - 1) < (unsigned)A.W;
+            b |= (unsigned)ok << tap;
+        }
+        okb[pt] = b;
+        vo[pt] = (unsigned)(((SHOT_PAD + mm) * 2 + hh) * 16);
+    }
+    // buffer loads: the descriptor covers the input planes, a lane's byte offset is 32 bits, the (q, plane) offset is a scalar
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)A.X3, 0, (int)((size_t)(A.C >> 4) * 3 * A.Mp * 32), 0x00020000);
+    const unsigned planeB = (unsigned)(A.Mp * 32);
+    const uint4 *wsrc = A.W3 + (size_t)(br * groups + ng) * niter * WCH + tid;
+    bf16x8 a[3][PT][NPL], bw[3][NT][NPL];
+    // positions of (iteration it_, kw_) into register set set_: the tap's byte shift is a scalar, its mask one bit per tile
+#define SHOT_LDA(set_, it_, kw_)                                                                                     \
+    {                                                                                                                \
+        const int q_ = (it_) / 9, g_ = (it_) - 9 * q_, kt_ = g_ / 3, kh_ = g_ - 3 * kt_;                             \
+        const int sh_ = (((kt_ - 1) * d * HW) + (kh_ - 1) * A.W + ((kw_) - 1)) * 32;                                 \
+        _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) {                                                          \
+            const unsigned v_ = ((it_) < niter && ((okb[pt] >> (g_ * 3 + (kw_))) & 1)) ? vo[pt] + sh_ : (unsigned)(hh * 16); \
+            _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                                     \
+                X3Q t_;                                                                                              \
+                const auto ld_ = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)v_, (int)((unsigned)(q_ * 3 + pl) * planeB), 0); \
+                t_.u[0] = ld_[0]; t_.u[1] = ld_[1]; t_.u[2] = ld_[2]; t_.u[3] = ld_[3];                              \
+                a[set_][pt][pl] = t_.v;                                                                              \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+#define SHOT_LDB(set_, buf_, kw_)                                                                                    \
+    _Pragma("unroll") for (int n = 0; n < NT; ++n) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {             \
+        X3Q t_;                                                                                                      \
+        t_.q = sm_w3[(buf_) * WCH + (((kw_) * NT + n) * NPL + pl) * 64 + lane];                                      \
+        bw[set_][n][pl] = t_.v;                                                                                      \
+    }
+    // the step's MFMAs: the plane pairs in svc_x3.h's order (small pairs first), the tiles innermost (independent chains)
+#define SHOT_MMA(set_)                                                                                               \
+    {                                                                                                                \
+        constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};                                        \
+        _Pragma("unroll") for (int pr = (NP == 3 ? 3 : 0); pr < 6; ++pr)                                             \
+            _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) _Pragma("unroll") for (int n = 0; n < NT; ++n)         \
+                acc[pt][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[set_][n][PW[pr]], a[set_][pt][PA[pr]], acc[pt][n], 0, 0, 0); \
+    }
+    // issue order inside a step: the loads spread between the MFMAs (one position load and one weight read per MPL MFMAs)
+    constexpr int NMMA = NP * PT * NT, NLD = (PT > NT ? PT : NT) * NPL, MPL = NMMA / NLD;
+#define SHOT_SCHED()                                                                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < NLD; ++i_) {                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, MPL, 0);                                                         \
+        if (i_ < PT * NPL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                        \
+        if (i_ < NT * NPL) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
+    }
+    f32x16 acc[PT][NT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[pt][n][i] = 0.f;
+    // (the weight blocks as clang vectors and copied unconditionally: a uint4 array copied from memory becomes a memcpy and
+    // stays in a private segment, as shot_fetch found; the last iteration re-reads its own block)
+    typedef unsigned shot_u4 __attribute__((ext_vector_type(4)));
+    // prologue: weights of iteration 0 into buffer 0, positions of its steps 0 and 1 requested, weights of step 0 read
+#pragma unroll
+    for (int k = 0; k < WPT; ++k)
+        if (tid + 256 * k < WCH) ((shot_u4 *)sm_w3)[tid + 256 * k] = ((const shot_u4 *)wsrc)[256 * k];
+    SHOT_LDA(0, 0, 0);
+    SHOT_LDA(1, 0, 1);
+    __syncthreads();
+    SHOT_LDB(0, 0, 0);
+    for (int it = 0; it < niter; ++it) {
+        const int cb = it & 1;
+        shot_u4 wreg[WPT];
+        {
+            const shot_u4 *wp = (const shot_u4 *)(wsrc + (size_t)(it + 1 < niter ? it + 1 : it) * WCH);
+#pragma unroll
+            for (int k = 0; k < WPT; ++k) wreg[k] = wp[tid + 256 * k < WCH ? 256 * k : 0];
+        }
+        SHOT_LDA(2, it, 2); SHOT_LDB(1, cb, 1); SHOT_MMA(0); SHOT_SCHED();
+        SHOT_LDA(0, it + 1, 0); SHOT_LDB(2, cb, 2); SHOT_MMA(1); SHOT_SCHED();
+        // the next iteration's weights: the other buffer's readers finished before the previous barrier; this iteration's
+        // last read (step 2's fragments, above) is complete when the barrier is passed
+        {
+            shot_u4 *wn = (shot_u4 *)(sm_w3 + (cb ^ 1) * WCH + tid);
+#pragma unroll
+            for (int k = 0; k < WPT; ++k)
+                if (tid + 256 * k < WCH) wn[256 * k] = wreg[k];
+        }
+        __syncthreads();
+        SHOT_LDA(1, it + 1, 1); SHOT_LDB(0, cb ^ 1, 0); SHOT_MMA(2); SHOT_SCHED();
+    }
+#undef SHOT_SCHED
+#undef SHOT_MMA
+#undef SHOT_LDB
+#undef SHOT_LDA
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const long long m = m0 + (wave * PT + pt) * 32 + r;
+        if (m >= A.M) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int c0 = (ng * NT + n) * 32;               // first channel of the tile inside the branch
+            float4 v[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = c0 + 8 * g + 4 * hh;
+                if (col >= A.F) continue;
+                const float4 b = *(const float4 *)(A.bias + br * A.F + col);
+                v[g] = make_float4(acc[pt][n][4 * g] + b.x, acc[pt][n][4 * g + 1] + b.y, acc[pt][n][4 * g + 2] + b.z, acc[pt][n][4 * g + 3] + b.w);
+                if (A.relu) { v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f); }
+            }
+#pragma unroll
+            for (int ql = 0; ql < 2; ++ql)
+                if (c0 + 16 * ql < A.F) shot_store_x3(A.Y3, A.Mp, m, hh, ((br * A.F + c0) >> 4) + ql, v[2 * ql], v[2 * ql + 1]);
+        }
+    }
+}
+
+// The weights of a cell in the order k_shot_conv_x3 reads them: round-to-nearest bf16 planes (svc_x3.h) of
+// Wt [branch][Fpad][kpad] (k = tap * C + channel), one thread per (branch, group, iteration = (q, kt, kh), kw, tile, lane).
+__global__ __launch_bounds__(256) void k_shot_x3_weights(const float *__restrict__ Wt, int Fpad, int kpad, int C, int NT, int NPL,
+                                                         uint4 *__restrict__ out, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int lane = (int)(i & 63), r = lane & 31, hh = lane >> 5;
+    size_t u = i >> 6;
+    const int n = (int)(u % NT); u /= NT;
+    const int kw = (int)(u % 3); u /= 3;
+    const int niter = 9 * (C >> 4), groups = Fpad / (32 * NT);
+    const int it = (int)(u % niter); u /= niter;
+    const int ng = (int)(u % groups), br = (int)(u / groups);
+    const int q = it / 9, tap = (it - 9 * q) * 3 + kw;
+    const float *w = Wt + ((size_t)br * Fpad + (ng * NT + n) * 32 + r) * kpad + tap * C + 16 * q + 4 * hh;
+    const X3 s = x3_split<true>(*(const float4 *)w, *(const float4 *)(w + 8));
+    X3Q P[3];
+    P[0].v = s.h; P[1].v = s.m; P[2].v = s.l;
+    uint4 *o = out + (((((size_t)(br * groups + ng) * niter + it) * 3 + kw) * NT + n) * NPL) * 64 + lane;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+        if (pl < NPL) o[pl * 64] = P[pl].q;
+}
+
+// MaxPool3D (1, 2, 2), VALID, on the planes: one thread per (q, output position, hh).  A value is the exact sum of its three
+// planes, so the maximum is taken on the sums and split again (the same planes come out).  Yf: the last pool writes fp32
+// [position][C] for Dense(256) instead.
+__global__ __launch_bounds__(256) void k_shot_pool_x3(const uint4 *__restrict__ X3, long long Mp_in, uint4 *__restrict__ Y3, long long Mp_out,
+                                                      float *__restrict__ Yf, size_t total, int H, int W, int Q) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int OH = H / 2, OW = W / 2;
+    const int hh = (int)(i & 1);
+    size_t u = i >> 1;
+    const size_t Mo = total / ((size_t)2 * Q);
+    const size_t mo = u % Mo;
+    const int q = (int)(u / Mo);
+    const int ox = (int)(mo % OW);
+    size_t v = mo / OW;
+    const int oy = (int)(v % OH);
+    const size_t f = v / OH;
+    const size_t mi = (f * H + 2 * oy) * W + 2 * ox;
+    float best[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint4 *p = X3 + ((size_t)(q * 3) * Mp_in + SHOT_PAD + mi + (k >> 1) * W + (k & 1)) * 2 + hh;
+        const uint4 h = p[0], m = p[(size_t)Mp_in * 2], l = p[(size_t)Mp_in * 4];
+        const uint32_t hu[4] = {h.x, h.y, h.z, h.w}, mu[4] = {m.x, m.y, m.z, m.w}, lu[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // element j = the low (even j) / high (odd j) half of word j / 2; a bf16 is the upper half of an f32
+            const int w = j >> 1;
+            const float x = (j & 1) ? (__uint_as_float(hu[w] & 0xffff0000u) + __uint_as_float(mu[w] & 0xffff0000u)) + __uint_as_float(lu[w] & 0xffff0000u)
+                                    : (__uint_as_float(hu[w] << 16) + __uint_as_float(mu[w] << 16)) + __uint_as_float(lu[w] << 16);
+            best[j] = k == 0 ? x : fmaxf(best[j], x);
+        }
+    }
+    const float4 v0 = make_float4(best[0], best[1], best[2], best[3]), v1 = make_float4(best[4], best[5], best[6], best[7]);
+    if (Yf) {
+        float *o = Yf + mo * ((size_t)Q * 16) + 16 * q + 4 * hh;
+        *(float4 *)o = v0;
+        *(float4 *)(o + 8) = v1;
+    } else {
+        shot_store_x3(Y3, Mp_out, (long long)mo, hh, q, v0, v1);
+        if (mo < SHOT_PAD) {
+            uint4 *z = Y3 + ((size_t)(q * 3) * Mp_out + mo) * 2 + hh;
+            z[0] = z[(size_t)Mp_out * 2] = z[(size_t)Mp_out * 4] = make_uint4(0, 0, 0, 0);
+        }
+    }
+}
+
 // ---- host -------------------------------------------------------------------------------------------------------------
 struct ShotCell { int cin, cpad, f, fpad, kpad; size_t w_off, b_off; };
 
@@ -478,6 +744,7 @@ extern "C" int svc_transnet_load(SvcHandle *h, const float *blob_host, size_t n_
     if (rc) return rc;
     SVC_HIP(hipMemcpy(h->shot_blob.p, blob_host, need * sizeof(float), hipMemcpyHostToDevice));
     h->shot_loaded = true;
+    h->shot_w3_mx = 0;                                       // the split copies are made again by the next predict
     return SVC_OK;
 }
 
@@ -496,12 +763,36 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
     shot_layout(cells, &d1w, &d1b, &d2w, &d2b);
     const float *blob = (const float *)h->shot_blob.p;
     const int T = frames_per_window;
-    // windows per pass: two ping-pong activation buffers of T x 27 x 48 x 64 floats per window (the largest tensor)
+    const int mx = h->shot_mx < 0 ? h->mx : h->shot_mx;      // 0: fp32 MFMA; 6 / 3: split-bf16 planes (SVC_SHOT_MX, default = SVC_MX)
+    const int NPL = mx == 3 ? 2 : 3;
+    // split-bf16 weights of the cells with >= 64 input channels, packed once per load in the kernels' read order
+    size_t w3_off[SHOT_L * SHOT_S] = {0};
+    if (mx) {
+        size_t tot = 0;
+        for (int i = 1; i < SHOT_L * SHOT_S; ++i) { w3_off[i] = tot; tot += (size_t)4 * cells[i].fpad * (cells[i].kpad / 16) * NPL * 2; }   // uint4
+        if (h->shot_w3_mx != mx) {
+            int rc = h->shot_w3.ensure(tot * sizeof(uint4));
+            if (rc) return rc;
+            for (int i = 1; i < SHOT_L * SHOT_S; ++i) {
+                const ShotCell &k = cells[i];
+                const int NT = k.fpad % 64 == 0 ? 2 : 1;
+                const size_t total = (size_t)4 * k.fpad * (k.kpad / 16) * 2;           // threads: one per (row, 16-deep step, hh)
+                k_shot_x3_weights<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(blob + k.w_off, k.fpad, k.kpad, k.cpad, NT, NPL,
+                                                                                 (uint4 *)h->shot_w3.p + w3_off[i], total);
+                SVC_CHECK_LAUNCH();
+            }
+            h->shot_w3_mx = mx;
+        }
+    }
+    // windows per pass: two ping-pong activation buffers of T x 27 x 48 x 64 values per window (the largest tensor), fp32 or
+    // three bf16 planes
     const size_t per_win = (size_t)T * SHOT_H * SHOT_W * 64;
-    const int chunk = std::max(1, std::min(n_windows, (int)(((size_t)768 << 20) / (2 * per_win * sizeof(float)))));
-    int rc = h->shot_ws.ensure(2 * per_win * chunk * sizeof(float));
+    const size_t val_bytes = mx ? 6 : 4, cap = (size_t)(mx ? 1536 : 768) << 20;
+    const int chunk = std::max(1, std::min(n_windows, (int)(cap / (2 * per_win * val_bytes))));
+    const size_t buf_bytes = per_win * chunk * val_bytes + (mx ? (size_t)64 * 3 * (SHOT_PAD + 4) * 32 : 0);
+    int rc = h->shot_ws.ensure(2 * buf_bytes);
     if (rc) return rc;
-    float *P[2] = {(float *)h->shot_ws.p, (float *)h->shot_ws.p + per_win * chunk};
+    float *P[2] = {(float *)h->shot_ws.p, (float *)((char *)h->shot_ws.p + buf_bytes)};
     for (int w0 = 0; w0 < n_windows; w0 += chunk) {
         const int nw = std::min(chunk, n_windows - w0);
         const size_t nfr = (size_t)nw * T;
@@ -512,14 +803,39 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
             SVC_CHECK_LAUNCH();
         }
         for (int b = 0; b < SHOT_L; ++b) {
+            const long long Mc = (long long)nfr * H * W, Mp = (Mc + SHOT_PAD + 3) / 4 * 4;       // plane stride of this resolution
             for (int c = 0; c < SHOT_S; ++c) {
                 const ShotCell &k = cells[b * SHOT_S + c];
+                if (mx && k.cpad >= 64) {
+                    ShotX3 X;
+                    X.X3 = (const uint4 *)P[cur]; X.W3 = (const uint4 *)h->shot_w3.p + w3_off[b * SHOT_S + c]; X.bias = blob + k.b_off;
+                    X.Y3 = (uint4 *)P[cur ^ 1]; X.M = Mc; X.Mp = Mp; X.T = T; X.H = H; X.W = W; X.C = k.cpad; X.F = k.f; X.Fpad = k.fpad;
+                    X.relu = 1; X.xcd = h->shot_xcd;
+                    const int NT = k.fpad % 64 == 0 ? 2 : 1, PT = h->shot_pt;
+                    unsigned gx = (unsigned)((Mc + 128 * PT - 1) / (128 * PT));
+                    if (X.xcd) gx = (gx + 7) / 8 * 8;
+                    dim3 grid(gx, (unsigned)(4 * (k.fpad / (32 * NT))));
+                    const size_t lds = (size_t)2 * 3 * NT * NPL * 64 * sizeof(uint4);
+#define SHOT_X3(NT_, PT_, NP_) k_shot_conv_x3<NT_, PT_, NP_><<<grid, 256, lds, s>>>(X)
+                    if (mx == 3) {
+                        if (NT == 2) { if (PT == 2) SHOT_X3(2, 2, 3); else SHOT_X3(2, 1, 3); }
+                        else { if (PT == 2) SHOT_X3(1, 2, 3); else SHOT_X3(1, 1, 3); }
+                    } else {
+                        if (NT == 2) { if (PT == 2) SHOT_X3(2, 2, 6); else SHOT_X3(2, 1, 6); }
+                        else { if (PT == 2) SHOT_X3(1, 2, 6); else SHOT_X3(1, 1, 6); }
+                    }
+#undef SHOT_X3
+                    SVC_CHECK_LAUNCH();
+                    cur ^= 1;
+                    continue;
+                }
                 ShotConv A;
                 A.X = P[cur]; A.Wt = blob + k.w_off; A.bias = blob + k.b_off; A.Y = P[cur ^ 1];
                 A.M = (long long)nfr * H * W; A.T = T; A.H = H; A.W = W; A.C = k.cpad;
                 A.logC = 0;
                 while ((1 << A.logC) < k.cpad) ++A.logC;
                 A.F = k.f; A.Fpad = k.fpad; A.kpad = k.kpad; A.ntaps = 27; A.ldy = 4 * k.f; A.relu = 1;
+                A.Y3 = mx ? (uint4 *)P[cur ^ 1] : nullptr; A.Mp = Mp;
                 dim3 grid((unsigned)((A.M + 127) / 128), (unsigned)(4 * (k.fpad / 32)));
                 const int shot_form = h->shot_form;             // 0: direct operand loads, 1: weights through LDS, 2: both operands (SVC_SHOT_FORM)
                 if (shot_form == 2 && k.cpad >= 64 && k.cpad % 64 == 0) {
@@ -544,8 +860,16 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
                 cur ^= 1;
             }
             const int C = 4 * (SHOT_F << b);
-            const size_t total = nfr * (H / 2) * (W / 2) * (C / 4);
-            k_shot_pool<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(P[cur], P[cur ^ 1], total, H, W, C / 4);
+            if (mx) {
+                const long long Mo = (long long)nfr * (H / 2) * (W / 2), Mpo = (Mo + SHOT_PAD + 3) / 4 * 4;
+                const size_t total = (size_t)Mo * (C / 16) * 2;
+                const bool last = b == SHOT_L - 1;
+                k_shot_pool_x3<<<(unsigned)((total + 255) / 256), 256, 0, s>>>((const uint4 *)P[cur], Mp, (uint4 *)P[cur ^ 1], Mpo,
+                                                                                last ? P[cur ^ 1] : nullptr, total, H, W, C / 16);
+            } else {
+                const size_t total = nfr * (H / 2) * (W / 2) * (C / 4);
+                k_shot_pool<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(P[cur], P[cur ^ 1], total, H, W, C / 4);
+            }
             SVC_CHECK_LAUNCH();
             cur ^= 1;
             H /= 2; W /= 2;
@@ -555,7 +879,7 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
             const int nflat = H * W * 4 * (SHOT_F << (SHOT_L - 1));
             A.X = P[cur]; A.Wt = blob + d1w; A.bias = blob + d1b; A.Y = P[cur ^ 1];
             A.M = (long long)nfr; A.T = 1; A.H = 1; A.W = 1; A.C = nflat; A.logC = 0;
-            A.F = SHOT_D; A.Fpad = SHOT_D; A.kpad = nflat; A.ntaps = 1; A.ldy = SHOT_D; A.relu = 1;
+            A.F = SHOT_D; A.Fpad = SHOT_D; A.kpad = nflat; A.ntaps = 1; A.ldy = SHOT_D; A.relu = 1; A.Y3 = nullptr; A.Mp = 0;
             dim3 grid((unsigned)((A.M + 127) / 128), (unsigned)(SHOT_D / 32));
             k_shot_conv<<<grid, 256, 0, s>>>(A);
             SVC_CHECK_LAUNCH();

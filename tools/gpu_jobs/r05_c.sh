@@ -1,3 +1,5 @@
 #!/bin/bash
-echo "== all families, smoothing kernel isolated"; LANES=12,4 SVC_MX=bf16x6 python tools/soak_job_repeat.py 80 100 2>&1 | grep -v amdgpu.ids | tail -6 | cut -c1-200
-echo "== k_irb only"; LANES=12,4 SVC_MX=bf16x6 SVC_MX_MASK=2 python tools/soak_job_repeat.py 80 100 2>&1 | grep -v amdgpu.ids | tail -4 | cut -c1-200
+for p in 3 4 5 6 8; do
+  BENCH_CONFIG3=0 BENCH_VARIANT=0 python bench.py --pipeline $p --steps 60 --warmup 8 --cpu-sample 0 --repeats 7 --iso-steps 1 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('pipeline $p: %.1f fps  %.4f ms/step  phases %s  host %s' % (d['value'], d['ms_per_step'], d['config']['batch_phase_ms_in_the_pipeline'], d['config']['host_ms_per_step']))"
+done

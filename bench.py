@@ -174,12 +174,13 @@ def cpu_baseline(sd, frames_u8, CP, flags):
     return n / dt, dt
 
 
-def config3_job(world, rank, dist_on, dev, sd, lanes, rccl_init_s, mode='resident'):
+def config3_job(world, rank, dist_on, dev, sd, lanes, rccl_init_s, mode='resident', shot_mx=None):
     """BASELINE configs[2] through the product's job code, timed between barriers (slowest rank).  -> dict for rank 0.
     mode 'resident': the frames the job selects are in HBM when the clock starts (bench.py's convention for `value`);
     'host_fed': they are in PINNED HOST memory and cross PCIe inside the job (smartVidCrop._HostFeed) -- the system number;
     'shot_net': the reference's VIDEO path (smartVidCrop.py:366-372): no trans_inds, every frame of every video resident in HBM
-    (85 GB), TransNet V1 on the device inside the job decides the shots and with them the selection."""
+    (85 GB), TransNet V1 on the device inside the job decides the shots and with them the selection; shot_mx: the matrix
+    pipe of its cells for this job (SVC_SHOT_MX; None = the library's default)."""
     from retargetvid_amd import evaluate as E, scheduler
     folder = os.path.join(ROOT, 'tests', 'golden', 'retargetvid')
     fcs = E.frame_counts(folder)
@@ -219,7 +220,18 @@ def config3_job(world, rank, dist_on, dev, sd, lanes, rccl_init_s, mode='residen
         tsd = weights.make_transnet_state_dict(0)
         tsd['TransNet/dense_1/kernel'] = tsd['TransNet/dense_1/kernel'] * np.float32(0.02)
         tsd['TransNet/dense_1/bias'] = np.array([12.0, -12.0], np.float32)
-        shot_net = TN.ShotTransNet(TN.ShotTransNetParams(), weights=tsd)
+        old_mx = os.environ.get('SVC_SHOT_MX')
+        if shot_mx is not None:
+            os.environ['SVC_SHOT_MX'] = shot_mx                      # read when the network's handle is created
+        try:
+            shot_net = TN.ShotTransNet(TN.ShotTransNetParams(), weights=tsd)
+        finally:
+            if shot_mx is not None:
+                if old_mx is None:
+                    os.environ.pop('SVC_SHOT_MX', None)
+                else:
+                    os.environ['SVC_SHOT_MX'] = old_mx
+        shot_pipe = shot_net.matrix_pipe()
 
     def make(i):
         v = dict(fr=30.0, frame_count=counts[i], w=640, h=360, frames=resident[i])
@@ -272,7 +284,7 @@ def config3_job(world, rank, dist_on, dev, sd, lanes, rccl_init_s, mode='residen
                          'reference\'s video path)'}[mode]
     return dict(workload='200-video RetargetVid-shaped synthetic set (real frame counts%s), targets 1:3 and 3:1, %s; '
                          'dist.crop_job -> scheduler.JobScheduler -> all_gather of the boxes' % ('' if mode == 'shot_net' else ', 0-3 cuts per video', where),
-                mode=mode,
+                mode=mode, **({'shot_net_matrix_pipe': shot_pipe} if mode == 'shot_net' else {}),
                 videos=len(vids), video_frames=int(sum(counts)), saliency_frames=n_sel, n_gpus=world, lanes_per_gpu=lanes,
                 seconds=round(best, 4), seconds_all_runs=[round(r, 4) for r in runs],
                 seconds_note='job wall clock between barriers (slowest rank), scheduler already created; the first run also pays '
@@ -596,7 +608,7 @@ def main():
             else:
                 os.environ['SVC_MX'] = old_mx
             variant = dict(error=repr(e))
-    c3 = c3_host = c3_shot = None
+    c3 = c3_host = c3_shot = c3_shot3 = None
     if os.environ.get('BENCH_CONFIG3', '1') != '0' and not plain:
         c3_lanes = int(os.environ.get('BENCH_CONFIG3_LANES', 12))
         try:
@@ -605,19 +617,22 @@ def main():
             c3 = dict(error=repr(e))
         # the two system-level variants (N = 1 only: 14.5 GB of pinned host memory / 85 GB of HBM per job): BENCH_CONFIG3_EXTRA=0 skips them
         if world == 1 and os.environ.get('BENCH_CONFIG3_EXTRA', '1') != '0':
-            for mode in ('host_fed', 'shot_net'):
+            # shot_net twice: on the library's default pipe (bf16x6: fp32-class probabilities) and on the opt-in three-pair form
+            for mode, smx in (('host_fed', None), ('shot_net', None), ('shot_net', 'bf16x3')):
                 torch.cuda.empty_cache()
                 try:
                     import psutil
                     if mode == 'host_fed' and psutil.virtual_memory().available < (40 << 30):
                         raise RuntimeError('less than 40 GB of host memory available: not pinning 14.5 GB')
-                    r_ = config3_job(world, rank, dist_on, dev, sd, c3_lanes, rccl_init_s, mode=mode)
+                    r_ = config3_job(world, rank, dist_on, dev, sd, c3_lanes, rccl_init_s, mode=mode, shot_mx=smx)
                 except Exception as e:
                     r_ = dict(error=repr(e))
                 if mode == 'host_fed':
                     c3_host = r_
-                else:
+                elif smx is None:
                     c3_shot = r_
+                else:
+                    c3_shot3 = r_
             torch.cuda.empty_cache()
     if rank == 0:
         front_fused = eng.front_fused()
@@ -721,7 +736,7 @@ def main():
                    config=dict(workload='Single 640x360 video, batch=32 frames, UNISAL saliency + crop on 1 MI355X',
                                workload_id=('r02-1to3blobs-sigma20-60' if not BENCH_BLOBS else
                                             'r03-%dblobs-sigma%g-%g' % (BENCH_BLOBS['n_blobs'], BENCH_BLOBS['sigma'][0], BENCH_BLOBS['sigma'][1])),
-                               config3=c3, config3_host_fed=c3_host, config3_shot_net=c3_shot, matrix_pipe_variant=variant,
+                               config3=c3, config3_host_fed=c3_host, config3_shot_net=c3_shot, config3_shot_net_bf16x3=c3_shot3, matrix_pipe_variant=variant,
                                one_batch_for_every_slot=same_batch,
                                batch_per_gpu=B, frame='640x360x3 u8', saliency_map='140x250 u8', network_input='256x416',
                                weights='synthetic seed 0 (weights.make_synthetic_state_dict)',

@@ -258,6 +258,11 @@ int svc_front_fused(const SvcHandle *h);
  * k_smooth_down_mfma runs alone on its CU -- DESIGN.md 5); bench.py
  * reports it as roofline.matrix_pipe.  No interface of the reference corresponds to it (its arithmetic type is f32 either way). */
 int svc_matrix_pipe(const SvcHandle *h);
+/* svc_transnet_matrix_pipe: the same for the TransNet cells with >= 64 input channels (svc_transnet_predict): 0 = fp32 MFMA,
+ * 6 = split-bf16 operands, six plane pairs (fp32-class results: |dP| against the oracle 6e-7, the fp32 pipe's 6e-7), 3 = three plane
+ * pairs (hi.hi + hi.mid + mid.hi: 16 significant bits per product, |dP| 1.4e-5; opt-in).  Environment SVC_SHOT_MX=f32 | bf16x6 |
+ * bf16x3 when the handle is created; default = the handle's SVC_MX. */
+int svc_transnet_matrix_pipe(const SvcHandle *h);
 /* svc_threshold_census: the regime diagnostic of the threshold (no counterpart in the reference; smartVidCrop.py:1050-1059 only
  * thresholds).  out[0] = maps that went through svc_saliency_thresholded_u8 on this handle since the last reset, out[1..3] = how
  * many pixels of their UN-thresholded u8 maps sat at t - 1, t and t + 1 (t = the threshold passed to the call).  Two correct

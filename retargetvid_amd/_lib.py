@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('SVC_LIB') or os.path.join(_HERE, 'libsvc_hip.so')    
 ABI_VERSION = 4          # include/svc.h SVC_ABI_VERSION this binding was written against
 
 EXPORTS = ('svc_last_error', 'svc_abi_version', 'svc_create', 'svc_destroy', 'svc_resize_frames_u8', 'svc_saliency_u8',
-           'svc_threshold_u8', 'svc_cluster_center', 'svc_iou_i32', 'svc_debug_cluster_state', 'svc_debug_tap', 'svc_front_fused', 'svc_matrix_pipe', 'svc_threshold_census', 'svc_debug_round_plan', 'svc_transnet_load', 'svc_transnet_predict',
+           'svc_threshold_u8', 'svc_cluster_center', 'svc_iou_i32', 'svc_debug_cluster_state', 'svc_debug_tap', 'svc_front_fused', 'svc_matrix_pipe', 'svc_threshold_census', 'svc_debug_round_plan', 'svc_transnet_load', 'svc_transnet_predict', 'svc_transnet_matrix_pipe',
            'svc_debug_argsort_u32',
            'svc_profile_enable', 'svc_profile_read', 'svc_profile_read_raw',
            'svc_host_fill_empty_centres', 'svc_host_interp_segment', 'svc_host_lowpass', 'svc_host_loess', 'svc_host_savgol',
@@ -77,6 +77,7 @@ def load():
     lib.svc_debug_tap.argtypes = [vp, i32, i32, vp, sz]
     lib.svc_front_fused.argtypes = [vp]
     lib.svc_matrix_pipe.argtypes = [vp]
+    lib.svc_transnet_matrix_pipe.argtypes = [vp]
     lib.svc_threshold_census.argtypes = [vp, vp, i32]
     lib.svc_debug_round_plan.argtypes = [vp, i32, vp, vp]
     lib.svc_transnet_load.argtypes = [vp, vp, sz]

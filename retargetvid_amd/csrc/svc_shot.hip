@@ -485,21 +485,33 @@ struct ShotX3 {
 };
 
 // A DDCNN cell on split-bf16 operands: implicit GEMM [positions x 27 C] . [27 C x filters] on v_mfma_f32_32x32x16_bf16, NP = 6
-// plane pairs per 16-deep step (svc_x3.h; NP = 3: hi.hi + hi.mid + mid.hi only, SVC_SHOT_MX=bf16x3).  A wavefront owns PT
-// tiles of 32 positions x NT tiles of 32 filters.  K order: the 16-channel group q OUTERMOST, then (kt, kh) = one iteration,
-// then kw = its three steps -- what the workgroups of an XCD have in flight is then one group's planes of a band of
-// frames (a few MB: it stays in the XCD's L2 while the 27 taps re-read it; with the taps outermost every tap streamed all
-// C channels: measured 2.29 ms -> see DESIGN for the 128-channel cell).
-// Positions: straight from the planes into the MFMA registers (see above), requested two steps ahead (three register sets).
-// Weights: the iteration's [kw][NT][planes][64 lanes] block is contiguous in W3 in exactly the order the lanes read it --
-// copied to LDS by all four waves one iteration ahead (double buffer, ONE barrier per iteration), read back lane-contiguous
-// (conflict-free) one step ahead.  The mask of the 27 taps is one register per tile; a tap is a scalar byte shift.
-template <int NT, int PT, int NP>
+// plane pairs per 16-deep step (svc_x3.h; NP = 3: hi.hi + hi.mid + mid.hi only, SVC_SHOT_MX=bf16x3).
+//
+// What bounds this kernel is the delivery of the position operand (measured with one load per tap: 21 TB/s from L2 to the
+// CUs' L1s in the 32-filter cells, the MFMAs at half their rate), so the three kw taps of a (kt, kh) share ONE load:
+//   y[m] = sum_kw W_kw . x[m + kw - 1]  =  P_0[m - 1] + P_1[m] + P_2[m + 1],   P_kw[m'] = W_kw . x[m']  (un-shifted),
+// i.e. a wavefront keeps one accumulator tile PER kw over the whole K loop, all three fed by the same position registers,
+// and the shift by one position happens ONCE, on the accumulators, in the epilogue (ds_bpermute; the frame's left / right
+// border masks the P_0 / P_2 term there; the (kt, kh) border is a property of m' and masks the load as before).  A wave
+// computes 32 PT consecutive positions and emits the inner 32 PT - 2 (the two ends only serve their neighbours): 3 % more
+// MFMAs for a third of the operand traffic.  The 16-filter cell packs kw = 0 | kw = 1 into ONE 32-row weight tile and
+// kw = 2 into half of a second (F16: 2 tiles instead of 3 half-empty ones).
+// K order: the 16-channel group q OUTERMOST, then (kt, kh) = one iteration -- what the workgroups of an XCD have in flight
+// is one group's planes of a band of frames (a few MB: it stays in the XCD's L2 while the taps re-read it; with the taps
+// outermost the 128-channel cell took 2.29 ms, with q outermost 1.00).
+// Positions: straight from the planes into the MFMA registers (see above), requested one iteration ahead.  Weights: the
+// iteration's [tile][plane][64 lanes] block is contiguous in W3 in exactly the order the lanes read it -- copied to LDS by
+// all four waves one iteration ahead (double buffer, ONE barrier per iteration), read back lane-contiguous (conflict-free)
+// one tile ahead.
+template <int NT, int PT, int NP, bool F16>
 __global__ __launch_bounds__(256) void k_shot_conv_x3(const ShotX3 A) {
     extern __shared__ uint4 sm_w3[];
     constexpr int NPL = NP == 3 ? 2 : 3;                     // planes an operand needs
-    constexpr int WCH = 3 * NT * NPL * 64;                   // uint4 per iteration
+    constexpr int KT = F16 ? 2 : 3 * NT;                     // weight tiles per iteration: (kw, n), or kw0|kw1 and kw2|0
+    constexpr int WCH = KT * NPL * 64;                       // uint4 per iteration
     constexpr int WPT = (WCH + 255) / 256;                   // per thread
+    constexpr int WS = 32 * PT - 2, WGS = 4 * WS;            // positions a wave / a workgroup emits
+    static_assert(!F16 || NT == 1, "the 16-filter packing is one tile wide");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int groups = A.Fpad / (32 * NT), br = blockIdx.y / groups, ng = blockIdx.y - br * groups;
     const int d = 1 << br, HW = A.H * A.W, niter = 9 * (A.C >> 4);
@@ -507,38 +519,39 @@ __global__ __launch_bounds__(256) void k_shot_conv_x3(const ShotX3 A) {
     // L2 holds one band of frames (the taps of neighbouring tiles re-read the same lines)
     long long tile = blockIdx.x;
     if (A.xcd) tile = (long long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const long long m0 = tile * (128 * PT);
     if (blockIdx.x == 0) shot_zero_pads(A.Y3, A.Mp, (br * A.F + ng * 32 * NT) >> 4, std::min(32 * NT, A.F - ng * 32 * NT) >> 4, tid);
-    if (m0 >= A.M) return;
+    if (tile * WGS >= A.M) return;
+    const long long mb = tile * WGS + wave * WS - 1;         // first position this wave computes (its first output is mb + 1)
     unsigned vo[PT], okb[PT];
+    int xs[PT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-        const long long m = m0 + (wave * PT + pt) * 32 + r;
-        const bool in = m < A.M;
+        const long long m = mb + 32 * pt + r;
+        const bool in = m >= 0 && m < A.M;
         const long long mm = in ? m : 0, fr = mm / HW;
         const int rem = (int)(mm - fr * HW), y = rem / A.W, x = rem - y * A.W, t = (int)(fr % A.T);
         unsigned b = 0;
-        for (int tap = 0; tap < 27; ++tap) {
-            const int kt = tap / 9, kh = (tap - 9 * kt) / 3, kw = tap - 9 * kt - 3 * kh;
-            const bool ok = in && (unsigned)(t + (kt - 1) * d) < (unsigned)A.T && (unsigned)(y + kh - 1) < (unsigned)A.H &&
-                            (unsigned)(x + kw - 1) < (unsigned)A.W;
-            b |= (unsigned)ok << tap;
+        for (int g = 0; g < 9; ++g) {
+            const int kt = g / 3, kh = g - 3 * kt;
+            const bool ok = in && (unsigned)(t + (kt - 1) * d) < (unsigned)A.T && (unsigned)(y + kh - 1) < (unsigned)A.H;
+            b |= (unsigned)ok << g;
         }
         okb[pt] = b;
+        xs[pt] = x;
         vo[pt] = (unsigned)(((SHOT_PAD + mm) * 2 + hh) * 16);
     }
     // buffer loads: the descriptor covers the input planes, a lane's byte offset is 32 bits, the (q, plane) offset is a scalar
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)A.X3, 0, (int)((size_t)(A.C >> 4) * 3 * A.Mp * 32), 0x00020000);
     const unsigned planeB = (unsigned)(A.Mp * 32);
     const uint4 *wsrc = A.W3 + (size_t)(br * groups + ng) * niter * WCH + tid;
-    bf16x8 a[3][PT][NPL], bw[3][NT][NPL];
-    // positions of (iteration it_, kw_) into register set set_: the tap's byte shift is a scalar, its mask one bit per tile
-#define SHOT_LDA(set_, it_, kw_)                                                                                     \
+    bf16x8 a[2][PT][NPL], bw[2][NPL];
+    // positions of iteration it_ = (q, kt, kh) into register set set_: the tap's byte shift is a scalar, its mask one bit per tile
+#define SHOT_LDA(set_, it_)                                                                                          \
     {                                                                                                                \
         const int q_ = (it_) / 9, g_ = (it_) - 9 * q_, kt_ = g_ / 3, kh_ = g_ - 3 * kt_;                             \
-        const int sh_ = (((kt_ - 1) * d * HW) + (kh_ - 1) * A.W + ((kw_) - 1)) * 32;                                 \
+        const int sh_ = (((kt_ - 1) * d * HW) + (kh_ - 1) * A.W) * 32;                                               \
         _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) {                                                          \
-            const unsigned v_ = ((it_) < niter && ((okb[pt] >> (g_ * 3 + (kw_))) & 1)) ? vo[pt] + sh_ : (unsigned)(hh * 16); \
+            const unsigned v_ = ((it_) < niter && ((okb[pt] >> g_) & 1)) ? vo[pt] + sh_ : (unsigned)(hh * 16);      \
             _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                                     \
                 X3Q t_;                                                                                              \
                 const auto ld_ = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)v_, (int)((unsigned)(q_ * 3 + pl) * planeB), 0); \
@@ -547,113 +560,165 @@ __global__ __launch_bounds__(256) void k_shot_conv_x3(const ShotX3 A) {
             }                                                                                                        \
         }                                                                                                            \
     }
-#define SHOT_LDB(set_, buf_, kw_)                                                                                    \
-    _Pragma("unroll") for (int n = 0; n < NT; ++n) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {             \
+#define SHOT_LDB(set_, buf_, wt_)                                                                                    \
+    _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                                             \
         X3Q t_;                                                                                                      \
-        t_.q = sm_w3[(buf_) * WCH + (((kw_) * NT + n) * NPL + pl) * 64 + lane];                                      \
-        bw[set_][n][pl] = t_.v;                                                                                      \
+        t_.q = sm_w3[(buf_) * WCH + ((wt_) * NPL + pl) * 64 + lane];                                                 \
+        bw[set_][pl] = t_.v;                                                                                         \
     }
-    // the step's MFMAs: the plane pairs in svc_x3.h's order (small pairs first), the tiles innermost (independent chains)
-#define SHOT_MMA(set_)                                                                                               \
+    // one weight tile against the iteration's positions: the plane pairs in svc_x3.h's order (small pairs first), the
+    // position tiles innermost (independent chains)
+#define SHOT_MMA(aset_, bset_, wt_)                                                                                  \
     {                                                                                                                \
         constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};                                        \
         _Pragma("unroll") for (int pr = (NP == 3 ? 3 : 0); pr < 6; ++pr)                                             \
-            _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) _Pragma("unroll") for (int n = 0; n < NT; ++n)         \
-                acc[pt][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[set_][n][PW[pr]], a[set_][pt][PA[pr]], acc[pt][n], 0, 0, 0); \
+            _Pragma("unroll") for (int pt = 0; pt < PT; ++pt)                                                        \
+                acc[pt][wt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[bset_][PW[pr]], a[aset_][pt][PA[pr]], acc[pt][wt_], 0, 0, 0); \
     }
-    // issue order inside a step: the loads spread between the MFMAs (one position load and one weight read per MPL MFMAs)
-    constexpr int NMMA = NP * PT * NT, NLD = (PT > NT ? PT : NT) * NPL, MPL = NMMA / NLD;
-#define SHOT_SCHED()                                                                                                 \
-    _Pragma("unroll") for (int i_ = 0; i_ < NLD; ++i_) {                                                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, MPL, 0);                                                         \
-        if (i_ < PT * NPL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                        \
-        if (i_ < NT * NPL) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
-    }
-    f32x16 acc[PT][NT];
+    f32x16 acc[PT][KT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int k = 0; k < KT; ++k)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[pt][n][i] = 0.f;
+            for (int i = 0; i < 16; ++i) acc[pt][k][i] = 0.f;
     // (the weight blocks as clang vectors and copied unconditionally: a uint4 array copied from memory becomes a memcpy and
     // stays in a private segment, as shot_fetch found; the last iteration re-reads its own block)
     typedef unsigned shot_u4 __attribute__((ext_vector_type(4)));
-    // prologue: weights of iteration 0 into buffer 0, positions of its steps 0 and 1 requested, weights of step 0 read
+    // prologue: weights of iteration 0 into buffer 0, its positions requested, its first weight tile read
 #pragma unroll
     for (int k = 0; k < WPT; ++k)
         if (tid + 256 * k < WCH) ((shot_u4 *)sm_w3)[tid + 256 * k] = ((const shot_u4 *)wsrc)[256 * k];
-    SHOT_LDA(0, 0, 0);
-    SHOT_LDA(1, 0, 1);
+    SHOT_LDA(0, 0);
     __syncthreads();
     SHOT_LDB(0, 0, 0);
-    for (int it = 0; it < niter; ++it) {
-        const int cb = it & 1;
-        shot_u4 wreg[WPT];
-        {
-            const shot_u4 *wp = (const shot_u4 *)(wsrc + (size_t)(it + 1 < niter ? it + 1 : it) * WCH);
-#pragma unroll
-            for (int k = 0; k < WPT; ++k) wreg[k] = wp[tid + 256 * k < WCH ? 256 * k : 0];
-        }
-        SHOT_LDA(2, it, 2); SHOT_LDB(1, cb, 1); SHOT_MMA(0); SHOT_SCHED();
-        SHOT_LDA(0, it + 1, 0); SHOT_LDB(2, cb, 2); SHOT_MMA(1); SHOT_SCHED();
-        // the next iteration's weights: the other buffer's readers finished before the previous barrier; this iteration's
-        // last read (step 2's fragments, above) is complete when the barrier is passed
-        {
-            shot_u4 *wn = (shot_u4 *)(sm_w3 + (cb ^ 1) * WCH + tid);
-#pragma unroll
-            for (int k = 0; k < WPT; ++k)
-                if (tid + 256 * k < WCH) wn[256 * k] = wreg[k];
-        }
-        __syncthreads();
-        SHOT_LDA(1, it + 1, 1); SHOT_LDB(0, cb ^ 1, 0); SHOT_MMA(2); SHOT_SCHED();
+    // one iteration: the tiles wt = 0 .. KT - 1 against position set sa_; the weight fragments alternate between two register
+    // sets starting with b0_ (KT may be odd: the loop body is two iterations, so every index is static)
+#define SHOT_ITER(it_, sa_, b0_)                                                                                     \
+    {                                                                                                                \
+        const int cb_ = (it_) & 1;                                                                                   \
+        shot_u4 wreg[WPT];                                                                                           \
+        {                                                                                                            \
+            const shot_u4 *wp = (const shot_u4 *)(wsrc + (size_t)((it_) + 1 < niter ? (it_) + 1 : (it_)) * WCH);     \
+            _Pragma("unroll") for (int k = 0; k < WPT; ++k) wreg[k] = wp[tid + 256 * k < WCH ? 256 * k : 0];         \
+        }                                                                                                            \
+        SHOT_LDA((sa_) ^ 1, (it_) + 1);                                                                              \
+        _Pragma("unroll") for (int wt = 0; wt < KT; ++wt) {                                                          \
+            if (wt + 1 < KT) {                                                                                       \
+                SHOT_LDB(((b0_) + wt + 1) & 1, cb_, wt + 1);                                                         \
+            } else {                                                                                                 \
+                /* the next iteration's weights: the other buffer's readers finished before the previous barrier; */ \
+                /* this iteration's last read (the fragments of tile KT - 1) is complete when the barrier is passed */ \
+                shot_u4 *wn = (shot_u4 *)(sm_w3 + (cb_ ^ 1) * WCH + tid);                                            \
+                _Pragma("unroll") for (int k = 0; k < WPT; ++k)                                                      \
+                    if (tid + 256 * k < WCH) wn[256 * k] = wreg[k];                                                  \
+                __syncthreads();                                                                                     \
+                SHOT_LDB(((b0_) + wt + 1) & 1, cb_ ^ 1, 0);                                                          \
+            }                                                                                                        \
+            SHOT_MMA(sa_, ((b0_) + wt) & 1, wt);                                                                     \
+            /* issue order: the weight reads and this tile's share of the position loads between the MFMAs */       \
+            _Pragma("unroll") for (int i_ = 0; i_ < NPL; ++i_) {                                                     \
+                __builtin_amdgcn_sched_group_barrier(0x008, NP * PT / NPL, 0);                                      \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                   \
+                if (wt * NPL + i_ < PT * NPL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     \
+            }                                                                                                        \
+        }                                                                                                            \
     }
-#undef SHOT_SCHED
+    for (int it = 0; it < niter; it += 2) {                  // niter = 9 C / 16 is even (C = 64, 128, 256)
+        SHOT_ITER(it, 0, 0);
+        SHOT_ITER(it + 1, 1, KT & 1);
+    }
+#undef SHOT_ITER
 #undef SHOT_MMA
 #undef SHOT_LDB
 #undef SHOT_LDA
+    // epilogue: y[m] = P_1[m] + P_0[m - 1] + P_2[m + 1] (+ bias, ReLU) on the wave's inner positions.  Lane (r, hh) of tile pt
+    // fetches lane r -+ 1 of the same half (ds_bpermute); r = 0 / 31 take the neighbouring tile's last / first lane.
+    const int lo = (hh * 32 + ((r + 31) & 31)) * 4, hi = (hh * 32 + ((r + 1) & 31)) * 4;
+    auto from_left = [&](const f32x16 (&P)[PT], int pt, int i) -> float {       // P[m - 1]
+        const float same = __int_as_float(__builtin_amdgcn_ds_bpermute(lo, __float_as_int(P[pt][i])));
+        const float prev = pt > 0 ? __int_as_float(__builtin_amdgcn_ds_bpermute(lo, __float_as_int(P[pt > 0 ? pt - 1 : 0][i]))) : 0.f;
+        return r == 0 ? prev : same;
+    };
+    auto from_right = [&](const f32x16 (&P)[PT], int pt, int i) -> float {      // P[m + 1]
+        const float same = __int_as_float(__builtin_amdgcn_ds_bpermute(hi, __float_as_int(P[pt][i])));
+        const float next = pt + 1 < PT ? __int_as_float(__builtin_amdgcn_ds_bpermute(hi, __float_as_int(P[pt + 1 < PT ? pt + 1 : pt][i]))) : 0.f;
+        return r == 31 ? next : same;
+    };
+    constexpr int NOUT = F16 ? 1 : NT;
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-        const long long m = m0 + (wave * PT + pt) * 32 + r;
-        if (m >= A.M) continue;
+    for (int n = 0; n < NOUT; ++n) {
+        f32x16 P0[PT], P1[PT], P2[PT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
+        for (int pt = 0; pt < PT; ++pt) {
+            if (F16) {                                       // tile 0 = kw 0 (rows 0..15) | kw 1 (rows 16..31), tile 1 = kw 2 | 0
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { P0[pt][i] = acc[pt][0][i]; P1[pt][i] = acc[pt][0][8 + i]; P2[pt][i] = acc[pt][KT - 1][i]; }
+#pragma unroll
+                for (int i = 8; i < 16; ++i) P0[pt][i] = P1[pt][i] = P2[pt][i] = 0.f;
+            } else {
+                P0[pt] = acc[pt][n]; P1[pt] = acc[pt][F16 ? 0 : NT + n]; P2[pt] = acc[pt][F16 ? 0 : 2 * NT + n];
+            }
+        }
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const long long m = mb + 32 * pt + r;
+            const int idx = 32 * pt + r;
+            const bool out = idx >= 1 && idx <= 32 * PT - 2 && m < A.M;
+            const bool useL = xs[pt] >= 1, useR = xs[pt] <= A.W - 2;
             const int c0 = (ng * NT + n) * 32;               // first channel of the tile inside the branch
             float4 v[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < (F16 ? 2 : 4); ++g) {
+                float e[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float l = from_left(P0, pt, 4 * g + i), rr = from_right(P2, pt, 4 * g + i);
+                    e[i] = (P1[pt][4 * g + i] + (useL ? l : 0.f)) + (useR ? rr : 0.f);
+                }
                 const int col = c0 + 8 * g + 4 * hh;
-                if (col >= A.F) continue;
-                const float4 b = *(const float4 *)(A.bias + br * A.F + col);
-                v[g] = make_float4(acc[pt][n][4 * g] + b.x, acc[pt][n][4 * g + 1] + b.y, acc[pt][n][4 * g + 2] + b.z, acc[pt][n][4 * g + 3] + b.w);
+                const float4 b = col < A.F ? *(const float4 *)(A.bias + br * A.F + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[g] = make_float4(e[0] + b.x, e[1] + b.y, e[2] + b.z, e[3] + b.w);
                 if (A.relu) { v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f); }
             }
+            if (!out) continue;
 #pragma unroll
-            for (int ql = 0; ql < 2; ++ql)
+            for (int ql = 0; ql < (F16 ? 1 : 2); ++ql)
                 if (c0 + 16 * ql < A.F) shot_store_x3(A.Y3, A.Mp, m, hh, ((br * A.F + c0) >> 4) + ql, v[2 * ql], v[2 * ql + 1]);
         }
     }
 }
 
 // The weights of a cell in the order k_shot_conv_x3 reads them: round-to-nearest bf16 planes (svc_x3.h) of
-// Wt [branch][Fpad][kpad] (k = tap * C + channel), one thread per (branch, group, iteration = (q, kt, kh), kw, tile, lane).
-__global__ __launch_bounds__(256) void k_shot_x3_weights(const float *__restrict__ Wt, int Fpad, int kpad, int C, int NT, int NPL,
+// Wt [branch][Fpad][kpad] (k = tap * C + channel), one thread per (branch, group, iteration = (q, kt, kh), weight tile, lane).
+// A weight tile is (kw, n): rows = filters (ng NT + n) 32 ..; f16 (the 16-filter cell): tile 0 = kw 0's filters | kw 1's,
+// tile 1 = kw 2's | zeros.
+__global__ __launch_bounds__(256) void k_shot_x3_weights(const float *__restrict__ Wt, int Fpad, int kpad, int C, int NT, int NPL, int f16,
                                                          uint4 *__restrict__ out, size_t total) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
+    const int KT = f16 ? 2 : 3 * NT;
     const int lane = (int)(i & 63), r = lane & 31, hh = lane >> 5;
     size_t u = i >> 6;
-    const int n = (int)(u % NT); u /= NT;
-    const int kw = (int)(u % 3); u /= 3;
+    const int wt = (int)(u % KT); u /= KT;
     const int niter = 9 * (C >> 4), groups = Fpad / (32 * NT);
     const int it = (int)(u % niter); u /= niter;
     const int ng = (int)(u % groups), br = (int)(u / groups);
-    const int q = it / 9, tap = (it - 9 * q) * 3 + kw;
-    const float *w = Wt + ((size_t)br * Fpad + (ng * NT + n) * 32 + r) * kpad + tap * C + 16 * q + 4 * hh;
-    const X3 s = x3_split<true>(*(const float4 *)w, *(const float4 *)(w + 8));
+    const int q = it / 9, g = it - 9 * q;
+    int kw, row;
+    bool zero = false;
+    if (f16) { kw = 2 * wt + (r >> 4); row = r & 15; zero = kw > 2; }
+    else { kw = wt / NT; row = (ng * NT + wt % NT) * 32 + r; }
+    X3 s;
+    if (zero) {
+        s = x3_split<true>(make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f));
+    } else {
+        const float *w = Wt + ((size_t)br * Fpad + row) * kpad + (g * 3 + kw) * C + 16 * q + 4 * hh;
+        s = x3_split<true>(*(const float4 *)w, *(const float4 *)(w + 8));
+    }
     X3Q P[3];
     P[0].v = s.h; P[1].v = s.m; P[2].v = s.l;
-    uint4 *o = out + (((((size_t)(br * groups + ng) * niter + it) * 3 + kw) * NT + n) * NPL) * 64 + lane;
+    uint4 *o = out + ((((size_t)(br * groups + ng) * niter + it) * KT + wt) * NPL) * 64 + lane;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
         if (pl < NPL) o[pl * 64] = P[pl].q;
@@ -748,6 +813,8 @@ extern "C" int svc_transnet_load(SvcHandle *h, const float *blob_host, size_t n_
     return SVC_OK;
 }
 
+extern "C" int svc_transnet_matrix_pipe(const SvcHandle *h) { return h ? (h->shot_mx < 0 ? h->mx : h->shot_mx) : 0; }
+
 extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_windows, int frames_per_window, float *probs,
                                     void *stream) {
     if (!h || n_windows < 0 || frames_per_window < 1 || (n_windows > 0 && (!frames || !probs))) {
@@ -769,15 +836,17 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
     size_t w3_off[SHOT_L * SHOT_S] = {0};
     if (mx) {
         size_t tot = 0;
-        for (int i = 1; i < SHOT_L * SHOT_S; ++i) { w3_off[i] = tot; tot += (size_t)4 * cells[i].fpad * (cells[i].kpad / 16) * NPL * 2; }   // uint4
+        // uint4 per cell: branches x groups x iterations x weight tiles x planes x 64 lanes
+        auto w3_tiles = [&](const ShotCell &k) { return k.f == 16 ? (size_t)2 : (size_t)3 * (k.fpad / 32); };
+        for (int i = 1; i < SHOT_L * SHOT_S; ++i) { w3_off[i] = tot; tot += (size_t)4 * 9 * (cells[i].cpad / 16) * w3_tiles(cells[i]) * NPL * 64; }
         if (h->shot_w3_mx != mx) {
             int rc = h->shot_w3.ensure(tot * sizeof(uint4));
             if (rc) return rc;
             for (int i = 1; i < SHOT_L * SHOT_S; ++i) {
                 const ShotCell &k = cells[i];
                 const int NT = k.fpad % 64 == 0 ? 2 : 1;
-                const size_t total = (size_t)4 * k.fpad * (k.kpad / 16) * 2;           // threads: one per (row, 16-deep step, hh)
-                k_shot_x3_weights<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(blob + k.w_off, k.fpad, k.kpad, k.cpad, NT, NPL,
+                const size_t total = (size_t)4 * 9 * (k.cpad / 16) * w3_tiles(k) * 64;         // threads: one per (tile, lane)
+                k_shot_x3_weights<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(blob + k.w_off, k.fpad, k.kpad, k.cpad, NT, NPL, k.f == 16,
                                                                                  (uint4 *)h->shot_w3.p + w3_off[i], total);
                 SVC_CHECK_LAUNCH();
             }
@@ -812,18 +881,19 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
                     X.Y3 = (uint4 *)P[cur ^ 1]; X.M = Mc; X.Mp = Mp; X.T = T; X.H = H; X.W = W; X.C = k.cpad; X.F = k.f; X.Fpad = k.fpad;
                     X.relu = 1; X.xcd = h->shot_xcd;
                     const int NT = k.fpad % 64 == 0 ? 2 : 1, PT = h->shot_pt;
-                    unsigned gx = (unsigned)((Mc + 128 * PT - 1) / (128 * PT));
+                    const bool f16 = k.f == 16;
+                    const int WGS = 4 * (32 * PT - 2);
+                    unsigned gx = (unsigned)((Mc + WGS - 1) / WGS);
                     if (X.xcd) gx = (gx + 7) / 8 * 8;
                     dim3 grid(gx, (unsigned)(4 * (k.fpad / (32 * NT))));
-                    const size_t lds = (size_t)2 * 3 * NT * NPL * 64 * sizeof(uint4);
-#define SHOT_X3(NT_, PT_, NP_) k_shot_conv_x3<NT_, PT_, NP_><<<grid, 256, lds, s>>>(X)
-                    if (mx == 3) {
-                        if (NT == 2) { if (PT == 2) SHOT_X3(2, 2, 3); else SHOT_X3(2, 1, 3); }
-                        else { if (PT == 2) SHOT_X3(1, 2, 3); else SHOT_X3(1, 1, 3); }
-                    } else {
-                        if (NT == 2) { if (PT == 2) SHOT_X3(2, 2, 6); else SHOT_X3(2, 1, 6); }
-                        else { if (PT == 2) SHOT_X3(1, 2, 6); else SHOT_X3(1, 1, 6); }
-                    }
+                    const size_t lds = (size_t)2 * (f16 ? 2 : 3 * NT) * NPL * 64 * sizeof(uint4);
+#define SHOT_X3(NT_, PT_, NP_, F16_) k_shot_conv_x3<NT_, PT_, NP_, F16_><<<grid, 256, lds, s>>>(X)
+#define SHOT_X3_NP(NP_)                                                                                              \
+                    if (f16) { if (PT == 2) SHOT_X3(1, 2, NP_, true); else SHOT_X3(1, 1, NP_, true); }               \
+                    else if (NT == 2) { if (PT == 2) SHOT_X3(2, 2, NP_, false); else SHOT_X3(2, 1, NP_, false); }    \
+                    else { if (PT == 2) SHOT_X3(1, 2, NP_, false); else SHOT_X3(1, 1, NP_, false); }
+                    if (mx == 3) { SHOT_X3_NP(3) } else { SHOT_X3_NP(6) }
+#undef SHOT_X3_NP
 #undef SHOT_X3
                     SVC_CHECK_LAUNCH();
                     cur ^= 1;

@@ -267,6 +267,7 @@ class JobScheduler:
         self.chunk, self.depth, self.lane_rows = int(chunk), int(depth), int(lane_rows)
         self.piece_frames, self.piece_bytes = int(piece_frames), int(piece_bytes)
         self.shot_net = shot_net
+        self._plan_ready = self._planned = self._plan_err = None
         self.dev = torch.device('cuda', torch.cuda.current_device())
         self.own_engines = engines is None
         if engines is None:
@@ -305,6 +306,7 @@ class JobScheduler:
         for e in self.engines:
             e.threshold_census(reset=True)
         t0 = time.perf_counter()
+        planner = self._start_planner()
         try:
             with torch.cuda.device(self.dev):
                 live = list(lanes)
@@ -315,6 +317,7 @@ class JobScheduler:
                 for ln in lanes:
                     ln.finish()
         except BaseException:
+            self._stop_planner(planner)
             # the feeder failed (a bad video in plan_video, rows that do not fit): no host-stage task of this job may still be
             # running when the caller sees the error -- the scheduler is reused for the next job
             for f in self.futures:
@@ -326,6 +329,7 @@ class JobScheduler:
                     pass
             torch.cuda.synchronize(self.dev)
             raise
+        self._stop_planner(planner)
         t1 = time.perf_counter()
         err = None
         for f in self.futures:
@@ -359,10 +363,62 @@ class JobScheduler:
             return None
         i = self.next_idx
         self.next_idx += 1
+        shots = None
+        if self._plan_ready is not None:                      # shot detection ran (or is running) in the planner thread
+            self._plan_ready[i].wait()
+            if self._plan_err is not None:
+                raise self._plan_err
+            v, shots = self._planned[i]
+            self._planned[i] = None
         with torch.cuda.stream(lane.stream):
-            v = self.videos[i]() if callable(self.videos[i]) else self.videos[i]
-            plan = S.plan_video(v, self.CP, engine=lane.eng, shot_net=self.shot_net)
+            if self._plan_ready is None:
+                v = self.videos[i]() if callable(self.videos[i]) else self.videos[i]
+            plan = S.plan_video(v, self.CP, engine=lane.eng, shot_net=self.shot_net, shots=shots)
         return _Video(i, v, plan, self.out)
+
+    # Shot detection ahead of the lanes (jobs with shot_net=): TransNet is the longest device stage of the video path, and run
+    # from the feeder (inside plan_video) every video's windows, their copy to the host and the scene walk sat between two
+    # lanes' enqueues.  One thread walks the videos in order on a stream of its own with the network's own engine; the
+    # feeder only picks up the finished (video, shots) pairs, so the saliency lanes overlap with the shot network.
+    def _start_planner(self):
+        import threading
+        self._plan_ready, self._planned, self._plan_err, self._plan_stop = None, None, None, False
+        if self.shot_net is None or not self.videos:
+            return None
+        self._plan_ready = [threading.Event() for _ in self.videos]
+        self._planned = [None] * len(self.videos)
+        th = threading.Thread(target=self._plan_ahead, name='svc-shot-planner', daemon=True)
+        th.start()
+        return th
+
+    def _plan_ahead(self):
+        import torch
+        try:
+            with torch.cuda.device(self.dev):
+                st = torch.cuda.Stream(device=self.dev)
+                with torch.cuda.stream(st):
+                    for i in range(len(self.videos)):
+                        if self._plan_stop:
+                            break
+                        v = self.videos[i]() if callable(self.videos[i]) else self.videos[i]
+                        shots = None
+                        if v.get('trans_inds') is None:
+                            shots = S.detect_shots(v['frames'], v['fr'], self.CP, net=self.shot_net, engine=self.shot_net.eng,
+                                                   trans_threshold=S.TRANS_THRESHOLD)
+                        else:
+                            st.synchronize()                  # whatever the callable enqueued is done before a lane reads the frames
+                        self._planned[i] = (v, shots)
+                        self._plan_ready[i].set()
+        except BaseException as e:                            # surfaced by the feeder (_next_video)
+            self._plan_err = e
+        finally:
+            for ev in self._plan_ready:
+                ev.set()
+
+    def _stop_planner(self, th):
+        if th is not None:
+            self._plan_stop = True
+            th.join()
 
     def _dispatch(self, lane, gids, xy):
         """Centres of finished maps -> their videos; a video whose last centre arrived goes to the host-stage pool."""

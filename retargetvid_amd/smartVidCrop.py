@@ -323,12 +323,13 @@ def _small_frames(engine, frames, idx, sal_h, sal_w, dev):
     return feed.downscale(host, idx, sal_h, sal_w)
 
 
-def plan_video(video, crop_params, engine=None, shot_net=None):
+def plan_video(video, crop_params, engine=None, shot_net=None, shots=None):
     """The ingest's host bookkeeping for one video dict (smartVidCrop.py:621-718, :740-758; the video path :379-399,
     :452-456): frame selection, the selected-frame view of the shots, the cut-blend flags and which selected frames keep
     an all-zero map (the last one of every read batch: the reference's off-by-one).  Shot detection runs here when the
-    dict has no ``trans_inds`` (device work on the current stream).  Shared by ingest_frames (one video at a time) and the
-    multi-video scheduler (retargetvid_amd/scheduler.py)."""
+    dict has no ``trans_inds`` (device work on the current stream) unless the caller did it already (``shots`` = what
+    detect_shots returned for this video: the scheduler's planner thread runs it ahead of the lanes).  Shared by
+    ingest_frames (one video at a time) and the multi-video scheduler (retargetvid_amd/scheduler.py)."""
     fr, frame_count, w, h = video['fr'], int(video['frame_count']), int(video['w']), int(video['h'])
     frames = video['frames']              # ndarray / CUDA tensor [n,h,w,3] u8 RGB, or an object with __len__ and .select(idx)
     n_frames = len(frames)
@@ -336,10 +337,11 @@ def plan_video(video, crop_params, engine=None, shot_net=None):
     sal_h, sal_w = int(h / dsr), int(w / dsr)
     trans_probs = None
     if video.get('trans_inds') is None:
-        if shot_net is None:
-            raise ValueError('the video dict has no trans_inds: pass shot_net= (a transnetv1_handler.ShotTransNet) to run shot '
-                             'detection inside the ingest, as the reference\'s video path does')
-        shots = detect_shots(frames, fr, crop_params, net=shot_net, engine=engine, trans_threshold=TRANS_THRESHOLD)
+        if shots is None:
+            if shot_net is None:
+                raise ValueError('the video dict has no trans_inds: pass shot_net= (a transnetv1_handler.ShotTransNet) to run shot '
+                                 'detection inside the ingest, as the reference\'s video path does')
+            shots = detect_shots(frames, fr, crop_params, net=shot_net, engine=engine, trans_threshold=TRANS_THRESHOLD)
         trans_probs = shots['trans_probs']
         true_inds, map2orig, batches = _select_frames_video(n_frames, frame_count, trans_probs, TRANS_THRESHOLD,
                                                             crop_params['skip'], crop_params['read_batch'])

@@ -33,7 +33,7 @@ class ShotTransNetParams:
 
 
 class ShotTransNet:
-    def __init__(self, params=None, session=None, weights=None, engine=None, windows_per_call=8):
+    def __init__(self, params=None, session=None, weights=None, engine=None, windows_per_call=16):
         self.params = params or ShotTransNetParams()
         p = self.params
         if (p.F, p.L, p.S, p.D, p.INPUT_WIDTH, p.INPUT_HEIGHT) != (16, 3, 2, 256, 48, 27):
@@ -46,6 +46,11 @@ class ShotTransNet:
         self.windows_per_call = int(windows_per_call)
         blob = np.ascontiguousarray(_weights.pack_transnet_blob(weights), np.float32)
         _lib.check(self.eng.lib.svc_transnet_load(self.eng._h, blob.ctypes.data_as(ctypes.c_void_p), blob.size))
+
+    def matrix_pipe(self):
+        """'f32', 'bf16x6' or 'bf16x3': what the convolution cells run on (svc_transnet_matrix_pipe; environment SVC_SHOT_MX
+        when the engine is created, default = SVC_MX)."""
+        return {0: 'f32', 6: 'bf16x6', 3: 'bf16x3'}[int(self.eng.lib.svc_transnet_matrix_pipe(self.eng._h))]
 
     def close(self):
         if self._own and self.eng is not None:

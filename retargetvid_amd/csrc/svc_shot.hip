@@ -10,7 +10,12 @@
 // v_mfma_f32_32x32x2_f32 (exact fp32 products) with the operands the way round the network kernels use them (weights as
 // A, positions as B: a lane ends with 16 channels of ONE position in runs of four -> bias, ReLU, float4 stores).  The four
 // dilations of a cell are the y dimension of one launch and write disjoint channel ranges of the cell's output.
-// Dense(256) is the same kernel with one tap over the 4608 flattened inputs.
+// Dense(256) is the same kernel with one tap over the 4608 flattened inputs, K cut in eight parts (k_shot_head adds them).
+//
+// Default since round 5 (SVC_SHOT_MX = SVC_MX = bf16x6): the cells run on v_mfma_f32_32x32x16_bf16 with every f32 operand as
+// three bf16 planes (svc_x3.h) and the activations kept split and planar between the cells -- "split-bf16 activations" below:
+// k_shot_in_x3 -> k_shot_first_x3 -> k_shot_conv_x3 ... k_shot_pool_x3 -> Dense -> k_shot_head.  The fp32 kernels above
+// (k_shot_conv, k_shot_conv_lds, k_shot_conv_lds2*) are SVC_SHOT_MX=f32.
 #include <algorithm>
 
 #include "svc_internal.h"
@@ -40,8 +45,7 @@ struct ShotConv {
     long long M;            // positions = B * T * H * W
     int T, H, W, C, logC;   // C = 1 << logC for the 27-tap form
     int F, Fpad, kpad, ntaps, ldy, relu;
-    uint4 *Y3;              // not null: the output goes out as split-bf16 planes (ShotX3's layout) instead of Y
-    long long Mp;           // plane stride of Y3 in positions
+    int ksplit;             // Dense only: > 1 = grid z cuts K in ksplit parts, part z writes its raw sums to Y + z * M * ldy (k_shot_head adds them, in order)
 };
 
 // ---- split-bf16 activations (SVC_MX=bf16x6: the cells with >= 64 input channels on the bf16 matrix pipe) ---------------
@@ -88,7 +92,8 @@ __global__ __launch_bounds__(256) void k_shot_conv(const ShotConv A) {
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     if (A.ntaps == 1) {                                      // Dense: one tap, the position's own row of C inputs
         const float *xp = A.X + (size_t)m * A.C + 4 * hh;
-        for (int kk = 0; kk < A.kpad; kk += 8) {
+        const int kpart = A.kpad / (A.ksplit > 1 ? A.ksplit : 1), kend = ((int)blockIdx.z + 1) * kpart;
+        for (int kk = (int)blockIdx.z * kpart; kk < kend; kk += 8) {
             const float4 a = *(const float4 *)(xp + kk);
             const float4 b = *(const float4 *)(wrow + kk);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc, 0, 0, 0);
@@ -149,23 +154,24 @@ __global__ __launch_bounds__(256) void k_shot_conv(const ShotConv A) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
         }
     }
-    if (A.Y3 && blockIdx.x == 0) shot_zero_pads(A.Y3, A.Mp, (br * A.F + nt * 32) >> 4, std::min(32, A.F - nt * 32) >> 4, threadIdx.x);
+    if (A.ksplit > 1) {                                      // a K part of Dense: raw sums, bias and ReLU are k_shot_head's
+        if ((long long)blockIdx.x * 128 + wave * 32 + r >= A.M) return;
+        float *yp = A.Y + ((size_t)blockIdx.z * A.M + m) * A.ldy;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(float4 *)(yp + nt * 32 + 8 * g + 4 * hh) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        return;
+    }
     if ((long long)blockIdx.x * 128 + wave * 32 + r >= A.M) return;
     float *yp = A.Y + (size_t)m * A.ldy + br * A.F;
-    float4 v[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int col = nt * 32 + 8 * g + 4 * hh;
         if (col >= A.F) continue;
         const float4 b = *(const float4 *)(A.bias + br * A.F + col);
-        v[g] = make_float4(acc[4 * g] + b.x, acc[4 * g + 1] + b.y, acc[4 * g + 2] + b.z, acc[4 * g + 3] + b.w);
-        if (A.relu) { v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f); }
-        if (!A.Y3) *(float4 *)(yp + col) = v[g];
-    }
-    if (A.Y3) {                                              // channels 16 q + 8 (g & 1) + 4 hh + i: the lane's g = 2 ql, 2 ql + 1 are one fragment
-#pragma unroll
-        for (int ql = 0; ql < 2; ++ql)
-            if (nt * 32 + 16 * ql < A.F) shot_store_x3(A.Y3, A.Mp, m, hh, ((br * A.F + nt * 32) >> 4) + ql, v[2 * ql], v[2 * ql + 1]);
+        float4 v = make_float4(acc[4 * g] + b.x, acc[4 * g + 1] + b.y, acc[4 * g + 2] + b.z, acc[4 * g + 3] + b.w);
+        if (A.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *(float4 *)(yp + col) = v;
     }
 }
 
@@ -457,12 +463,21 @@ __global__ __launch_bounds__(256) void k_shot_pool(const float *__restrict__ X, 
     ((float4 *)Y)[i] = v;
 }
 
-// Dense(2) + softmax, class 1: one wavefront per frame
+// Dense(2) + softmax, class 1: one wavefront per frame.  nsplit > 0: X holds Dense(256)'s K parts [nsplit][rows][256] as raw
+// sums -- added here in part order, then its bias b1 and ReLU.
 __global__ __launch_bounds__(64) void k_shot_head(const float *__restrict__ X, const float *__restrict__ W2, const float *__restrict__ b2,
-                                                  float *__restrict__ prob, int rows) {
+                                                  float *__restrict__ prob, int rows, int nsplit, const float *__restrict__ b1) {
     const int row = blockIdx.x, lane = threadIdx.x;
     if (row >= rows) return;
-    const float4 xv = *(const float4 *)(X + (size_t)row * SHOT_D + lane * 4);
+    float4 xv = *(const float4 *)(X + (size_t)row * SHOT_D + lane * 4);
+    if (nsplit > 0) {
+        for (int z = 1; z < nsplit; ++z) {
+            const float4 p = *(const float4 *)(X + ((size_t)z * rows + row) * SHOT_D + lane * 4);
+            xv.x += p.x; xv.y += p.y; xv.z += p.z; xv.w += p.w;
+        }
+        const float4 b = *(const float4 *)(b1 + lane * 4);
+        xv = make_float4(fmaxf(xv.x + b.x, 0.f), fmaxf(xv.y + b.y, 0.f), fmaxf(xv.z + b.z, 0.f), fmaxf(xv.w + b.w, 0.f));
+    }
     const float4 w0 = *(const float4 *)(W2 + lane * 4), w1 = *(const float4 *)(W2 + SHOT_D + lane * 4);
     float s0 = xv.x * w0.x + xv.y * w0.y + xv.z * w0.z + xv.w * w0.w;
     float s1 = xv.x * w1.x + xv.y * w1.y + xv.z * w1.z + xv.w * w1.w;
@@ -484,6 +499,68 @@ struct ShotX3 {
     int T, H, W, C, F, Fpad, relu, xcd;
 };
 
+// The epilogue of the kernels that keep the kw taps in the accumulators: y[m] = P_1[m] + P_0[m - 1] + P_2[m + 1] (+ bias, ReLU)
+// on the wave's inner positions, stored as split planes.  acc[pt][kw * NT + n], or (F16) tile 0 = kw 0 (rows 0..15) | kw 1
+// (rows 16..31), tile KT - 1 = kw 2 | 0.  mb = the wave's first computed position, xs = the x of the lane's positions.
+template <int NT, int PT, int KT, bool F16>
+__device__ __forceinline__ void shot_kw_epilogue(const f32x16 (&acc)[PT][KT], uint4 *Y3, long long Mp, long long M, int W, int F,
+                                                 const float *bias, int relu, int br, int ng, long long mb, int r, int hh, const int (&xs)[PT]) {
+    // lane (r, hh) of tile pt fetches lane r -+ 1 of the same half (ds_bpermute); r = 0 / 31 take the neighbouring tile's last / first lane
+    const int lo = (hh * 32 + ((r + 31) & 31)) * 4, hi = (hh * 32 + ((r + 1) & 31)) * 4;
+    auto from_left = [&](const f32x16 (&P)[PT], int pt, int i) -> float {       // P[m - 1]
+        const float same = __int_as_float(__builtin_amdgcn_ds_bpermute(lo, __float_as_int(P[pt][i])));
+        const float prev = pt > 0 ? __int_as_float(__builtin_amdgcn_ds_bpermute(lo, __float_as_int(P[pt > 0 ? pt - 1 : 0][i]))) : 0.f;
+        return r == 0 ? prev : same;
+    };
+    auto from_right = [&](const f32x16 (&P)[PT], int pt, int i) -> float {      // P[m + 1]
+        const float same = __int_as_float(__builtin_amdgcn_ds_bpermute(hi, __float_as_int(P[pt][i])));
+        const float next = pt + 1 < PT ? __int_as_float(__builtin_amdgcn_ds_bpermute(hi, __float_as_int(P[pt + 1 < PT ? pt + 1 : pt][i]))) : 0.f;
+        return r == 31 ? next : same;
+    };
+    constexpr int NOUT = F16 ? 1 : NT;
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) {
+        f32x16 P0[PT], P1[PT], P2[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            if (F16) {                                       // tile 0 = kw 0 (rows 0..15) | kw 1 (rows 16..31), tile 1 = kw 2 | 0
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { P0[pt][i] = acc[pt][0][i]; P1[pt][i] = acc[pt][0][8 + i]; P2[pt][i] = acc[pt][KT - 1][i]; }
+#pragma unroll
+                for (int i = 8; i < 16; ++i) P0[pt][i] = P1[pt][i] = P2[pt][i] = 0.f;
+            } else {
+                P0[pt] = acc[pt][n]; P1[pt] = acc[pt][F16 ? 0 : NT + n]; P2[pt] = acc[pt][F16 ? 0 : 2 * NT + n];
+            }
+        }
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const long long m = mb + 32 * pt + r;
+            const int idx = 32 * pt + r;
+            const bool out = idx >= 1 && idx <= 32 * PT - 2 && m < M;
+            const bool useL = xs[pt] >= 1, useR = xs[pt] <= W - 2;
+            const int c0 = (ng * NT + n) * 32;               // first channel of the tile inside the branch
+            float4 v[4];
+#pragma unroll
+            for (int g = 0; g < (F16 ? 2 : 4); ++g) {
+                float e[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float l = from_left(P0, pt, 4 * g + i), rr = from_right(P2, pt, 4 * g + i);
+                    e[i] = (P1[pt][4 * g + i] + (useL ? l : 0.f)) + (useR ? rr : 0.f);
+                }
+                const int col = c0 + 8 * g + 4 * hh;
+                const float4 b = col < F ? *(const float4 *)(bias + br * F + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[g] = make_float4(e[0] + b.x, e[1] + b.y, e[2] + b.z, e[3] + b.w);
+                if (relu) { v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f); }
+            }
+            if (!out) continue;
+#pragma unroll
+            for (int ql = 0; ql < (F16 ? 1 : 2); ++ql)
+                if (c0 + 16 * ql < F) shot_store_x3(Y3, Mp, m, hh, ((br * F + c0) >> 4) + ql, v[2 * ql], v[2 * ql + 1]);
+        }
+    }
+}
+
 // A DDCNN cell on split-bf16 operands: implicit GEMM [positions x 27 C] . [27 C x filters] on v_mfma_f32_32x32x16_bf16, NP = 6
 // plane pairs per 16-deep step (svc_x3.h; NP = 3: hi.hi + hi.mid + mid.hi only, SVC_SHOT_MX=bf16x3).
 //
@@ -503,6 +580,8 @@ struct ShotX3 {
 // iteration's [tile][plane][64 lanes] block is contiguous in W3 in exactly the order the lanes read it -- copied to LDS by
 // all four waves one iteration ahead (double buffer, ONE barrier per iteration), read back lane-contiguous (conflict-free)
 // one tile ahead.
+// NT (filter tiles per wavefront) is 1 in every launch: the 64-filter cells run their two filter groups as separate workgroups
+// (two tiles per wave -- six accumulator tiles per position tile, one wave per SIMD -- took 580 / 1033 us against 451 / 863).
 template <int NT, int PT, int NP, bool F16>
 __global__ __launch_bounds__(256) void k_shot_conv_x3(const ShotX3 A) {
     extern __shared__ uint4 sm_w3[];
@@ -632,61 +711,7 @@ __global__ __launch_bounds__(256) void k_shot_conv_x3(const ShotX3 A) {
 #undef SHOT_MMA
 #undef SHOT_LDB
 #undef SHOT_LDA
-    // epilogue: y[m] = P_1[m] + P_0[m - 1] + P_2[m + 1] (+ bias, ReLU) on the wave's inner positions.  Lane (r, hh) of tile pt
-    // fetches lane r -+ 1 of the same half (ds_bpermute); r = 0 / 31 take the neighbouring tile's last / first lane.
-    const int lo = (hh * 32 + ((r + 31) & 31)) * 4, hi = (hh * 32 + ((r + 1) & 31)) * 4;
-    auto from_left = [&](const f32x16 (&P)[PT], int pt, int i) -> float {       // P[m - 1]
-        const float same = __int_as_float(__builtin_amdgcn_ds_bpermute(lo, __float_as_int(P[pt][i])));
-        const float prev = pt > 0 ? __int_as_float(__builtin_amdgcn_ds_bpermute(lo, __float_as_int(P[pt > 0 ? pt - 1 : 0][i]))) : 0.f;
-        return r == 0 ? prev : same;
-    };
-    auto from_right = [&](const f32x16 (&P)[PT], int pt, int i) -> float {      // P[m + 1]
-        const float same = __int_as_float(__builtin_amdgcn_ds_bpermute(hi, __float_as_int(P[pt][i])));
-        const float next = pt + 1 < PT ? __int_as_float(__builtin_amdgcn_ds_bpermute(hi, __float_as_int(P[pt + 1 < PT ? pt + 1 : pt][i]))) : 0.f;
-        return r == 31 ? next : same;
-    };
-    constexpr int NOUT = F16 ? 1 : NT;
-#pragma unroll
-    for (int n = 0; n < NOUT; ++n) {
-        f32x16 P0[PT], P1[PT], P2[PT];
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            if (F16) {                                       // tile 0 = kw 0 (rows 0..15) | kw 1 (rows 16..31), tile 1 = kw 2 | 0
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { P0[pt][i] = acc[pt][0][i]; P1[pt][i] = acc[pt][0][8 + i]; P2[pt][i] = acc[pt][KT - 1][i]; }
-#pragma unroll
-                for (int i = 8; i < 16; ++i) P0[pt][i] = P1[pt][i] = P2[pt][i] = 0.f;
-            } else {
-                P0[pt] = acc[pt][n]; P1[pt] = acc[pt][F16 ? 0 : NT + n]; P2[pt] = acc[pt][F16 ? 0 : 2 * NT + n];
-            }
-        }
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            const long long m = mb + 32 * pt + r;
-            const int idx = 32 * pt + r;
-            const bool out = idx >= 1 && idx <= 32 * PT - 2 && m < A.M;
-            const bool useL = xs[pt] >= 1, useR = xs[pt] <= A.W - 2;
-            const int c0 = (ng * NT + n) * 32;               // first channel of the tile inside the branch
-            float4 v[4];
-#pragma unroll
-            for (int g = 0; g < (F16 ? 2 : 4); ++g) {
-                float e[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float l = from_left(P0, pt, 4 * g + i), rr = from_right(P2, pt, 4 * g + i);
-                    e[i] = (P1[pt][4 * g + i] + (useL ? l : 0.f)) + (useR ? rr : 0.f);
-                }
-                const int col = c0 + 8 * g + 4 * hh;
-                const float4 b = col < A.F ? *(const float4 *)(A.bias + br * A.F + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-                v[g] = make_float4(e[0] + b.x, e[1] + b.y, e[2] + b.z, e[3] + b.w);
-                if (A.relu) { v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f); }
-            }
-            if (!out) continue;
-#pragma unroll
-            for (int ql = 0; ql < (F16 ? 1 : 2); ++ql)
-                if (c0 + 16 * ql < A.F) shot_store_x3(A.Y3, A.Mp, m, hh, ((br * A.F + c0) >> 4) + ql, v[2 * ql], v[2 * ql + 1]);
-        }
-    }
+    shot_kw_epilogue<NT, PT, KT, F16>(acc, A.Y3, A.Mp, A.M, A.W, A.F, A.bias, A.relu, br, ng, mb, r, hh, xs);
 }
 
 // The weights of a cell in the order k_shot_conv_x3 reads them: round-to-nearest bf16 planes (svc_x3.h) of
@@ -722,6 +747,138 @@ __global__ __launch_bounds__(256) void k_shot_x3_weights(const float *__restrict
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
         if (pl < NPL) o[pl * 64] = P[pl].q;
+}
+
+// ---- the first cell (3 input channels) on the same pipe --------------------------------------------------------------------
+// Its input is the frames themselves: k_shot_in_x3 writes v / 255 as three bf16 planes [3][Mp][4 channels] (8 bytes per
+// position and plane, channel 3 = 0, SHOT_PAD zero positions in front).  K = 27 taps x 3 channels is far too short per tap for
+// a 16-deep step, so a step packs FOUR (kt, kh) pairs x 4 channels: pair pi = 4 q + 2 (j >> 2) + hh for element j of lane
+// (r, hh) (9 pairs in 3 steps, the last three empty), the kw taps stay in the accumulators and the 16 filters pack as in
+// k_shot_conv_x3's F16 form: 3 steps x 2 tiles x NP MFMAs per 32 positions and dilation (fp32 form: 54 x 64-cycle MFMAs).
+struct ShotFirst {
+    const uint2 *X3;        // [3 planes][Mp][4 bf16]
+    const uint4 *W3;        // [branch][3 steps][2 tiles][NPL planes][64 lanes] (k_shot_first_weights)
+    const float *bias;
+    uint4 *Y3;              // output planes [4][3][Mp][2] (64 channels: branch br = group br)
+    long long M, Mp;
+    int T, H, W, relu, xcd;
+};
+
+// uint8 [n][27][48][3] -> the three planes of v / 255 (tf.cast(float32) / 255., split exactly: svc_x3.h)
+__global__ __launch_bounds__(256) void k_shot_in_x3(const uint8_t *__restrict__ in, uint2 *__restrict__ out, long long M, long long Mp) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const uint8_t *p = in + i * 3;
+    uint32_t h[4], m[4], l[4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) x3_split1<false>((float)p[c] / 255.0f, h[c], m[c], l[c]);
+    h[3] = m[3] = l[3] = 0;
+    out[SHOT_PAD + i] = make_uint2(x3_pack(h[0], h[1]), x3_pack(h[2], h[3]));
+    out[Mp + SHOT_PAD + i] = make_uint2(x3_pack(m[0], m[1]), x3_pack(m[2], m[3]));
+    out[2 * Mp + SHOT_PAD + i] = make_uint2(x3_pack(l[0], l[1]), x3_pack(l[2], l[3]));
+    if (i < SHOT_PAD) out[i] = out[Mp + i] = out[2 * Mp + i] = make_uint2(0, 0);
+}
+
+__global__ __launch_bounds__(256) void k_shot_first_weights(const float *__restrict__ Wt, int Fpad, int kpad, int NPL, uint4 *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;             // (branch, step, tile, lane)
+    if (i >= 4 * 3 * 2 * 64) return;
+    const int lane = i & 63, r = lane & 31, hh = lane >> 5, wt = (i >> 6) & 1, q = (i >> 7) % 3, br = i / (3 * 2 * 64);
+    const int row = r & 15, kw = 2 * wt + (r >> 4);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int pi = 4 * q + 2 * (j >> 2) + hh;             // (kt, kh) pair of this element, channel j & 3
+        v[j] = (pi < 9 && kw < 3) ? Wt[((size_t)br * Fpad + row) * kpad + (pi * 3 + kw) * 4 + (j & 3)] : 0.f;
+    }
+    const X3 s = x3_split<true>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+    X3Q P[3];
+    P[0].v = s.h; P[1].v = s.m; P[2].v = s.l;
+    uint4 *o = out + (size_t)(((br * 3 + q) * 2 + wt) * NPL) * 64 + lane;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+        if (pl < NPL) o[pl * 64] = P[pl].q;
+}
+
+#define SHOT_FIRST_REP 4
+template <int PT, int NP>
+__global__ __launch_bounds__(256) void k_shot_first_x3(const ShotFirst A) {
+    constexpr int NPL = NP == 3 ? 2 : 3, KT = 2, WCH = 3 * KT * NPL * 64;
+    constexpr int WS = 32 * PT - 2, WGS = 4 * WS;
+    __shared__ uint4 sm_w[WCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int br = blockIdx.y, d = 1 << br, HW = A.H * A.W;
+    long long tile0 = blockIdx.x;
+    if (A.xcd) tile0 = (long long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (blockIdx.x == 0) shot_zero_pads(A.Y3, A.Mp, br, 1, tid);
+    if (tile0 * SHOT_FIRST_REP * WGS >= A.M) return;
+    for (int k = tid; k < WCH; k += 256) sm_w[k] = A.W3[(size_t)br * WCH + k];
+    __syncthreads();
+    // a workgroup's work on one tile is short (3 steps): SHOT_FIRST_REP consecutive tiles per workgroup share the weight
+    // copy and the launch (228 -> ... us per 800 frames)
+    for (int rep = 0; rep < SHOT_FIRST_REP; ++rep) {
+    const long long tile = tile0 * SHOT_FIRST_REP + rep;
+    if (tile * WGS >= A.M) break;
+    const long long mb = tile * WGS + wave * WS - 1;
+    int xs[PT];
+    unsigned off[PT][3][2];                                  // byte offset of the lane's pair (q, jg) inside a plane, 0 = the zero position
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const long long m = mb + 32 * pt + r;
+        const bool in = m >= 0 && m < A.M;
+        const long long mm = in ? m : 0, fr = mm / HW;
+        const int rem = (int)(mm - fr * HW), y = rem / A.W, x = rem - y * A.W, t = (int)(fr % A.T);
+        xs[pt] = x;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int jg = 0; jg < 2; ++jg) {
+                const int pi = 4 * q + 2 * jg + hh, kt = pi / 3, kh = pi - 3 * kt;
+                const bool ok = in && pi < 9 && (unsigned)(t + (kt - 1) * d) < (unsigned)A.T && (unsigned)(y + kh - 1) < (unsigned)A.H;
+                off[pt][q][jg] = ok ? (unsigned)((SHOT_PAD + mm + (long long)(kt - 1) * d * HW + (kh - 1) * A.W) * 8) : 0u;
+            }
+    }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)A.X3, 0, (int)(3 * A.Mp * 8), 0x00020000);
+    const unsigned planeB = (unsigned)(A.Mp * 8);
+    bf16x8 a[3][PT][NPL];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                X3Q t_;
+                const auto lo = __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)off[pt][q][0], (int)(pl * planeB), 0);
+                const auto hi = __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)off[pt][q][1], (int)(pl * planeB), 0);
+                t_.u[0] = lo[0]; t_.u[1] = lo[1]; t_.u[2] = hi[0]; t_.u[3] = hi[1];
+                a[q][pt][pl] = t_.v;
+            }
+    f32x16 acc[PT][KT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[pt][k][i] = 0.f;
+    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int wt = 0; wt < KT; ++wt) {
+            bf16x8 bw[NPL];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                X3Q t_;
+                t_.q = sm_w[((q * KT + wt) * NPL + pl) * 64 + lane];
+                bw[pl] = t_.v;
+            }
+#pragma unroll
+            for (int pr = (NP == 3 ? 3 : 0); pr < 6; ++pr)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+                    acc[pt][wt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[PW[pr]], a[q][pt][PA[pr]], acc[pt][wt], 0, 0, 0);
+        }
+    shot_kw_epilogue<1, PT, KT, true>(acc, A.Y3, A.Mp, A.M, A.W, 16, A.bias, A.relu, br, 0, mb, r, hh, xs);
+    }
 }
 
 // MaxPool3D (1, 2, 2), VALID, on the planes: one thread per (q, output position, hh).  A value is the exact sum of its three
@@ -839,12 +996,18 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
         // uint4 per cell: branches x groups x iterations x weight tiles x planes x 64 lanes
         auto w3_tiles = [&](const ShotCell &k) { return k.f == 16 ? (size_t)2 : (size_t)3 * (k.fpad / 32); };
         for (int i = 1; i < SHOT_L * SHOT_S; ++i) { w3_off[i] = tot; tot += (size_t)4 * 9 * (cells[i].cpad / 16) * w3_tiles(cells[i]) * NPL * 64; }
+        const size_t w3_first = tot;                          // the first cell's block behind the others
+        tot += (size_t)4 * 3 * 2 * NPL * 64;
+        w3_off[0] = w3_first;
         if (h->shot_w3_mx != mx) {
             int rc = h->shot_w3.ensure(tot * sizeof(uint4));
             if (rc) return rc;
+            k_shot_first_weights<<<(4 * 3 * 2 * 64 + 255) / 256, 256, 0, s>>>(blob + cells[0].w_off, cells[0].fpad, cells[0].kpad, NPL,
+                                                                              (uint4 *)h->shot_w3.p + w3_first);
+            SVC_CHECK_LAUNCH();
             for (int i = 1; i < SHOT_L * SHOT_S; ++i) {
                 const ShotCell &k = cells[i];
-                const int NT = k.fpad % 64 == 0 ? 2 : 1;
+                const int NT = 1;
                 const size_t total = (size_t)4 * 9 * (k.cpad / 16) * w3_tiles(k) * 64;         // threads: one per (tile, lane)
                 k_shot_x3_weights<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(blob + k.w_off, k.fpad, k.kpad, k.cpad, NT, NPL, k.f == 16,
                                                                                  (uint4 *)h->shot_w3.p + w3_off[i], total);
@@ -866,21 +1029,40 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
         const int nw = std::min(chunk, n_windows - w0);
         const size_t nfr = (size_t)nw * T;
         int H = SHOT_H, W = SHOT_W, cur = 0;
+        const bool first_x3 = mx != 0;
         {
             const size_t npix = nfr * H * W;
-            k_shot_in<<<(unsigned)((npix + 255) / 256), 256, 0, s>>>(frames + (size_t)w0 * T * H * W * 3, P[0], npix);
+            if (first_x3)
+                k_shot_in_x3<<<(unsigned)((npix + 255) / 256), 256, 0, s>>>(frames + (size_t)w0 * T * H * W * 3, (uint2 *)P[0], (long long)npix,
+                                                                           (long long)((npix + SHOT_PAD + 3) / 4 * 4));
+            else
+                k_shot_in<<<(unsigned)((npix + 255) / 256), 256, 0, s>>>(frames + (size_t)w0 * T * H * W * 3, P[0], npix);
             SVC_CHECK_LAUNCH();
         }
         for (int b = 0; b < SHOT_L; ++b) {
             const long long Mc = (long long)nfr * H * W, Mp = (Mc + SHOT_PAD + 3) / 4 * 4;       // plane stride of this resolution
             for (int c = 0; c < SHOT_S; ++c) {
                 const ShotCell &k = cells[b * SHOT_S + c];
+                if (first_x3 && b == 0 && c == 0) {
+                    ShotFirst X;
+                    X.X3 = (const uint2 *)P[cur]; X.W3 = (const uint4 *)h->shot_w3.p + w3_off[0]; X.bias = blob + k.b_off; X.Y3 = (uint4 *)P[cur ^ 1];
+                    X.M = Mc; X.Mp = Mp; X.T = T; X.H = H; X.W = W; X.relu = 1; X.xcd = h->shot_xcd;
+                    const int PT = h->shot_pt, WGS = 4 * (32 * PT - 2) * SHOT_FIRST_REP;
+                    unsigned gx = (unsigned)((Mc + WGS - 1) / WGS);
+                    if (X.xcd) gx = (gx + 7) / 8 * 8;
+                    dim3 grid(gx, 4);
+                    if (mx == 3) { if (PT == 2) k_shot_first_x3<2, 3><<<grid, 256, 0, s>>>(X); else k_shot_first_x3<1, 3><<<grid, 256, 0, s>>>(X); }
+                    else { if (PT == 2) k_shot_first_x3<2, 6><<<grid, 256, 0, s>>>(X); else k_shot_first_x3<1, 6><<<grid, 256, 0, s>>>(X); }
+                    SVC_CHECK_LAUNCH();
+                    cur ^= 1;
+                    continue;
+                }
                 if (mx && k.cpad >= 64) {
                     ShotX3 X;
                     X.X3 = (const uint4 *)P[cur]; X.W3 = (const uint4 *)h->shot_w3.p + w3_off[b * SHOT_S + c]; X.bias = blob + k.b_off;
                     X.Y3 = (uint4 *)P[cur ^ 1]; X.M = Mc; X.Mp = Mp; X.T = T; X.H = H; X.W = W; X.C = k.cpad; X.F = k.f; X.Fpad = k.fpad;
                     X.relu = 1; X.xcd = h->shot_xcd;
-                    const int NT = k.fpad % 64 == 0 ? 2 : 1, PT = h->shot_pt;
+                    const int NT = 1, PT = h->shot_pt;
                     const bool f16 = k.f == 16;
                     const int WGS = 4 * (32 * PT - 2);
                     unsigned gx = (unsigned)((Mc + WGS - 1) / WGS);
@@ -890,7 +1072,6 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
 #define SHOT_X3(NT_, PT_, NP_, F16_) k_shot_conv_x3<NT_, PT_, NP_, F16_><<<grid, 256, lds, s>>>(X)
 #define SHOT_X3_NP(NP_)                                                                                              \
                     if (f16) { if (PT == 2) SHOT_X3(1, 2, NP_, true); else SHOT_X3(1, 1, NP_, true); }               \
-                    else if (NT == 2) { if (PT == 2) SHOT_X3(2, 2, NP_, false); else SHOT_X3(2, 1, NP_, false); }    \
                     else { if (PT == 2) SHOT_X3(1, 2, NP_, false); else SHOT_X3(1, 1, NP_, false); }
                     if (mx == 3) { SHOT_X3_NP(3) } else { SHOT_X3_NP(6) }
 #undef SHOT_X3_NP
@@ -905,7 +1086,7 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
                 A.logC = 0;
                 while ((1 << A.logC) < k.cpad) ++A.logC;
                 A.F = k.f; A.Fpad = k.fpad; A.kpad = k.kpad; A.ntaps = 27; A.ldy = 4 * k.f; A.relu = 1;
-                A.Y3 = mx ? (uint4 *)P[cur ^ 1] : nullptr; A.Mp = Mp;
+                A.ksplit = 1;
                 dim3 grid((unsigned)((A.M + 127) / 128), (unsigned)(4 * (k.fpad / 32)));
                 const int shot_form = h->shot_form;             // 0: direct operand loads, 1: weights through LDS, 2: both operands (SVC_SHOT_FORM)
                 if (shot_form == 2 && k.cpad >= 64 && k.cpad % 64 == 0) {
@@ -949,12 +1130,15 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
             const int nflat = H * W * 4 * (SHOT_F << (SHOT_L - 1));
             A.X = P[cur]; A.Wt = blob + d1w; A.bias = blob + d1b; A.Y = P[cur ^ 1];
             A.M = (long long)nfr; A.T = 1; A.H = 1; A.W = 1; A.C = nflat; A.logC = 0;
-            A.F = SHOT_D; A.Fpad = SHOT_D; A.kpad = nflat; A.ntaps = 1; A.ldy = SHOT_D; A.relu = 1; A.Y3 = nullptr; A.Mp = 0;
-            dim3 grid((unsigned)((A.M + 127) / 128), (unsigned)(SHOT_D / 32));
+            A.F = SHOT_D; A.Fpad = SHOT_D; A.kpad = nflat; A.ntaps = 1; A.ldy = SHOT_D; A.relu = 1;
+            // 7 x 8 workgroups of 576 steps leave the chip idle (184 us per 800 frames): K in eight parts, summed by the head
+            A.ksplit = nflat % (8 * 8) == 0 ? 8 : 1;
+            dim3 grid((unsigned)((A.M + 127) / 128), (unsigned)(SHOT_D / 32), (unsigned)A.ksplit);
             k_shot_conv<<<grid, 256, 0, s>>>(A);
             SVC_CHECK_LAUNCH();
             cur ^= 1;
-            k_shot_head<<<(unsigned)nfr, 64, 0, s>>>(P[cur], blob + d2w, blob + d2b, probs + (size_t)w0 * T, (int)nfr);
+            k_shot_head<<<(unsigned)nfr, 64, 0, s>>>(P[cur], blob + d2w, blob + d2b, probs + (size_t)w0 * T, (int)nfr,
+                                                     A.ksplit > 1 ? A.ksplit : 0, blob + d1b);
             SVC_CHECK_LAUNCH();
         }
     }

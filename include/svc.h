@@ -254,8 +254,8 @@ int svc_front_fused(const SvcHandle *h);
  * (v_mfma_f32_32x32x2_f32: exact f32 products, rounds 1-4), 6 = split-bf16 operands on v_mfma_f32_32x32x16_bf16 (every f32
  * operand as three bf16 planes = its 24 significant bits, six plane pairs per product, f32 accumulation: csrc/svc_net.hip,
  * "Split-bf16 operands").  Chosen when the handle is created (environment SVC_MX=f32 | bf16x6; default bf16x6: ~10 %
- * faster, every parity gate of the fp32 pipe unchanged, bit-reproducible with several streams sharing the chip once
- * k_smooth_down_mfma runs alone on its CU -- DESIGN.md 5); bench.py
+ * faster, every parity gate of the fp32 pipe unchanged, bit-reproducible with several streams sharing the chip -- the one
+ * kernel that was not, the smoothing kernel, computes its bilinear stage with scalar instructions since: DESIGN.md 5); bench.py
  * reports it as roofline.matrix_pipe.  No interface of the reference corresponds to it (its arithmetic type is f32 either way). */
 int svc_matrix_pipe(const SvcHandle *h);
 /* svc_transnet_matrix_pipe: the same for the TransNet cells with >= 64 input channels (svc_transnet_predict): 0 = fp32 MFMA,

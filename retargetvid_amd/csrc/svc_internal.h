@@ -119,8 +119,8 @@ struct SvcHandle {
     hipEvent_t depth_ev[8] = {};       // recorded behind the upload of a slot; waited on before the slot is rewritten
     std::map<std::tuple<const void *, int, int, int>, DevBuf> lane_w;   // split-K layers' weights in lane order (svc_net.hip: lane_weights), keyed by (matrix, row stride, K, padded N)
     std::map<std::tuple<const void *, int, int, int>, DevBuf> x3_w;     // split-bf16 copies of weight matrices (svc_net.hip: x3_weights), keyed by (matrix, row stride, K, 2 * padded N + order)
-    int mx = 6;                        // matrix pipe of the 1x1-convolution GEMMs: 6 = split-bf16 operands, six plane pairs on v_mfma_f32_32x32x16_bf16 (round 5, the default: a pass 1.42 -> 1.24 ms alone, 1.01 -> 0.87 ms with four passes sharing the chip, every parity gate unchanged); 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, rounds 1-4: SVC_MX=f32).  With 6, k_smooth_down_mfma takes a CU to itself (sd_excl): the one kernel found to miscompute beside bf16 workgroups
-    int sd_excl = -1;                  // k_smooth_down_mfma alone on its CU (an LDS request nothing fits beside): -1 = when the split-bf16 pipe is on, 0 / 1 = never / always (SVC_SD_EXCL)
+    int mx = 6;                        // matrix pipe of the 1x1-convolution GEMMs: 6 = split-bf16 operands, six plane pairs on v_mfma_f32_32x32x16_bf16 (round 5, the default: a pass 1.42 -> 1.24 ms alone, 1.01 -> 0.87 ms with four passes sharing the chip, every parity gate unchanged); 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, rounds 1-4: SVC_MX=f32).  The one kernel found to miscompute beside bf16 workgroups, the smoothing kernel, lost a product in a packed-instruction sequence of its bilinear stage: written with scalar instructions since (sd_bilinear)
+    int sd_excl = 0;                   // 1: k_smooth_down_mfma alone on its CU (an LDS request nothing fits beside): the containment used before sd_bilinear, kept for A/B runs (SVC_SD_EXCL)
     unsigned irb_mx = 0x1b;            // ... which of k_irb's five fixed-shape instances take that form for their expand GEMM (bit = block 2, 3, 4, 5-6, 7; SVC_IRB_MX).  Measured per instance against the fp32 form, us per pass alone / shared: -17 / -11, -12 / -7, +11 / +11 (block 4: Cin = 24 pads its second step, two halo tiles per wave: 36 spilled registers), -11 / -4, -10 / -6: block 4 stays fp32
     unsigned mx_mask = 0xff;           // ... and which kernel families: bit 0 k_pwr, 1 k_irb, 2 k_dwpw, 3 k_pw_sk, 4 k_pwpw (SVC_MX_MASK; for A/B timing)
     bool sk_lane = true;               // k_pw_sk reads its weights from the lane-order copy: a wave's load is 1 KB contiguous instead of 32 rows x 32 B (SVC_SK_LANE=0: from the [N][K] matrix)

@@ -1429,7 +1429,47 @@ __device__ __forceinline__ float dec_f32(unsigned u) {
 // consecutive px -- float4 writes into the smoothed-row tile.  The bilinear down-scale and the running maximum are
 // those of k_smooth_down.  The sum over the 49 taps is grouped by the MFMA (pairs of taps) instead of one chain of
 // FMAs, a difference of a few ulp.
+// The bilinear blend  ly0 (lx0 a00 + lx1 a01) + ly1 (lx0 a10 + lx1 a11)  as nine SCALAR VALU instructions (the IEEE operations of
+// the C expression, in its order: results unchanged).  Written in C the compiler packs it --
+//     v_pk_mul_f32 (lx0 a10, lx1 a01) ; v_pk_mul_f32 (lx0 a00, lx1 a11) ; v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]
+// -- and in that form, with workgroups of the bf16-pipe kernels (k_pwr above all) sharing the CU, 1 - 6 % of the passes had the
+// product lx1 * a11 MISSING from the sum in lanes 48..63 of one wavefront: the self-check build (-DSD_DEBUG -DSD_PACKED: second
+// evaluation + read-back) logged the operands in the registers as correct and the stored value as the sum without that term,
+// 17 - 151 events per 1 600 - 2 400 passes in four code shapes (waits and s_nop 7 in front of the packed instructions change
+// nothing); with the products or the additions as scalar instructions: 0 of 3 200 passes, twice.  The bare instruction sequence
+// in a kernel of its own beside the same co-runners is NOT hit (tools/micro/pk_opsel_victim.hip), so the trigger needs more of
+// this kernel's context than the three instructions; what is established is where the value is lost and what removes it
+// (profiles/r05_mx_reproducibility.txt, item 7).
+__device__ __forceinline__ float sd_bilinear(float lx0, float lx1, float ly0, float ly1, float a00, float a01, float a10, float a11) {
+#ifdef SD_PACKED
+    return ly0 * (lx0 * a00 + lx1 * a01) + ly1 * (lx0 * a10 + lx1 * a11);      // the compiler's packed form: reproduces the loss
+#else
+    float p00, p01, p10, p11, r0, r1, q0, q1, v;
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p00) : "v"(lx0), "v"(a00));
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p01) : "v"(lx1), "v"(a01));
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p10) : "v"(lx0), "v"(a10));
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p11) : "v"(lx1), "v"(a11));
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(r0) : "v"(p00), "v"(p01));
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(r1) : "v"(p10), "v"(p11));
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q0) : "v"(ly0), "v"(r0));
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q1) : "v"(ly1), "v"(r1));
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(v) : "v"(q0), "v"(q1));
+    return v;
+#endif
+}
+
 #define SD_KP 56          // taps per phase, padded to a multiple of 8
+#ifdef SD_DEBUG
+// Diagnostic build (make EXTRA="-DSD_DEBUG -DSD_PACKED" OUT=../libsvc_hip_sddbg.so): the bilinear stage evaluates every pixel TWICE
+// from LDS and reads its store back; a disagreement is logged (svc_debug_sd_log; tools/soak_network_concurrent.py prints the records).
+__device__ unsigned g_sd_count[4];
+__device__ float g_sd_log[64][16];
+extern "C" int svc_debug_sd_log(unsigned *count4, float *rec64x16) {
+    if (hipMemcpyFromSymbol(count4, HIP_SYMBOL(g_sd_count), sizeof(unsigned) * 4) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(rec64x16, HIP_SYMBOL(g_sd_log), sizeof(float) * 64 * 16) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 __global__ __launch_bounds__(256) void k_smooth_down_mfma(const float *__restrict__ logit, const float *__restrict__ phase,
                                                           float *__restrict__ pre, unsigned *__restrict__ fmax, int LH,
                                                           int LW, int NH, int NW, int h, int w, int rows_per_block,
@@ -1501,10 +1541,39 @@ __global__ __launch_bounds__(256) void k_smooth_down_mfma(const float *__restric
         int y1 = y0 + (y0 < NH - 1 ? 1 : 0), x1 = x0 + (x0 < NW - 1 ? 1 : 0);
         float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
         const float *t0 = tile + (y0 - ylo) * NW, *t1 = tile + (y1 - ylo) * NW;
-        float v = ly0 * (lx0 * t0[x0] + lx1 * t0[x1]) + ly1 * (lx0 * t1[x0] + lx1 * t1[x1]);
+        const float v = sd_bilinear(lx0, lx1, ly0, ly1, t0[x0], t0[x1], t1[x0], t1[x1]);
         pre[((size_t)f * h + oy) * w + ox] = v;
         lmax = fmaxf(lmax, v);
     }
+#ifdef SD_DEBUG
+    __threadfence();
+    __syncthreads();
+    for (int idx = tid; idx < (oy1 - oy0) * w; idx += 256) {
+        uint32_t ox;
+        const int oy = oy0 + (int)fdivmod((uint32_t)idx, dw, ox);
+        float sy = fmaxf(scy * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(scx * (ox + 0.5f) - 0.5f, 0.f);
+        int y0 = (int)sy, x0 = (int)sx;
+        int y1 = y0 + (y0 < NH - 1 ? 1 : 0), x1 = x0 + (x0 < NW - 1 ? 1 : 0);
+        float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const volatile float *t0 = tile + (y0 - ylo) * NW, *t1 = tile + (y1 - ylo) * NW;
+        const float a00 = t0[x0], a01 = t0[x1], a10 = t1[x0], a11 = t1[x1];
+        const float v2 = ly0 * (lx0 * a00 + lx1 * a01) + ly1 * (lx0 * a10 + lx1 * a11);
+        const float rb = __builtin_nontemporal_load(pre + ((size_t)f * h + oy) * w + ox);      // what memory holds now
+        atomicAdd(&g_sd_count[3], 1u);
+        if (rb != v2) {
+            // a third evaluation tells a wrong first evaluation (v3 == v2 != rb) from an unstable one
+            const float v3 = ly0 * (lx0 * t0[x0] + lx1 * t0[x1]) + ly1 * (lx0 * t1[x0] + lx1 * t1[x1]);
+            const unsigned slot = atomicAdd(&g_sd_count[0], 1u);
+            if (slot < 64) {
+                float *o = g_sd_log[slot];
+                o[0] = (float)f; o[1] = (float)oy; o[2] = (float)ox; o[3] = (float)tid; o[4] = rb; o[5] = v2; o[6] = v3;
+                o[7] = a00; o[8] = a01; o[9] = a10; o[10] = a11; o[11] = lx1; o[12] = ly1; o[13] = (float)blockIdx.x;
+                o[14] = (float)(__builtin_amdgcn_s_getreg((4 << 0) | (8 << 6) | (3 << 11)));       // HW_ID: cu id bits 8..11
+                o[15] = (float)__builtin_amdgcn_s_getreg((4 << 0) | (4 << 6) | (1 << 11));          // HW_ID: simd id bits 4..5
+            }
+        }
+    }
+#endif
     for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
     if ((tid & 63) == 0) wmax[tid >> 6] = enc_f32(lmax);
     __syncthreads();
@@ -1555,7 +1624,7 @@ __global__ __launch_bounds__(256) void k_smooth_down(const float *__restrict__ l
         int y1 = y0 + (y0 < NH - 1 ? 1 : 0), x1 = x0 + (x0 < NW - 1 ? 1 : 0);
         float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
         const float *t0 = tile + (y0 - ylo) * NW, *t1 = tile + (y1 - ylo) * NW;
-        float v = ly0 * (lx0 * t0[x0] + lx1 * t0[x1]) + ly1 * (lx0 * t1[x0] + lx1 * t1[x1]);
+        const float v = sd_bilinear(lx0, lx1, ly0, ly1, t0[x0], t0[x1], t1[x0], t1[x1]);
         pre[((size_t)f * h + oy) * w + ox] = v;
         lmax = fmaxf(lmax, v);
     }
@@ -3197,13 +3266,10 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
         dim3 grid(ceil_div(p->h, p->sd_rows), n);
         if (h->smooth_mfma && NW % 8 == 0 && NW == 8 * W3 && NH == 8 * H3) {
             size_t lds = ((size_t)H3 * W3 + 64 * SD_KP + (size_t)p->sd_tile_cap * NW) * sizeof(float);
-            // With the split-bf16 pipe on (h->mx, the default), this kernel gets a CU to itself (an LDS request nothing fits beside):
-            // its results were found changed -- 16 consecutive pixels of one wavefront, 1 - 6 % of the passes -- when its workgroups
-            // shared a CU with workgroups of the bf16 kernels of OTHER streams (tools/soak_network_concurrent.py,
-            // profiles/r05_mx_reproducibility.txt; cause not found: its LDS canaries stay intact, a stand-in kernel of the same shape
-            // is never hit).  Alone on the CU: 0 of 26 000 passes and 0 of 697 multi-video jobs differ, as with the fp32 pipe, and
-            // the pass is no slower (the kernel is 2 % of it).
-            if (h->sd_excl < 0 ? h->mx != 0 : h->sd_excl != 0) {
+            // SVC_SD_EXCL=1: the kernel alone on its CU (an LDS request nothing fits beside).  That was the containment of the lost
+            // product in its bilinear stage before the stage was rewritten with scalar instructions (sd_bilinear above); off by
+            // default since -- the soaks are clean without it -- and kept as a knob for A/B runs with the -DSD_PACKED build.
+            if (h->sd_excl > 0) {
                 lds = std::max(lds, (size_t)150 * 1024);
                 if (h->lds_attr_done.insert((const void *)k_smooth_down_mfma).second)
                     SVC_HIP(hipFuncSetAttribute((const void *)k_smooth_down_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));

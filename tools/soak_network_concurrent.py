@@ -28,7 +28,7 @@ outs = [torch.empty_like(ref) for _ in range(N)]
 VICTIM = int(os.environ.get('VICTIM', '0'))
 if VICTIM:
     import ctypes
-    vl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'micro', 'libvictim.so'))
+    vl = ctypes.CDLL(os.environ.get('VICTIM_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'micro', 'libvictim.so'))   # VICTIM_LIB: tools/micro/libpkvictim.so = the packed-instruction probes
     vl.victim_launch.argtypes = [ctypes.c_void_p]
     vl.victim_diffs.restype = ctypes.c_uint64
     assert vl.victim_init() == 0
@@ -71,5 +71,20 @@ for it in range(ITERS):
 print('%d passes, %d with a map that differs from the reference' % (ITERS * N, bad))
 if VICTIM:
     print('stand-in victim: %d launches, %d words differ from its lone run' % (VICTIM * ITERS, vl.victim_diffs()))
+    if hasattr(vl, 'victim_report'):
+        rep = (ctypes.c_uint64 * 16)()
+        vl.victim_report(rep)
+        for t, name in enumerate(('pk_mul x2 + pk_add op_sel swap', 'pk_add op_sel swap alone', 'pk_mul x2 + scalar adds', 'pk_mul x2 + pk_add, no swap')):
+            print('   test %d (%s): disagreements with the scalar instructions, by quarter of the wavefront (lanes 0-15 .. 48-63): %s' % (t, name, [int(rep[t * 4 + q]) for q in range(4)]))
+if hasattr(engs[0].lib, 'svc_debug_sd_log'):              # the -DSD_DEBUG build: what the smoothing kernel's self-check saw
+    import ctypes
+    cnt = (ctypes.c_uint * 4)()
+    rec = np.zeros((64, 16), np.float32)
+    assert engs[0].lib.svc_debug_sd_log(cnt, rec.ctypes.data_as(ctypes.c_void_p)) == 0
+    print('smoothing kernel self-check: %d pixels checked, %d with memory != second evaluation' % (cnt[3], cnt[0]))
+    print('   frame oy ox tid | memory  second  third (variant 3: first pass t1[x1]) | tile a00 a01 a10 a11 | lx1 ly1 | block cu simd (variant 3: first pass t1[x0], its t1[x1] index, the index now)')
+    for r_ in rec[:min(int(cnt[0]), 64)]:
+        print('   %3d %3d %3d %3d | %.6f %.6f %.6g | %.5f %.5f %.5f %.5f | %.4f %.4f | %.6g %d %d' % (r_[0], r_[1], r_[2], r_[3], r_[4], r_[5], r_[6], r_[7], r_[8], r_[9],
+                                                                                                  r_[10], r_[11], r_[12], r_[13], r_[14], r_[15]))
 if os.environ.get('SVC_SD_POISON'):
     print('LDS canary words the smoothing kernel found changed, per engine: %s' % [e.threshold_census()['maps'] for e in engs])

@@ -10,6 +10,8 @@
 //   test 1: the products by scalar v_mul_f32, then v_pk_add op_sel:[0,1] op_sel_hi:[1,0] alone
 //   test 2: v_pk_mul, v_pk_mul, then the additions by scalar v_add_f32 (the packed products read half by half)
 //   test 3: v_pk_mul, v_pk_mul, v_pk_add WITHOUT op_sel (operands arranged so that no half is swapped)
+//   tests 4-7 (second kernel, k_pkvictim_lds): test 0's sequence with the four a-values arriving from an LDS tile through the
+//   smoothing kernel's own addressing (bilinear read-out of a 14 x 416 tile), 256- and 1024-thread workgroups, 44 KB of LDS
 // hipcc -O3 --offload-arch=gfx950 -shared -fPIC tools/micro/pk_opsel_victim.hip -o tools/micro/libpkvictim.so
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -62,26 +64,65 @@ __global__ __launch_bounds__(256) void k_pkvictim(unsigned long long *cnt, int i
     for (int t = 0; t < 4; ++t)
         if (bad[t]) atomicAdd(cnt + t * 4 + q, (unsigned long long)bad[t]);
 }
+// test 4 (256 threads) / 5 (1024 threads): the operands come from LDS as in k_smooth_down's bilinear stage
+#define TNW 416
+#define TROWS 14
+template <int NTH>
+__global__ __launch_bounds__(NTH) void k_pkvictim_lds(unsigned long long *cnt, int iters, int slot) {
+    extern __shared__ float tile[];
+    const int tid = threadIdx.x, q = (tid & 63) >> 4, b = blockIdx.x;
+    for (int i = tid; i < TROWS * TNW; i += NTH) {
+        const uint32_t h = (uint32_t)(b * 7919 + i) * 2654435761u;
+        tile[i] = (float)(h >> 8) * (1.0f / 16777216.0f) + (float)(i % TNW) * 0.001f;
+    }
+    __syncthreads();
+    const float scy = 256.0f / 140.0f, scx = 416.0f / 250.0f;
+    unsigned bad = 0;
+    for (int it = 0; it < iters; ++it)
+        for (int idx = tid; idx < 7 * 250; idx += NTH) {
+            const int oyr = idx / 250, ox = idx - oyr * 250;
+            const float sy = fmaxf(scy * (oyr + 0.5f) - 0.5f, 0.f), sx = fmaxf(scx * (ox + 0.5f) - 0.5f, 0.f);
+            const int y0 = (int)sy, x0 = (int)sx, y1 = y0 + (y0 < TROWS - 1 ? 1 : 0), x1 = x0 + (x0 < TNW - 1 ? 1 : 0);
+            const float lx1 = sx - x0, lx0 = 1.f - lx1;
+            const float *t0 = tile + y0 * TNW, *t1 = tile + y1 * TNW;
+            float a00 = t0[x0], a01 = t0[x1], a10 = t1[x0], a11 = t1[x1];
+            f2 m1 = {a10, a01}, m2 = {a00, a11}, d;
+            const f2 L = {lx0, lx1};
+            asm volatile("v_pk_mul_f32 %0, %2, %0\n\tv_pk_mul_f32 %1, %2, %1" : "+v"(m1), "+v"(m2) : "v"(L));
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(m1), "v"(m2));
+            float p00, p01, p10, p11, r0, r1;
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p00) : "v"(lx0), "v"(a00));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p01) : "v"(lx1), "v"(a01));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p10) : "v"(lx0), "v"(a10));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p11) : "v"(lx1), "v"(a11));
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(r0) : "v"(p00), "v"(p01));
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(r1) : "v"(p10), "v"(p11));
+            bad += (d.x != r1) + (d.y != r0);
+        }
+    if (bad) atomicAdd(cnt + slot * 4 + q, (unsigned long long)bad);
+}
 static unsigned long long *g_cnt = nullptr;
 static unsigned long long g_launches = 0;
 extern "C" int victim_init() {
-    if (hipMalloc(&g_cnt, 16 * 8)) return -1;
-    hipMemset(g_cnt, 0, 16 * 8);
+    if (hipMalloc(&g_cnt, 32 * 8)) return -1;
+    hipMemset(g_cnt, 0, 32 * 8);
     return (int)hipDeviceSynchronize();
 }
 extern "C" int victim_launch(void *stream) {
     ++g_launches;
     k_pkvictim<<<1024, 256, 0, (hipStream_t)stream>>>(g_cnt, 400);
+    k_pkvictim_lds<256><<<640, 256, TROWS * TNW * 4, (hipStream_t)stream>>>(g_cnt, 8, 4);
+    k_pkvictim_lds<1024><<<320, 1024, TROWS * TNW * 4, (hipStream_t)stream>>>(g_cnt, 16, 5);
     return (int)hipGetLastError();
 }
 extern "C" unsigned long long victim_diffs() {
-    unsigned long long h[16], t = 0;
+    unsigned long long h[32], t = 0;
     hipDeviceSynchronize();
     hipMemcpy(h, g_cnt, sizeof h, hipMemcpyDeviceToHost);
-    for (int i = 0; i < 16; ++i) t += h[i];
+    for (int i = 0; i < 32; ++i) t += h[i];
     return t;
 }
-extern "C" int victim_report(unsigned long long *out16) {
+extern "C" int victim_report(unsigned long long *out32) {
     hipDeviceSynchronize();
-    return (int)hipMemcpy(out16, g_cnt, 16 * 8, hipMemcpyDeviceToHost);
+    return (int)hipMemcpy(out32, g_cnt, 32 * 8, hipMemcpyDeviceToHost);
 }

@@ -72,9 +72,9 @@ print('%d passes, %d with a map that differs from the reference' % (ITERS * N, b
 if VICTIM:
     print('stand-in victim: %d launches, %d words differ from its lone run' % (VICTIM * ITERS, vl.victim_diffs()))
     if hasattr(vl, 'victim_report'):
-        rep = (ctypes.c_uint64 * 16)()
+        rep = (ctypes.c_uint64 * 32)()
         vl.victim_report(rep)
-        for t, name in enumerate(('pk_mul x2 + pk_add op_sel swap', 'pk_add op_sel swap alone', 'pk_mul x2 + scalar adds', 'pk_mul x2 + pk_add, no swap')):
+        for t, name in enumerate(('pk_mul x2 + pk_add op_sel swap', 'pk_add op_sel swap alone', 'pk_mul x2 + scalar adds', 'pk_mul x2 + pk_add, no swap', 'test 0 with operands from LDS, 256 threads', 'test 0 with operands from LDS, 1024 threads')):
             print('   test %d (%s): disagreements with the scalar instructions, by quarter of the wavefront (lanes 0-15 .. 48-63): %s' % (t, name, [int(rep[t * 4 + q]) for q in range(4)]))
 if hasattr(engs[0].lib, 'svc_debug_sd_log'):              # the -DSD_DEBUG build: what the smoothing kernel's self-check saw
     import ctypes

@@ -162,6 +162,7 @@ struct SvcHandle {
     int shot_w3_mx = 0;
     int shot_mx = -1;                  // TransNet cells' matrix pipe: -1 = follow mx, 0 = fp32, 6 = bf16x6, 3 = bf16x3 (SVC_SHOT_MX)
     int shot_pt = 2;                   // 32-position tiles per wavefront of k_shot_conv_x3 (SVC_SHOT_PT: 1 | 2)
+    int shot_m16 = 3;                  // > 0: the cells with >= 64 input channels on v_mfma_f32_16x16x32_bf16 (k_shot_conv_x3m), value = 16-position tiles per wavefront (2, 3, 4); 0: on 32x32x16 (k_shot_conv_x3) (SVC_SHOT_M16)
     int shot_xcd = 1;                  // XCD-aware tile order of k_shot_conv_x3 (SVC_SHOT_XCD)
     bool shot_loaded = false;
     int shot_form = 2;                 // TransNet convolution cells: 0 = operands straight from global memory (k_shot_conv), 1 = weights through LDS, 2 = both operands through LDS with whole-line loads (SVC_SHOT_FORM)

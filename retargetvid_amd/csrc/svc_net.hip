@@ -3490,6 +3490,8 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->shot_mx = !strcmp(env, "bf16x6") ? 6 : !strcmp(env, "bf16x3") ? 3 : !strcmp(env, "f32") ? 0 : atoi(env);
     env = getenv("SVC_SHOT_PT");
     if (env) h->shot_pt = atoi(env) == 1 ? 1 : 2;
+    env = getenv("SVC_SHOT_M16");
+    if (env) { const int v = atoi(env); h->shot_m16 = v >= 2 && v <= 4 ? v : 0; }
     env = getenv("SVC_SHOT_XCD");
     if (env) h->shot_xcd = atoi(env) != 0;
     env = getenv("SVC_PRIM_PT");

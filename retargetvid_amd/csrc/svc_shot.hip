@@ -714,6 +714,186 @@ __global__ __launch_bounds__(256) void k_shot_conv_x3(const ShotX3 A) {
     shot_kw_epilogue<NT, PT, KT, F16>(acc, A.Y3, A.Mp, A.M, A.W, A.F, A.bias, A.relu, br, ng, mb, r, hh, xs);
 }
 
+// The same cell on v_mfma_f32_16x16x32_bf16 (SVC_SHOT_M16): 16 filters x 16 positions per MFMA, 32 channels deep.  Why a second
+// shape: the 16-filter cell fills its weight tiles (3 kw tiles of 16 filters instead of two 32-row tiles of which one is half
+// empty: a quarter fewer MFMAs), and under the chip's clock management the 16x16x32 shape sustains more FLOP/s than 32x32x16
+// (MI355X_MICROARCH.md, DVFS).  Lane (p, g) = (lane & 15, lane >> 4) holds the eight channels of k group g of one position /
+// filter; group g is the uint4 (q = 2 s + (g >> 1), hh = g & 1) of the planar layout, so the position operand is still a plain
+// load (two runs of 512 bytes per instruction) and the kw taps stay in the accumulators (f32x4 per tile).  A lane ends with
+// filters 4 g .. 4 g + 3 of one position: half a uint4 per plane (8-byte stores).  Iteration = (32-channel group s, kt, kh).
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+template <int NT, int PT, int NP>
+__global__ __launch_bounds__(256) void k_shot_conv_x3m(const ShotX3 A) {
+    extern __shared__ uint4 sm_w3[];
+    constexpr int NPL = NP == 3 ? 2 : 3;
+    constexpr int KT = 3 * NT;                               // weight tiles (kw, n) of 16 filters per iteration
+    constexpr int WCH = KT * NPL * 64;
+    constexpr int WPT = (WCH + 255) / 256;
+    constexpr int WS = 16 * PT - 2, WGS = 4 * WS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, g = lane >> 4;
+    const int groups = A.F / (16 * NT), br = blockIdx.y / groups, ng = blockIdx.y - br * groups;
+    const int d = 1 << br, HW = A.H * A.W, niter = 9 * (A.C >> 5);
+    long long tile = blockIdx.x;
+    if (A.xcd) tile = (long long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (blockIdx.x == 0) shot_zero_pads(A.Y3, A.Mp, (br * A.F + ng * 16 * NT) >> 4, NT, tid);
+    if (tile * WGS >= A.M) return;
+    const long long mb = tile * WGS + wave * WS - 1;
+    const unsigned planeB = (unsigned)(A.Mp * 32);
+    const unsigned goff = (unsigned)((g & 1) * 16) + (unsigned)(g >> 1) * 3u * planeB;      // the lane's k group: half hh of group q + (g >> 1)
+    unsigned vo[PT], okb[PT];
+    int xs[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const long long m = mb + 16 * pt + p;
+        const bool in = m >= 0 && m < A.M;
+        const long long mm = in ? m : 0, fr = mm / HW;
+        const int rem = (int)(mm - fr * HW), y = rem / A.W, x = rem - y * A.W, t = (int)(fr % A.T);
+        unsigned b = 0;
+        for (int k = 0; k < 9; ++k) {
+            const int kt = k / 3, kh = k - 3 * kt;
+            const bool ok = in && (unsigned)(t + (kt - 1) * d) < (unsigned)A.T && (unsigned)(y + kh - 1) < (unsigned)A.H;
+            b |= (unsigned)ok << k;
+        }
+        okb[pt] = b;
+        xs[pt] = x;
+        vo[pt] = (unsigned)((SHOT_PAD + mm) * 32) + goff;
+    }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)A.X3, 0, (int)((size_t)(A.C >> 4) * 3 * A.Mp * 32), 0x00020000);
+    const uint4 *wsrc = A.W3 + (size_t)(br * groups + ng) * niter * WCH + tid;
+    bf16x8 a[2][PT][NPL], bw[2][NPL];
+#define SHOT_LDA(set_, it_)                                                                                          \
+    {                                                                                                                \
+        const int s_ = (it_) / 9, k_ = (it_) - 9 * s_, kt_ = k_ / 3, kh_ = k_ - 3 * kt_;                             \
+        const int sh_ = (((kt_ - 1) * d * HW) + (kh_ - 1) * A.W) * 32;                                               \
+        _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) {                                                          \
+            const unsigned v_ = ((it_) < niter && ((okb[pt] >> k_) & 1)) ? vo[pt] + sh_ : goff;                      \
+            _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                                     \
+                X3Q t_;                                                                                              \
+                const auto ld_ = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)v_, (int)((unsigned)(s_ * 6 + pl) * planeB), 0); \
+                t_.u[0] = ld_[0]; t_.u[1] = ld_[1]; t_.u[2] = ld_[2]; t_.u[3] = ld_[3];                              \
+                a[set_][pt][pl] = t_.v;                                                                              \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+#define SHOT_LDB(set_, buf_, wt_)                                                                                    \
+    _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                                             \
+        X3Q t_;                                                                                                      \
+        t_.q = sm_w3[(buf_) * WCH + ((wt_) * NPL + pl) * 64 + lane];                                                 \
+        bw[set_][pl] = t_.v;                                                                                         \
+    }
+#define SHOT_MMA(aset_, bset_, wt_)                                                                                  \
+    {                                                                                                                \
+        constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};                                        \
+        _Pragma("unroll") for (int pr = (NP == 3 ? 3 : 0); pr < 6; ++pr)                                             \
+            _Pragma("unroll") for (int pt = 0; pt < PT; ++pt)                                                        \
+                acc[pt][wt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[bset_][PW[pr]], a[aset_][pt][PA[pr]], acc[pt][wt_], 0, 0, 0); \
+    }
+    f32x4m acc[PT][KT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[pt][k][i] = 0.f;
+    typedef unsigned shot_u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int k = 0; k < WPT; ++k)
+        if (tid + 256 * k < WCH) ((shot_u4 *)sm_w3)[tid + 256 * k] = ((const shot_u4 *)wsrc)[256 * k];
+    SHOT_LDA(0, 0);
+    __syncthreads();
+    SHOT_LDB(0, 0, 0);
+#define SHOT_ITER(it_, sa_, b0_)                                                                                     \
+    {                                                                                                                \
+        const int cb_ = (it_) & 1;                                                                                   \
+        shot_u4 wreg[WPT];                                                                                           \
+        {                                                                                                            \
+            const shot_u4 *wp = (const shot_u4 *)(wsrc + (size_t)((it_) + 1 < niter ? (it_) + 1 : (it_)) * WCH);     \
+            _Pragma("unroll") for (int k = 0; k < WPT; ++k) wreg[k] = wp[tid + 256 * k < WCH ? 256 * k : 0];         \
+        }                                                                                                            \
+        SHOT_LDA((sa_) ^ 1, (it_) + 1);                                                                              \
+        _Pragma("unroll") for (int wt = 0; wt < KT; ++wt) {                                                          \
+            if (wt + 1 < KT) {                                                                                       \
+                SHOT_LDB(((b0_) + wt + 1) & 1, cb_, wt + 1);                                                         \
+            } else {                                                                                                 \
+                shot_u4 *wn = (shot_u4 *)(sm_w3 + (cb_ ^ 1) * WCH + tid);                                            \
+                _Pragma("unroll") for (int k = 0; k < WPT; ++k)                                                      \
+                    if (tid + 256 * k < WCH) wn[256 * k] = wreg[k];                                                  \
+                __syncthreads();                                                                                     \
+                SHOT_LDB(((b0_) + wt + 1) & 1, cb_ ^ 1, 0);                                                          \
+            }                                                                                                        \
+            SHOT_MMA(sa_, ((b0_) + wt) & 1, wt);                                                                     \
+            _Pragma("unroll") for (int i_ = 0; i_ < NPL; ++i_) {                                                     \
+                __builtin_amdgcn_sched_group_barrier(0x008, NP * PT / NPL, 0);                                       \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                   \
+                if (wt * NPL + i_ < PT * NPL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+    for (int it = 0; it < niter; it += 2) {                  // niter = 9 C / 32 is even (C = 64, 128, 256)
+        SHOT_ITER(it, 0, 0);
+        SHOT_ITER(it + 1, 1, KT & 1);
+    }
+#undef SHOT_ITER
+#undef SHOT_MMA
+#undef SHOT_LDB
+#undef SHOT_LDA
+    // epilogue: y[m] = P_1[m] + P_0[m - 1] + P_2[m + 1]; lane (p, g) fetches lane p -+ 1 of its group, p = 0 / 15 from the neighbouring tile
+    const int lo = (g * 16 + ((p + 15) & 15)) * 4, hi = (g * 16 + ((p + 1) & 15)) * 4;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const long long m = mb + 16 * pt + p;
+            const int idx = 16 * pt + p;
+            const bool out = idx >= 1 && idx <= 16 * PT - 2 && m < A.M;
+            const bool useL = xs[pt] >= 1, useR = xs[pt] <= A.W - 2;
+            const int c0 = (ng * NT + n) * 16 + 4 * g;       // the lane's four channels inside the branch
+            const float4 b = *(const float4 *)(A.bias + br * A.F + c0);
+            const float bb[4] = {b.x, b.y, b.z, b.w};
+            uint32_t hw[4], mw[4], lw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float same_l = __int_as_float(__builtin_amdgcn_ds_bpermute(lo, __float_as_int(acc[pt][n][i])));
+                const float prev_l = pt > 0 ? __int_as_float(__builtin_amdgcn_ds_bpermute(lo, __float_as_int(acc[pt > 0 ? pt - 1 : 0][n][i]))) : 0.f;
+                const float same_r = __int_as_float(__builtin_amdgcn_ds_bpermute(hi, __float_as_int(acc[pt][2 * NT + n][i])));
+                const float next_r = pt + 1 < PT ? __int_as_float(__builtin_amdgcn_ds_bpermute(hi, __float_as_int(acc[pt + 1 < PT ? pt + 1 : pt][2 * NT + n][i]))) : 0.f;
+                const float l = p == 0 ? prev_l : same_l, rr = p == 15 ? next_r : same_r;
+                float v = ((acc[pt][NT + n][i] + (useL ? l : 0.f)) + (useR ? rr : 0.f)) + bb[i];
+                if (A.relu) v = fmaxf(v, 0.f);
+                x3_split1<false>(v, hw[i], mw[i], lw[i]);
+            }
+            if (!out) continue;
+            // channels 4 g .. 4 g + 3 of group q: half (g >> 1) of the uint4 of half-plane hh = g & 1
+            uint2 *o = (uint2 *)(A.Y3 + ((size_t)((((br * A.F) >> 4) + ng * NT + n) * 3) * A.Mp + SHOT_PAD + m) * 2 + (g & 1)) + (g >> 1);
+            o[0] = make_uint2(x3_pack(hw[0], hw[1]), x3_pack(hw[2], hw[3]));
+            o[(size_t)A.Mp * 4] = make_uint2(x3_pack(mw[0], mw[1]), x3_pack(mw[2], mw[3]));
+            o[(size_t)A.Mp * 8] = make_uint2(x3_pack(lw[0], lw[1]), x3_pack(lw[2], lw[3]));
+        }
+}
+
+// k_shot_conv_x3m's weights: one thread per (branch, group, iteration = (s, kt, kh), weight tile (kw, n), lane (f, g))
+__global__ __launch_bounds__(256) void k_shot_x3m_weights(const float *__restrict__ Wt, int Fpad, int kpad, int C, int F, int NT, int NPL,
+                                                          uint4 *__restrict__ out, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int KT = 3 * NT;
+    const int lane = (int)(i & 63), f = lane & 15, g = lane >> 4;
+    size_t u = i >> 6;
+    const int wt = (int)(u % KT); u /= KT;
+    const int niter = 9 * (C >> 5), groups = F / (16 * NT);
+    const int it = (int)(u % niter); u /= niter;
+    const int ng = (int)(u % groups), br = (int)(u / groups);
+    const int s = it / 9, k9 = it - 9 * s, kw = wt / NT, row = (ng * NT + wt % NT) * 16 + f;
+    const float *w = Wt + ((size_t)br * Fpad + row) * kpad + (k9 * 3 + kw) * C + 16 * (2 * s + (g >> 1)) + 4 * (g & 1);
+    const X3 sp = x3_split<true>(*(const float4 *)w, *(const float4 *)(w + 8));
+    X3Q P[3];
+    P[0].v = sp.h; P[1].v = sp.m; P[2].v = sp.l;
+    uint4 *o = out + ((((size_t)(br * groups + ng) * niter + it) * KT + wt) * NPL) * 64 + lane;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+        if (pl < NPL) o[pl * 64] = P[pl].q;
+}
+
 // The weights of a cell in the order k_shot_conv_x3 reads them: round-to-nearest bf16 planes (svc_x3.h) of
 // Wt [branch][Fpad][kpad] (k = tap * C + channel), one thread per (branch, group, iteration = (q, kt, kh), weight tile, lane).
 // A weight tile is (kw, n): rows = filters (ng NT + n) 32 ..; f16 (the 16-filter cell): tile 0 = kw 0's filters | kw 1's,
@@ -999,7 +1179,7 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
         const size_t w3_first = tot;                          // the first cell's block behind the others
         tot += (size_t)4 * 3 * 2 * NPL * 64;
         w3_off[0] = w3_first;
-        if (h->shot_w3_mx != mx) {
+        if (h->shot_w3_mx != mx * 2 + h->shot_m16) {
             int rc = h->shot_w3.ensure(tot * sizeof(uint4));
             if (rc) return rc;
             k_shot_first_weights<<<(4 * 3 * 2 * 64 + 255) / 256, 256, 0, s>>>(blob + cells[0].w_off, cells[0].fpad, cells[0].kpad, NPL,
@@ -1007,13 +1187,20 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
             SVC_CHECK_LAUNCH();
             for (int i = 1; i < SHOT_L * SHOT_S; ++i) {
                 const ShotCell &k = cells[i];
+                if (h->shot_m16) {                            // 16-filter tiles, 32-deep iterations: (4 br) x (F / 16 tiles) x 3 kw x 9 (kt, kh) x C / 32 x 64 lanes
+                    const size_t total = (size_t)4 * (k.f / 16) * 3 * 9 * (k.cpad / 32) * 64;
+                    k_shot_x3m_weights<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(blob + k.w_off, k.fpad, k.kpad, k.cpad, k.f, std::min(k.f / 16, 2), NPL,
+                                                                                      (uint4 *)h->shot_w3.p + w3_off[i], total);
+                    SVC_CHECK_LAUNCH();
+                    continue;
+                }
                 const int NT = 1;
                 const size_t total = (size_t)4 * 9 * (k.cpad / 16) * w3_tiles(k) * 64;         // threads: one per (tile, lane)
                 k_shot_x3_weights<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(blob + k.w_off, k.fpad, k.kpad, k.cpad, NT, NPL, k.f == 16,
                                                                                  (uint4 *)h->shot_w3.p + w3_off[i], total);
                 SVC_CHECK_LAUNCH();
             }
-            h->shot_w3_mx = mx;
+            h->shot_w3_mx = mx * 2 + h->shot_m16;
         }
     }
     // windows per pass: two ping-pong activation buffers of T x 27 x 48 x 64 values per window (the largest tensor), fp32 or
@@ -1053,6 +1240,30 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
                     dim3 grid(gx, 4);
                     if (mx == 3) { if (PT == 2) k_shot_first_x3<2, 3><<<grid, 256, 0, s>>>(X); else k_shot_first_x3<1, 3><<<grid, 256, 0, s>>>(X); }
                     else { if (PT == 2) k_shot_first_x3<2, 6><<<grid, 256, 0, s>>>(X); else k_shot_first_x3<1, 6><<<grid, 256, 0, s>>>(X); }
+                    SVC_CHECK_LAUNCH();
+                    cur ^= 1;
+                    continue;
+                }
+                if (mx && k.cpad >= 64 && h->shot_m16) {
+                    ShotX3 X;
+                    X.X3 = (const uint4 *)P[cur]; X.W3 = (const uint4 *)h->shot_w3.p + w3_off[b * SHOT_S + c]; X.bias = blob + k.b_off;
+                    X.Y3 = (uint4 *)P[cur ^ 1]; X.M = Mc; X.Mp = Mp; X.T = T; X.H = H; X.W = W; X.C = k.cpad; X.F = k.f; X.Fpad = k.fpad;
+                    X.relu = 1; X.xcd = h->shot_xcd;
+                    // position tiles of 16 per wavefront: shot_m16 with two filter tiles, one more with one (the 16-filter cell: 1 167 us at
+                    // three tiles, 1 066 at four; two filter tiles at four tiles leave one wave per SIMD: 465 / 872 -> 592 / 1 028 us)
+                    const int NT = std::min(k.f / 16, 2), PT = NT == 1 ? std::min(h->shot_m16 + 1, 4) : h->shot_m16;
+                    const int WGS = 4 * (16 * PT - 2);
+                    unsigned gx = (unsigned)((Mc + WGS - 1) / WGS);
+                    if (X.xcd) gx = (gx + 7) / 8 * 8;
+                    dim3 grid(gx, (unsigned)(4 * (k.f / (16 * NT))));
+                    const size_t lds = (size_t)2 * 3 * NT * NPL * 64 * sizeof(uint4);
+#define SHOT_X3M(NT_, PT_, NP_) k_shot_conv_x3m<NT_, PT_, NP_><<<grid, 256, lds, s>>>(X)
+#define SHOT_X3M_NP(NP_)                                                                                             \
+                    if (NT == 1) { if (PT == 2) SHOT_X3M(1, 2, NP_); else if (PT == 3) SHOT_X3M(1, 3, NP_); else SHOT_X3M(1, 4, NP_); } \
+                    else { if (PT == 2) SHOT_X3M(2, 2, NP_); else if (PT == 3) SHOT_X3M(2, 3, NP_); else SHOT_X3M(2, 4, NP_); }
+                    if (mx == 3) { SHOT_X3M_NP(3) } else { SHOT_X3M_NP(6) }
+#undef SHOT_X3M_NP
+#undef SHOT_X3M
                     SVC_CHECK_LAUNCH();
                     cur ^= 1;
                     continue;

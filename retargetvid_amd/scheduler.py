@@ -268,6 +268,7 @@ class JobScheduler:
         self.piece_frames, self.piece_bytes = int(piece_frames), int(piece_bytes)
         self.shot_net = shot_net
         self._plan_ready = self._planned = self._plan_err = None
+        self._plan_nets = []                                  # the planner threads' networks: shot_net and its clones (made by the first job)
         self.dev = torch.device('cuda', torch.cuda.current_device())
         self.own_engines = engines is None
         if engines is None:
@@ -281,6 +282,9 @@ class JobScheduler:
 
     def close(self):
         self.pool.shutdown(wait=True)
+        for n in self._plan_nets[1:]:                          # the clones are the scheduler's; shot_net itself is the caller's
+            n.close()
+        self._plan_nets = []
         if self.own_engines:
             for e in self.engines:
                 e.close()
@@ -380,6 +384,11 @@ class JobScheduler:
     # from the feeder (inside plan_video) every video's windows, their copy to the host and the scene walk sat between two
     # lanes' enqueues.  One thread walks the videos in order on a stream of its own with the network's own engine; the
     # feeder only picks up the finished (video, shots) pairs, so the saliency lanes overlap with the shot network.
+    # Two planner threads (videos alternate between them), the second with a clone of the network on an engine of its own: one
+    # thread's copy of the probabilities to the host and its scene walk overlap with the other's windows on the device
+    # (one thread: 10.3 ms per video of which 6.8 ms is the network; the job 2.46 s -> see DESIGN 5).
+    PLANNERS = 2
+
     def _start_planner(self):
         import threading
         self._plan_ready, self._planned, self._plan_err, self._plan_stop = None, None, None, False
@@ -387,24 +396,28 @@ class JobScheduler:
             return None
         self._plan_ready = [threading.Event() for _ in self.videos]
         self._planned = [None] * len(self.videos)
-        th = threading.Thread(target=self._plan_ahead, name='svc-shot-planner', daemon=True)
-        th.start()
-        return th
+        while len(self._plan_nets) < min(self.PLANNERS, len(self.videos)):
+            self._plan_nets.append(self.shot_net if not self._plan_nets else self.shot_net.clone())
+        ths = [threading.Thread(target=self._plan_ahead, args=(k, len(self._plan_nets)), name='svc-shot-planner-%d' % k, daemon=True)
+               for k in range(len(self._plan_nets))]
+        for th in ths:
+            th.start()
+        return ths
 
-    def _plan_ahead(self):
+    def _plan_ahead(self, k, stride):
         import torch
+        net = self._plan_nets[k]
         try:
             with torch.cuda.device(self.dev):
                 st = torch.cuda.Stream(device=self.dev)
                 with torch.cuda.stream(st):
-                    for i in range(len(self.videos)):
-                        if self._plan_stop:
+                    for i in range(k, len(self.videos), stride):
+                        if self._plan_stop or self._plan_err is not None:
                             break
                         v = self.videos[i]() if callable(self.videos[i]) else self.videos[i]
                         shots = None
                         if v.get('trans_inds') is None:
-                            shots = S.detect_shots(v['frames'], v['fr'], self.CP, net=self.shot_net, engine=self.shot_net.eng,
-                                                   trans_threshold=S.TRANS_THRESHOLD)
+                            shots = S.detect_shots(v['frames'], v['fr'], self.CP, net=net, engine=net.eng, trans_threshold=S.TRANS_THRESHOLD)
                         else:
                             st.synchronize()                  # whatever the callable enqueued is done before a lane reads the frames
                         self._planned[i] = (v, shots)
@@ -412,13 +425,17 @@ class JobScheduler:
         except BaseException as e:                            # surfaced by the feeder (_next_video)
             self._plan_err = e
         finally:
-            for ev in self._plan_ready:
+            for ev in self._plan_ready[k::stride]:
                 ev.set()
+            if self._plan_err is not None:                    # nobody waits for a video the other thread will not reach
+                for ev in self._plan_ready:
+                    ev.set()
 
-    def _stop_planner(self, th):
-        if th is not None:
+    def _stop_planner(self, ths):
+        if ths:
             self._plan_stop = True
-            th.join()
+            for th in ths:
+                th.join()
 
     def _dispatch(self, lane, gids, xy):
         """Centres of finished maps -> their videos; a video whose last centre arrived goes to the host-stage pool."""

@@ -33,19 +33,34 @@ class ShotTransNetParams:
 
 
 class ShotTransNet:
-    def __init__(self, params=None, session=None, weights=None, engine=None, windows_per_call=16):
+    def __init__(self, params=None, session=None, weights=None, engine=None, windows_per_call=16, _blob=None):
         self.params = params or ShotTransNetParams()
         p = self.params
         if (p.F, p.L, p.S, p.D, p.INPUT_WIDTH, p.INPUT_HEIGHT) != (16, 3, 2, 256, 48, 27):
             raise ValueError('only the F16 L3 S2 D256 network on 48x27 frames (the reference\'s configuration) is built')
-        if weights is None:
+        if weights is None and _blob is None:
             raise ValueError('ShotTransNet needs weights= (TensorFlow-layout arrays under the reference\'s variable names): the '
                              'checkpoint %r cannot be read without TensorFlow' % (p.CHECKPOINT_PATH,))
         self._own = engine is None
         self.eng = engine or ops.Engine(seed=0)
         self.windows_per_call = int(windows_per_call)
-        blob = np.ascontiguousarray(_weights.pack_transnet_blob(weights), np.float32)
+        blob = _blob if _blob is not None else np.ascontiguousarray(_weights.pack_transnet_blob(weights), np.float32)
+        self._blob = blob
         _lib.check(self.eng.lib.svc_transnet_load(self.eng._h, blob.ctypes.data_as(ctypes.c_void_p), blob.size))
+
+    def clone(self):
+        """A second network with the same weights and matrix pipe on an engine of its own (a handle's workspace serves one call
+        at a time): what the job scheduler's second planner thread runs."""
+        import os
+        old = os.environ.get('SVC_SHOT_MX')
+        os.environ['SVC_SHOT_MX'] = self.matrix_pipe()               # read when the engine is created
+        try:
+            return ShotTransNet(self.params, windows_per_call=self.windows_per_call, _blob=self._blob)
+        finally:
+            if old is None:
+                os.environ.pop('SVC_SHOT_MX', None)
+            else:
+                os.environ['SVC_SHOT_MX'] = old
 
     def matrix_pipe(self):
         """'f32', 'bf16x6' or 'bf16x3': what the convolution cells run on (svc_transnet_matrix_pipe; environment SVC_SHOT_MX

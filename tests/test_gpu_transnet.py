@@ -68,10 +68,13 @@ KNOB_SETS = [
     ({'SVC_SHOT_MX': 'f32'}, 'f32'),                                   # fp32 MFMA, both operands through LDS (rounds 2-4)
     ({'SVC_SHOT_MX': 'f32', 'SVC_SHOT_FORM': '0'}, 'f32'),             # ... operands straight from global memory
     ({'SVC_SHOT_MX': 'f32', 'SVC_SHOT_FORM': '1'}, 'f32'),             # ... weights through LDS
-    ({'SVC_SHOT_MX': 'bf16x6', 'SVC_SHOT_PT': '1'}, 'bf16x6'),         # split-bf16 planes, one 32-position tile per wavefront
-    ({'SVC_SHOT_MX': 'bf16x6', 'SVC_SHOT_XCD': '0'}, 'bf16x6'),        # ... without the XCD-aware tile order
+    ({'SVC_SHOT_M16': '0'}, 'bf16x6'),                                 # split-bf16 planes on v_mfma_f32_32x32x16_bf16 (k_shot_conv_x3), two 32-position tiles per wavefront
+    ({'SVC_SHOT_M16': '0', 'SVC_SHOT_PT': '1'}, 'bf16x6'),             # ... one tile
+    ({'SVC_SHOT_XCD': '0'}, 'bf16x6'),                                 # the default shape (16x16x32) without the XCD-aware tile order
     ({'SVC_SHOT_MX': 'bf16x3'}, 'bf16x3'),                             # three plane pairs (16 significant bits per product)
-    ({'SVC_SHOT_MX': 'bf16x3', 'SVC_SHOT_PT': '1'}, 'bf16x3'),
+    ({'SVC_SHOT_MX': 'bf16x3', 'SVC_SHOT_M16': '0', 'SVC_SHOT_PT': '1'}, 'bf16x3'),
+    ({'SVC_SHOT_M16': '4'}, 'bf16x6'),                                 # 16x16x32 with 4 / 2 position tiles per wavefront (default 3)
+    ({'SVC_SHOT_M16': '2', 'SVC_SHOT_MX': 'bf16x3'}, 'bf16x3'),
 ]
 
 
@@ -79,7 +82,7 @@ KNOB_SETS = [
 def test_kernel_forms_agree(net, knobs, pipe):
     """Every form of the convolution cells computes the same network: the fp32-MFMA forms (operands straight from global
     memory / weights through LDS / both operands through LDS), the split-bf16 form the handle uses by default (bf16x6:
-    planar split activations, the kw taps kept in the accumulators) with its tile knobs, and the three-pair form bf16x3,
+    planar split activations, the kw taps kept in the accumulators) on both MFMA shapes with its tile knobs, and the three-pair form bf16x3,
     whose 16-bit products stay inside the same tolerance (measured |dP| 1.4e-5 against 6e-7)."""
     import os
     n, sd = net
@@ -204,6 +207,34 @@ def test_packed_job_with_shot_detection_inside_equals_sequential_runs(net):
                 assert a[r][0]['bbs'] == b[r][0]['bbs'] and a[r][0]['dx'] == b[r][0]['dx']
     finally:
         eng.close()
+
+
+def test_a_failure_in_the_planner_threads_reaches_the_caller(net):
+    """Shot detection runs ahead of the lanes in the scheduler's planner threads (two networks: shot_net and a clone): a video
+    one of them cannot plan raises in the caller's thread, and the scheduler runs the next job."""
+    from retargetvid_amd import smartVidCrop as S, synth, scheduler
+    n, sd = net
+    usd = weights.make_synthetic_state_dict(0)
+    CP = dict(S.sc_init_crop_params(), read_batch=64, hdbscan_min=5)
+    good = []
+    for k in range(3):
+        frames = synth.blob_frames(60 + 10 * k, 90, 160, seed=50 + k)
+        frames[30:] = frames[30:][:, ::-1]
+        good.append(dict(fr=25.0, frame_count=len(frames), w=160, h=90, frames=frames))
+    bad = dict(good[1], frames=np.zeros((40, 90, 160, 4), np.uint8))          # four channels: the down-scale refuses it
+    js = scheduler.JobScheduler(CP, ('1:3',), lanes=2, state_dict=usd, shot_net=n)
+    try:
+        with pytest.raises(Exception):
+            js.run([good[0], bad, good[2]])
+        ref = js.run(good)
+        again = js.run(good)
+        assert len(js._plan_nets) == 2 and js._plan_nets[0] is n
+        for a, b in zip(ref, again):
+            assert a['1:3'][0]['bbs'] == b['1:3'][0]['bbs']
+        one = S.smart_vid_crop(good[1], dict(CP, out_ratio='1:3'), save_vid=False, engine=js.engines[0], shot_net=n)
+        assert one[0]['bbs'] == ref[1]['1:3'][0]['bbs']
+    finally:
+        js.close()
 
 
 def test_only_the_windows_whose_rows_are_kept_are_computed(net):

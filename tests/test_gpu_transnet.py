@@ -110,6 +110,17 @@ def test_kernel_forms_agree(net, knobs, pipe):
         assert np.abs(got - oracle).max() <= 5e-6                      # the fp32-class pipes sit two orders inside the tolerance
 
 
+def test_more_windows_than_one_pass_holds(net):
+    """svc_transnet_predict cuts a call into passes of as many windows as its workspace holds (15 on the split-bf16 pipe): 17
+    windows in one call are the same numbers, bit for bit, as the same windows in two calls."""
+    n, sd = net
+    fr = np.stack([_frames(100, 200 + k, smooth=(k % 2 == 0)) for k in range(17)])
+    whole = n.predict_raw(fr)
+    parts = np.concatenate([n.predict_raw(fr[:9]), n.predict_raw(fr[9:])])
+    assert whole.shape == (17, 100) and np.array_equal(whole, parts)
+    assert np.abs(whole[[0, 16]] - R.forward(sd, fr[[0, 16]])).max() <= TOL
+
+
 def test_errors():
     eng = ops.Engine(seed=0)
     try:

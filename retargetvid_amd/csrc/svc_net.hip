@@ -2603,6 +2603,8 @@ struct IrbGeom {
 // block 2), block 7 slightly faster.
 template <int S, int TOH, int TOW, bool EXPAND, int CIN = 0, int CE = 0, int COUT = 0, bool MX = false>
 // (the split slices of block 7 leave room for three workgroups per CU, not four: its register budget follows)
+// (the other split-bf16 instances spill 2 / 5 registers at four waves per SIMD; at three, without spills, the pass is 1.265 ms alone /
+// 0.877 shared against 1.255 / 0.878: kept at four)
 #define IRB_MX3(S_, CIN_, COUT_, MX_) ((MX_) && (COUT_) == 64)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRB_MX3(S, CIN, COUT, MX) ? 3 : IRB_WAVES, 8))) void k_irb(const float *__restrict__ X, int H, int W, int Cin_,
                                              const float *__restrict__ We, const float *__restrict__ be, int Ce_,

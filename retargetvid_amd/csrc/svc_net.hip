@@ -25,6 +25,16 @@
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// XCD-aware workgroup order: hardware workgroup ids go round the eight XCDs, so with the logical tile of workgroup b taken as
+// (b & 7) * (n / 8) + (b >> 3) XCD x works on the x-th eighth of the tiles -- four whole frames of a 32-frame pass, in every
+// kernel alike, so a frame's activations are produced and consumed through one XCD's L2 (measured: a pass 1.236 -> 1.227 ms
+// alone, 0.866 -> 0.860 ms with four passes sharing the chip, three alternations; grids whose x extent is no multiple of 8 keep
+// the hardware order).
+__device__ __forceinline__ unsigned xcd_bx() {
+    const unsigned b = blockIdx.x, n = gridDim.x;
+    return (n & 7) ? b : (b & 7) * (n >> 3) + (b >> 3);
+}
+
 // a += x * w on four channels as two packed fp32 FMAs (v_pk_fma_f32: two lanes' worth of fused multiply-adds per
 // instruction; the same fma per element as fmaf, so the depthwise sums do not change)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(256) void k_stem_mfma(const float *__restrict__ X, 
     constexpr int PR = 2 * STEM_TH + 1, PCW = 2 * STEM_TW + 1;
     __shared__ float Pin[PR * STEM_PRS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-    int bid = blockIdx.x;
+    int bid = xcd_bx();
     const int tx = bid % tiles_x;
     bid /= tiles_x;
     const int ty = bid % tiles_y, f = bid / tiles_y;
@@ -441,7 +451,7 @@ static inline int front_lds_bytes() { return FR_IN_BYTES + FR_SONLY_BYTES; }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_front(const FrontArgs A) {       // <= 128 registers: four workgroups per CU
     extern __shared__ uint8_t sm_fr[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-    int bid = blockIdx.x;
+    int bid = xcd_bx();
     const int tx = bid % A.tiles_x;
     bid /= A.tiles_x;
     const int ty = bid % A.tiles_y, f = bid / A.tiles_y;
@@ -681,7 +691,7 @@ __global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx
                                             int relu6, UpsAdd ups) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int m0 = blockIdx.x * 128 + wave * 32;
+    const int m0 = xcd_bx() * 128 + wave * 32;
     const int n0 = blockIdx.y * (32 * TN);
     if (m0 >= M) return;
     const int row = min(m0 + r, M - 1);
@@ -859,7 +869,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     float *slab = sm_pwr + wave * (32 * PWR_SLAB);
     float *bch = sm_pwr + 4 * 32 * PWR_SLAB;
     float *wch = bch + 128;
-    const int m0 = blockIdx.x * 128 + wave * 32;
+    const int m0 = xcd_bx() * 128 + wave * 32;
     const int n0 = blockIdx.y * (32 * ntw);
     const int ncols = min(32 * ntw, Npad - n0);            // multiple of 32, at most 128
     // activations of the wave's 32 pixels: every load in flight at once -- requested in WHOLE LINES (round 4: eight lanes per
@@ -1018,7 +1028,7 @@ __global__ __launch_bounds__(256) void k_pw16(const float *__restrict__ X, int l
                                               int relu6) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, q = lane >> 4;
-    const int m0 = blockIdx.x * (64 * MT) + wave * (16 * MT);
+    const int m0 = xcd_bx() * (64 * MT) + wave * (16 * MT);
     const int n0 = blockIdx.y * (16 * NT);
     if (m0 >= M) return;
     const float *xa[MT];
@@ -1090,7 +1100,7 @@ __global__ __launch_bounds__(256) void k_pw_sk(const float *__restrict__ X, int 
     __shared__ float red[4][TN][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * (32 * TN);
+    const int m0 = xcd_bx() * 32, n0 = blockIdx.y * (32 * TN);
     const float *xp = X + (size_t)min(m0 + r, M - 1) * ldx + 4 * hh;
     const float *wp[TN];
 #pragma unroll
@@ -1230,7 +1240,7 @@ __global__ __launch_bounds__(256) void k_dw(const float *__restrict__ X, const f
                                             const float *__restrict__ bias, float *__restrict__ Y, int n, int H,
                                             int W, int C, int OH, int OW, FDiv dC4, FDiv dOW, FDiv dOH) {
     const int C4 = C >> 2;
-    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t gid = xcd_bx() * 256u + threadIdx.x;
     const uint32_t total = (uint32_t)n * OH * OW * C4;
     if (gid >= total) return;
     uint32_t c4, ox, oy;
@@ -1273,7 +1283,7 @@ template <int TX, int TY>
 __global__ __launch_bounds__(256) void k_dw_tile(const float *__restrict__ X, const float *__restrict__ Wt,
                                                  const float *__restrict__ bias, float *__restrict__ Y, int n,
                                                  int H, int W, int C, FDiv dC4, FDiv dGX, FDiv dGY, uint32_t total) {
-    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t gid = xcd_bx() * 256u + threadIdx.x;
     if (gid >= total) return;
     uint32_t c4, gx, gy;
     const uint32_t cell = fdivmod(gid, dC4, c4);
@@ -2105,7 +2115,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 8))
     float (*Dw)[32 * IRB_ES] = (float (*)[32 * IRB_ES])smem_dwpw;
     float (*red)[16][64] = (float (*)[16][64])(smem_dwpw + NWV * 32 * IRB_ES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-    int bid = blockIdx.x;
+    int bid = xcd_bx();
     const int tx = bid % tiles_x;
     bid /= tiles_x;
     const int ty = bid % tiles_y, f = bid / tiles_y;
@@ -2321,7 +2331,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     constexpr int K1 = 8 * KS1;
     __shared__ float red_pp[4][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-    const int m0 = blockIdx.x * 32;
+    const int m0 = xcd_bx() * 32;
     const float *xp = X + (size_t)min(m0 + r, M - 1) * ldx + 4 * hh;
     constexpr int Q1 = KS1 / 2;
     static_assert(KS1 % 2 == 0, "K1 must be a multiple of 16");
@@ -2639,7 +2649,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRB_MX3(S, 
     float *Bes = Wds + 9 * 32;                              // [CeP]           expand biases (all chunks): no global load inside the chunk loop
     float *Bds = Bes + ((Ce + 31) / 32 * 32);               // [CeP]           depthwise biases
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-    int bid = blockIdx.x;
+    int bid = xcd_bx();
     const int tx = bid % tiles_x;
     bid /= tiles_x;
     const int ty = bid % tiles_y, f = bid / tiles_y;

@@ -33,8 +33,23 @@ if VICTIM:
     vl.victim_diffs.restype = ctypes.c_uint64
     assert vl.victim_init() == 0
     vstream = torch.cuda.Stream()
+# SHOT=k: beside every pass, TransNet V1 (k windows of 100 frames, cells on the split-bf16 pipe whatever SVC_MX says) on a stream of its own:
+# a second kind of bf16-MFMA co-runner (no v_perm_b32 in its loop, operands loaded pre-split)
+SHOT = int(os.environ.get('SHOT', '0'))
+if SHOT:
+    from retargetvid_amd import transnetv1_handler as Hd, weights as W_
+    os.environ['SVC_SHOT_MX'] = 'bf16x6'
+    snet = Hd.ShotTransNet(Hd.ShotTransNetParams(), weights=W_.make_transnet_state_dict(0))
+    sfr = torch.from_numpy(np.random.RandomState(1).randint(0, 256, (SHOT, 100, 27, 48, 3)).astype(np.uint8)).cuda()
+    sstream = torch.cuda.Stream()
+    sref = snet.predict_raw_device(sfr).clone()
+    torch.cuda.synchronize()
+    sbad = 0
 bad = 0
 for it in range(ITERS):
+    if SHOT:
+        with torch.cuda.stream(sstream):
+            sout = snet.predict_raw_device(sfr)
     if VICTIM:
         for _ in range(VICTIM):
             vl.victim_launch(ctypes.c_void_p(vstream.cuda_stream))
@@ -45,6 +60,8 @@ for it in range(ITERS):
         with torch.cuda.stream(sts[i]):
             engs[i].saliency(fr, out=outs[i])
     torch.cuda.synchronize()
+    if SHOT and not torch.equal(sout, sref):
+        sbad += 1
     for i in range(N):
         if not torch.equal(outs[i], ref):
             bad += 1
@@ -69,6 +86,8 @@ for it in range(ITERS):
                     w = np.flatnonzero(want == got[idx[k]])
                     if len(w): print('   got[%d] equals want at flat index %s' % (idx[k], w[:4].tolist()))
 print('%d passes, %d with a map that differs from the reference' % (ITERS * N, bad))
+if SHOT:
+    print('TransNet beside them: %d calls of %d windows, %d with probabilities that differ from its lone run' % (ITERS, SHOT, sbad))
 if VICTIM:
     print('stand-in victim: %d launches, %d words differ from its lone run' % (VICTIM * ITERS, vl.victim_diffs()))
     if hasattr(vl, 'victim_report'):

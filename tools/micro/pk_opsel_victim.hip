@@ -101,6 +101,40 @@ __global__ __launch_bounds__(NTH) void k_pkvictim_lds(unsigned long long *cnt, i
         }
     if (bad) atomicAdd(cnt + slot * 4 + q, (unsigned long long)bad);
 }
+
+// ---- aggressors for the stand-alone run (tools/micro/pk_opsel_run.py): instruction mixes of k_pwr's bf16 form, one kind per launch ------
+//   0: v_pk_mov_b32 ... op_sel:[1,0]   1: v_perm_b32   2: v_mfma_f32_32x32x16_bf16 fed by v_perm_b32   3: ds_read_b128 + the MFMA
+typedef short ag_b8 __attribute__((ext_vector_type(8)));
+typedef float ag_f16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void k_aggressor(float *sink, int iters, int kind) {
+    __shared__ uint4 lds[1024];
+    const int tid = threadIdx.x;
+    lds[tid] = make_uint4(tid, tid * 3, tid * 5, tid * 7); lds[tid + 256] = lds[tid]; lds[tid + 512] = lds[tid]; lds[tid + 768] = lds[tid];
+    __syncthreads();
+    f2 a = {(float)tid, 1.5f}, b = {2.5f, (float)(tid & 7)}, d = {0.f, 0.f};
+    unsigned u = tid * 2654435761u, w = 0x9e3779b9u;
+    ag_f16 acc;
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        if (kind == 0) {
+            asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]\n\tv_pk_mov_b32 %1, %0, %2 op_sel:[1,0]" : "+v"(d), "+v"(a) : "v"(b));
+        } else if (kind == 1) {
+            asm volatile("v_perm_b32 %0, %0, %1, %2\n\tv_perm_b32 %1, %1, %0, %2" : "+v"(u), "+v"(w) : "s"(0x07060302u));
+        } else {
+            union { ag_b8 v; unsigned q[4]; uint4 x; } A, B;
+            if (kind == 3) { A.x = lds[(tid + it * 7) & 1023]; B.x = lds[(tid * 3 + it) & 1023]; }
+            else { A.q[0] = u; A.q[1] = w; A.q[2] = u ^ w; A.q[3] = u + w; B = A; }
+            asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(A.q[0]) : "v"(w), "s"(0x07060302u));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, B.v, acc, 0, 0, 0);
+            u = u * 1664525u + 1013904223u;
+        }
+    }
+    if (sink) sink[blockIdx.x * 256 + tid] = d.x + a.y + (float)u + (float)w + acc[0] + acc[7];
+}
+extern "C" int aggressor_launch(void *stream, int kind, int blocks, int iters) {
+    k_aggressor<<<blocks, 256, 0, (hipStream_t)stream>>>(nullptr, iters, kind);
+    return (int)hipGetLastError();
+}
 static unsigned long long *g_cnt = nullptr;
 static unsigned long long g_launches = 0;
 extern "C" int victim_init() {

@@ -733,9 +733,10 @@ def test_the_fp32_pipe_stays_selectable_and_both_pipes_are_reproducible(engine, 
 
 def test_maps_are_bit_reproducible_with_four_streams_sharing_the_chip(synthetic_sd):
     """Round 5: with the bf16 pipe the pre-softmax map had 16 pixels of one wavefront wrong in 1 - 6 % of the passes when four streams
-    shared the chip -- k_smooth_down_mfma miscomputes beside workgroups of the bf16 kernels (cause not found) and now takes
-    a CU to itself.  Four engines on four streams push the same 32 frames 120 times: every map equals the single-stream reference
-    (tools/soak_network_concurrent.py is the long form: 0 of 26 000 passes)."""
+    shared the chip -- the smoothing kernel's bilinear stage lost one product in a packed-instruction sequence beside workgroups of
+    k_pwr's bf16 form; the stage runs on scalar instructions since (sd_bilinear), without the CU isolation that
+    contained it first.  Four engines on four streams push the same 32 frames 120 times: every map equals the single-stream
+    reference (tools/soak_network_concurrent.py is the long form: 0 of 20 400 passes without isolation; the packed form: 5 - 9 %)."""
     from retargetvid_amd import scheduler
     fr = torch.from_numpy(synth.blob_frames(32, 140, 250, seed=0)).cuda()
     engs = [ops.Engine(synthetic_sd) for _ in range(4)]

@@ -384,10 +384,11 @@ class JobScheduler:
     # from the feeder (inside plan_video) every video's windows, their copy to the host and the scene walk sat between two
     # lanes' enqueues.  One thread walks the videos in order on a stream of its own with the network's own engine; the
     # feeder only picks up the finished (video, shots) pairs, so the saliency lanes overlap with the shot network.
-    # Two planner threads (videos alternate between them), the second with a clone of the network on an engine of its own: one
-    # thread's copy of the probabilities to the host and its scene walk overlap with the other's windows on the device
-    # (one thread: 10.3 ms per video of which 6.8 ms is the network; the job 2.46 s -> see DESIGN 5).
-    PLANNERS = 2
+    # Three planner threads (the videos go round them), the second and third with a clone of the network on an engine of its own:
+    # one thread's copy of the probabilities to the host and its scene walk overlap with the others' windows on the device
+    # (one thread: 10.3 ms per video of which 6.8 ms is the network; the 200-video job 2.46 s with one, 2.25 - 2.27 with two,
+    # 2.17 - 2.19 with three, 2.28 with four: three alternations).
+    PLANNERS = 3
 
     def _start_planner(self):
         import threading

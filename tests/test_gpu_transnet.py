@@ -221,7 +221,7 @@ def test_packed_job_with_shot_detection_inside_equals_sequential_runs(net):
 
 
 def test_a_failure_in_the_planner_threads_reaches_the_caller(net):
-    """Shot detection runs ahead of the lanes in the scheduler's planner threads (two networks: shot_net and a clone): a video
+    """Shot detection runs ahead of the lanes in the scheduler's planner threads (three networks: shot_net and two clones): a video
     one of them cannot plan raises in the caller's thread, and the scheduler runs the next job."""
     from retargetvid_amd import smartVidCrop as S, synth, scheduler
     n, sd = net
@@ -239,7 +239,7 @@ def test_a_failure_in_the_planner_threads_reaches_the_caller(net):
             js.run([good[0], bad, good[2]])
         ref = js.run(good)
         again = js.run(good)
-        assert len(js._plan_nets) == 2 and js._plan_nets[0] is n
+        assert len(js._plan_nets) == 3 and js._plan_nets[0] is n
         for a, b in zip(ref, again):
             assert a['1:3'][0]['bbs'] == b['1:3'][0]['bbs']
         one = S.smart_vid_crop(good[1], dict(CP, out_ratio='1:3'), save_vid=False, engine=js.engines[0], shot_net=n)

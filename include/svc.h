@@ -73,7 +73,7 @@ const char *svc_last_error(void);
  * 3 = SvcParams ends with com_km; SVC_MAP_HELD is honoured by svc_cluster_center (a v2 library ignores the bit), svc_debug_cluster_state
  *     returns 32 header words, svc_debug_round_plan / svc_debug_argsort_u32 / svc_transnet_* exist.
  * 4 = the host stages svc_host_* (SvcTemporalParams) and svc_saliency_thresholded_u8 exist. */
-#define SVC_ABI_VERSION 4
+#define SVC_ABI_VERSION 5
 int svc_abi_version(void);
 
 /* weights_blob_host: the packed, BN-folded static SALICON slice of a UNISAL
@@ -96,6 +96,13 @@ int svc_saliency_u8(SvcHandle *h, const uint8_t *frames_nhwc, int n, int height,
  * Identical bytes; one launch less per chunk.  t in 0..255 (0 = svc_saliency_u8). */
 int svc_saliency_thresholded_u8(SvcHandle *h, const uint8_t *frames_nhwc, int n, int height, int width,
                                 uint8_t *maps_nhw, int t, void *stream);
+
+/* svc_saliency_thresholded_u8 (t in 1..255) that also ADDS, per frame, how many pixels of the UN-thresholded map sit at t - 1, t
+ * and t + 1 to the caller's DEVICE rows census_n4[n][4] (uint32; column 3 unused; the caller zeroes them): svc_threshold_census
+ * per frame, for callers whose passes mix the frames of several videos (retargetvid_amd/scheduler.py reports the regime
+ * diagnostic per video from these rows).  census_n4 may be NULL (= svc_saliency_thresholded_u8).  No counterpart in the reference. */
+int svc_saliency_census_u8(SvcHandle *h, const uint8_t *frames_nhwc, int n, int height, int width,
+                           uint8_t *maps_nhw, int t, uint32_t *census_n4, void *stream);
 
 /* maps[i] = maps[i] < t ? 0 : maps[i], in place. */
 int svc_threshold_u8(SvcHandle *h, uint8_t *maps, size_t n_bytes, int t, void *stream);
@@ -232,6 +239,21 @@ int svc_debug_argsort_u32(SvcHandle *h, const uint32_t *keys_host, int n, int32_
  *   Windowing of a video (100-frame windows, stride 50, edge padding) is host logic: transnetv1_handler.predict_video. */
 int svc_transnet_load(SvcHandle *h, const float *blob_host, size_t n_floats);
 int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_windows, int frames_per_window, float *probs, void *stream);
+/* svc_transnet_predict_rows: the same, but the caller keeps only rows row0 .. row1 - 1 of every window (the reference's
+ * predict_video keeps rows 25 .. 74 of its 100-frame windows, transnetv1_handler.py:117-121).  Those rows of probs are bit for bit
+ * svc_transnet_predict's; the others are UNSPECIFIED (left as they were on the split-bf16 pipes, computed on the fp32 pipe).
+ * A cell's temporal reach is 8 frames (its largest dilation), so on the split-bf16 pipes every layer is computed only on the frames
+ * the kept rows depend on: 50 / 66 / 82 / 98 of 100 frames in the last four cells = a fifth of the network's FLOPs less.
+ * 0 <= row0 < row1 <= frames_per_window. */
+int svc_transnet_predict_rows(SvcHandle *h, const uint8_t *frames, int n_windows, int frames_per_window, int row0, int row1,
+                              float *probs, void *stream);
+/* The handle's TransNet knobs as five int32: {matrix pipe: -1 = the handle's SVC_MX | 0 fp32 | 6 bf16x6 | 3 bf16x3, 16-position
+ * tiles per wavefront of the 16x16x32 kernel (0 = the 32x32x16 kernel), 32-position tiles of that kernel (1 | 2), XCD-aware tile
+ * order (0 | 1), fp32 form (0..2)} -- read from SVC_SHOT_* when the handle is created; ShotTransNet.clone() copies them to the
+ * engine of the copy with these two calls instead of going through the process environment.  _set rejects values that are not
+ * a configuration with SVC_E_INVALID. */
+int svc_transnet_config_get(const SvcHandle *h, int32_t *cfg5);
+int svc_transnet_config_set(SvcHandle *h, const int32_t *cfg5);
 
 /* Test/diagnostic door: copy an intermediate activation of the LAST svc_saliency_u8
  * call (NHWC fp32, frame 0..n-1) to a HOST buffer.  `which` is one of the SVC_TAP_*
@@ -261,7 +283,8 @@ int svc_matrix_pipe(const SvcHandle *h);
 /* svc_transnet_matrix_pipe: the same for the TransNet cells with >= 64 input channels (svc_transnet_predict): 0 = fp32 MFMA,
  * 6 = split-bf16 operands, six plane pairs (fp32-class results: |dP| against the oracle 6e-7, the fp32 pipe's 6e-7), 3 = three plane
  * pairs (hi.hi + hi.mid + mid.hi: 16 significant bits per product, |dP| 1.4e-5; opt-in).  Environment SVC_SHOT_MX=f32 | bf16x6 |
- * bf16x3 when the handle is created; default = the handle's SVC_MX. */
+ * bf16x3 when the handle is created; default = the handle's SVC_MX.  svc_create rejects any other spelling of SVC_MX / SVC_SHOT_MX
+ * with SVC_E_INVALID (ABI 5: a typo used to select the fp32 pipe silently). */
 int svc_transnet_matrix_pipe(const SvcHandle *h);
 /* svc_threshold_census: the regime diagnostic of the threshold (no counterpart in the reference; smartVidCrop.py:1050-1059 only
  * thresholds).  out[0] = maps that went through svc_saliency_thresholded_u8 on this handle since the last reset, out[1..3] = how

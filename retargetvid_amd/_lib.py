@@ -9,14 +9,15 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SVC_LIB') or os.path.join(_HERE, 'libsvc_hip.so')      # SVC_LIB: another build of the same ABI (A/B runs)
 
-ABI_VERSION = 4          # include/svc.h SVC_ABI_VERSION this binding was written against
+ABI_VERSION = 5          # include/svc.h SVC_ABI_VERSION this binding was written against
 
 EXPORTS = ('svc_last_error', 'svc_abi_version', 'svc_create', 'svc_destroy', 'svc_resize_frames_u8', 'svc_saliency_u8',
            'svc_threshold_u8', 'svc_cluster_center', 'svc_iou_i32', 'svc_debug_cluster_state', 'svc_debug_tap', 'svc_front_fused', 'svc_matrix_pipe', 'svc_threshold_census', 'svc_debug_round_plan', 'svc_transnet_load', 'svc_transnet_predict', 'svc_transnet_matrix_pipe',
            'svc_debug_argsort_u32',
            'svc_profile_enable', 'svc_profile_read', 'svc_profile_read_raw',
            'svc_host_fill_empty_centres', 'svc_host_interp_segment', 'svc_host_lowpass', 'svc_host_loess', 'svc_host_savgol',
-           'svc_host_temporal', 'svc_host_boxes', 'svc_host_focus_stability', 'svc_saliency_thresholded_u8')
+           'svc_host_temporal', 'svc_host_boxes', 'svc_host_focus_stability', 'svc_saliency_thresholded_u8',
+           'svc_saliency_census_u8', 'svc_transnet_predict_rows', 'svc_transnet_config_get', 'svc_transnet_config_set')
 
 
 class SvcParams(ctypes.Structure):
@@ -82,6 +83,10 @@ def load():
     lib.svc_debug_round_plan.argtypes = [vp, i32, vp, vp]
     lib.svc_transnet_load.argtypes = [vp, vp, sz]
     lib.svc_transnet_predict.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.svc_transnet_predict_rows.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.svc_transnet_config_get.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
+    lib.svc_transnet_config_set.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
+    lib.svc_saliency_census_u8.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp]
     lib.svc_debug_argsort_u32.argtypes = [vp, vp, i32, vp]
     lib.svc_profile_enable.argtypes = [vp, i32]
     lib.svc_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]

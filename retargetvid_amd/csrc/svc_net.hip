@@ -1650,7 +1650,7 @@ __global__ __launch_bounds__(256) void k_smooth_down(const float *__restrict__ l
 // (svc_threshold_census; DESIGN.md 2: 7 per level = windows identical between two correct fp32 implementations, 500 = 21 % differ).
 __global__ __launch_bounds__(256) void k_quantise(const float *__restrict__ pre, const unsigned *__restrict__ fmax,
                                                   uint8_t *__restrict__ out, int n, int hw, FDiv dhw, int thr,
-                                                  unsigned long long *__restrict__ census) {
+                                                  unsigned long long *__restrict__ census, unsigned *__restrict__ rows) {
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t total = (uint32_t)n * hw;
     if (gid >= total) return;
@@ -1661,7 +1661,10 @@ __global__ __launch_bounds__(256) void k_quantise(const float *__restrict__ pre,
     out[gid] = (int)v < thr ? (uint8_t)0 : v;              // thr = 0: the plain map; > 0: sc_threshold fused in (svc_saliency_thresholded_u8)
     if (census && thr > 0) {
         const int d = (int)v - (thr - 1);
-        if (d >= 0 && d <= 2) atomicAdd((unsigned *)(census + 4) + f * 4 + d, 1u);       // (a few hundred pixels per map at most)
+        if (d >= 0 && d <= 2) {
+            atomicAdd((unsigned *)(census + 4) + f * 4 + d, 1u);                           // (a few hundred pixels per map at most)
+            if (rows) atomicAdd(rows + f * 4 + d, 1u);                                      // the caller's per-frame rows (svc_saliency_census_u8)
+        }
     }
 }
 
@@ -3067,7 +3070,7 @@ static int launch_irb(SvcHandle *h, hipStream_t s, const float *X, int n, int H,
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
 // One pass of the network over n <= plan->nb frames.
-static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *maps, hipStream_t s, int thr = 0) {
+static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *maps, hipStream_t s, int thr = 0, unsigned *census_rows = nullptr) {
     NetPlan *p = h->plan;
     const int NH = p->NH, NW = p->NW;
     int H = NH / 2, W = NW / 2;
@@ -3297,14 +3300,15 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     }
     if (seg_on()) k_quantise<<<blocks256((size_t)n * p->h * p->w), 256, 0, s>>>(p->buf(B_PRE), (const unsigned *)p->fmax.p, maps, n,
                                                                  p->h * p->w, make_fdiv(p->h * p->w), thr,
-                                                                 (unsigned long long *)h->census.p);
+                                                                 (unsigned long long *)h->census.p, census_rows);
     SVC_CHECK_LAUNCH();
     if (thr > 0) h->census_maps += (unsigned long long)n;
     p->last_n = n;
     return SVC_OK;
 }
 
-static int saliency_impl(SvcHandle *h, const uint8_t *frames, int n, int height, int width, uint8_t *maps, int thr, void *stream);
+static int saliency_impl(SvcHandle *h, const uint8_t *frames, int n, int height, int width, uint8_t *maps, int thr, void *stream,
+                         uint32_t *census_rows = nullptr);
 
 extern "C" int svc_saliency_u8(SvcHandle *h, const uint8_t *frames, int n, int height, int width, uint8_t *maps,
                                void *stream) {
@@ -3317,7 +3321,17 @@ extern "C" int svc_saliency_thresholded_u8(SvcHandle *h, const uint8_t *frames, 
     return saliency_impl(h, frames, n, height, width, maps, t, stream);
 }
 
-static int saliency_impl(SvcHandle *h, const uint8_t *frames, int n, int height, int width, uint8_t *maps, int thr, void *stream) {
+// svc_saliency_thresholded_u8 that also ADDS, per frame, the pixels of the un-thresholded map at t - 1, t, t + 1 to the caller's
+// device rows census_n4[n][4] (u32; column 3 unused): the per-video form of svc_threshold_census (the multi-video job's lanes
+// mix the frames of many videos in one pass).  The caller zeroes the rows.
+extern "C" int svc_saliency_census_u8(SvcHandle *h, const uint8_t *frames, int n, int height, int width, uint8_t *maps,
+                                      int t, uint32_t *census_n4, void *stream) {
+    if (t < 1 || t > 255) { svc_set_error("svc_saliency_census_u8: threshold outside 1..255"); return SVC_E_INVALID; }
+    return saliency_impl(h, frames, n, height, width, maps, t, stream, census_n4);
+}
+
+static int saliency_impl(SvcHandle *h, const uint8_t *frames, int n, int height, int width, uint8_t *maps, int thr, void *stream,
+                         uint32_t *census_rows) {
     if (!h || n < 0 || (n > 0 && (!frames || !maps)) || height < 8 || width < 8) {     // n = 0: a no-op, null buffers allowed
         svc_set_error("svc_saliency_u8: invalid argument");
         return SVC_E_INVALID;
@@ -3332,7 +3346,7 @@ static int saliency_impl(SvcHandle *h, const uint8_t *frames, int n, int height,
         int m = std::min(h->plan->nb, n - i);
         const uint8_t *fr = frames + i * fin;
         uint8_t *mp = maps + i * fout;
-        RC(forward_chunk(h, fr, m, mp, s, thr));
+        RC(forward_chunk(h, fr, m, mp, s, thr, census_rows ? census_rows + (size_t)i * 4 : nullptr));
     }
     return SVC_OK;
 }
@@ -3478,7 +3492,11 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     env = getenv("SVC_DWPW_MIN_PX");
     if (env) h->dwpw_min_px = atoi(env);
     env = getenv("SVC_MX");
-    if (env) h->mx = (!strcmp(env, "bf16x6") || !strcmp(env, "6")) ? 6 : 0;
+    if (env) {                                               // a typo must not silently select another pipe
+        if (!strcmp(env, "bf16x6") || !strcmp(env, "6")) h->mx = 6;
+        else if (!strcmp(env, "f32") || !strcmp(env, "0")) h->mx = 0;
+        else { svc_set_error("svc_create: SVC_MX=%s (expected f32 or bf16x6)", env); delete h; return SVC_E_INVALID; }
+    }
     if (h->mx && !getenv("SVC_DWPW_MIN_PX")) h->dwpw_min_px = 100;
     env = getenv("SVC_SD_EXCL");
     if (env) h->sd_excl = atoi(env);
@@ -3499,7 +3517,12 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     env = getenv("SVC_SHOT_FORM");
     if (env) h->shot_form = atoi(env);
     env = getenv("SVC_SHOT_MX");
-    if (env) h->shot_mx = !strcmp(env, "bf16x6") ? 6 : !strcmp(env, "bf16x3") ? 3 : !strcmp(env, "f32") ? 0 : atoi(env);
+    if (env) {
+        if (!strcmp(env, "bf16x6") || !strcmp(env, "6")) h->shot_mx = 6;
+        else if (!strcmp(env, "bf16x3") || !strcmp(env, "3")) h->shot_mx = 3;
+        else if (!strcmp(env, "f32") || !strcmp(env, "0")) h->shot_mx = 0;
+        else { svc_set_error("svc_create: SVC_SHOT_MX=%s (expected f32, bf16x6 or bf16x3)", env); delete h; return SVC_E_INVALID; }
+    }
     env = getenv("SVC_SHOT_PT");
     if (env) h->shot_pt = atoi(env) == 1 ? 1 : 2;
     env = getenv("SVC_SHOT_M16");

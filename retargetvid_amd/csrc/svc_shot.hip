@@ -46,7 +46,22 @@ struct ShotConv {
     int T, H, W, C, logC;   // C = 1 << logC for the 27-tap form
     int F, Fpad, kpad, ntaps, ldy, relu;
     int ksplit;             // Dense only: > 1 = grid z cuts K in ksplit parts, part z writes its raw sums to Y + z * M * ldy (k_shot_head adds them, in order)
+    int rT, rt0, rtn;       // Dense only: rows (frames) rt0 .. rt0 + rtn - 1 of every window of rT rows are computed (svc_transnet_predict_rows); rtn == rT: all
 };
+
+// ---- temporal crop (svc_transnet_predict_rows) --------------------------------------------------------------------------
+// The caller keeps rows [r0, r1) of every window (the reference keeps the middle 50 of 100: transnetv1_handler.py:117-121).  A
+// cell reaches 8 frames to either side (its largest dilation), so the last cell is needed on [r0, r1) only, the one before on
+// [r0 - 8, r1 + 8), ... -- every layer computes the frames t0 .. t0 + tn - 1 of every window and nothing else (T = 100, rows
+// 25 .. 74: cells 6 / 5 / 4 / 3 compute 50 / 66 / 82 / 98 frames: a fifth of the network's FLOPs less, the kept rows bit for bit
+// those of the full pass: a kernel's tiles walk a COMPACT index space (window, frame - t0, y, x) and shot_real maps an index to
+// the position in the full-length planes; what the kw-shift needs of neighbouring lanes -- consecutive positions inside a
+// frame row -- holds in both).
+__device__ __forceinline__ long long shot_real(long long c, int T, int t0, int tn, int HW) {
+    if (tn == T) return c;
+    const long long span = (long long)tn * HW, w = c / span;
+    return c + (w * (T - tn) + t0) * HW;
+}
 
 // ---- split-bf16 activations (SVC_MX=bf16x6: the cells with >= 64 input channels on the bf16 matrix pipe) ---------------
 // Between the cells an activation is kept SPLIT (svc_x3.h: x = hi + mid + lo, three bf16, exact) and PLANAR:
@@ -76,7 +91,8 @@ __device__ __forceinline__ void shot_zero_pads(uint4 *Y3, long long Mp, int q0, 
 
 __global__ __launch_bounds__(256) void k_shot_conv(const ShotConv A) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
-    const long long m = std::min((long long)blockIdx.x * 128 + wave * 32 + r, A.M - 1);
+    long long m = std::min((long long)blockIdx.x * 128 + wave * 32 + r, A.M - 1);
+    if (A.ntaps == 1) m = shot_real(m, A.rT, A.rt0, A.rtn, 1);       // Dense: A.M counts the rows that are computed (svc_transnet_predict_rows)
     const int tiles = A.Fpad >> 5, br = blockIdx.y / tiles, nt = blockIdx.y - br * tiles;
     const int d = 1 << br;                                   // temporal dilation of this branch: 1, 2, 4, 8
     // position of this lane
@@ -156,7 +172,7 @@ __global__ __launch_bounds__(256) void k_shot_conv(const ShotConv A) {
     }
     if (A.ksplit > 1) {                                      // a K part of Dense: raw sums, bias and ReLU are k_shot_head's
         if ((long long)blockIdx.x * 128 + wave * 32 + r >= A.M) return;
-        float *yp = A.Y + ((size_t)blockIdx.z * A.M + m) * A.ldy;
+        float *yp = A.Y + ((size_t)blockIdx.z * (A.M / A.rtn * A.rT) + m) * A.ldy;      // part z of ALL rows (real row index)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *(float4 *)(yp + nt * 32 + 8 * g + 4 * hh) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
@@ -466,8 +482,10 @@ __global__ __launch_bounds__(256) void k_shot_pool(const float *__restrict__ X, 
 // Dense(2) + softmax, class 1: one wavefront per frame.  nsplit > 0: X holds Dense(256)'s K parts [nsplit][rows][256] as raw
 // sums -- added here in part order, then its bias b1 and ReLU.
 __global__ __launch_bounds__(64) void k_shot_head(const float *__restrict__ X, const float *__restrict__ W2, const float *__restrict__ b2,
-                                                  float *__restrict__ prob, int rows, int nsplit, const float *__restrict__ b1) {
-    const int row = blockIdx.x, lane = threadIdx.x;
+                                                  float *__restrict__ prob, int rows, int nsplit, const float *__restrict__ b1,
+                                                  int T, int t0, int tn) {
+    // blockIdx.x counts the rows that are computed (tn of every T: svc_transnet_predict_rows); rows = all rows (the parts' stride)
+    const int row = (int)shot_real(blockIdx.x, T, t0, tn, 1), lane = threadIdx.x;
     if (row >= rows) return;
     float4 xv = *(const float4 *)(X + (size_t)row * SHOT_D + lane * 4);
     if (nsplit > 0) {
@@ -495,8 +513,9 @@ struct ShotX3 {
     const uint4 *W3;        // [branch][filter group][iteration = (q, kt, kh)][kw][NT tiles][NPL planes][64 lanes] uint4 (k_shot_x3_weights)
     const float *bias;      // [branches * F]
     uint4 *Y3;              // output planes [4 F / 16][3][Mp][2]: branch br writes channels br * F ..
-    long long M, Mp;        // positions = B * T * H * W; plane stride
+    long long M, Mp;        // positions the launch computes = B * tn * H * W (compact, see shot_real); plane stride
     int T, H, W, C, F, Fpad, relu, xcd;
+    int t0, tn;             // frames t0 .. t0 + tn - 1 of every window (tn == T: all)
 };
 
 // The epilogue of the kernels that keep the kw taps in the accumulators: y[m] = P_1[m] + P_0[m - 1] + P_2[m + 1] (+ bias, ReLU)
@@ -504,7 +523,8 @@ struct ShotX3 {
 // (rows 16..31), tile KT - 1 = kw 2 | 0.  mb = the wave's first computed position, xs = the x of the lane's positions.
 template <int NT, int PT, int KT, bool F16>
 __device__ __forceinline__ void shot_kw_epilogue(const f32x16 (&acc)[PT][KT], uint4 *Y3, long long Mp, long long M, int W, int F,
-                                                 const float *bias, int relu, int br, int ng, long long mb, int r, int hh, const int (&xs)[PT]) {
+                                                 const float *bias, int relu, int br, int ng, long long mb, int r, int hh, const int (&xs)[PT],
+                                                 int T, int t0, int tn, int HW) {
     // lane (r, hh) of tile pt fetches lane r -+ 1 of the same half (ds_bpermute); r = 0 / 31 take the neighbouring tile's last / first lane
     const int lo = (hh * 32 + ((r + 31) & 31)) * 4, hi = (hh * 32 + ((r + 1) & 31)) * 4;
     auto from_left = [&](const f32x16 (&P)[PT], int pt, int i) -> float {       // P[m - 1]
@@ -534,9 +554,10 @@ __device__ __forceinline__ void shot_kw_epilogue(const f32x16 (&acc)[PT][KT], ui
         }
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-            const long long m = mb + 32 * pt + r;
+            const long long cm = mb + 32 * pt + r;
             const int idx = 32 * pt + r;
-            const bool out = idx >= 1 && idx <= 32 * PT - 2 && m < M;
+            const bool out = idx >= 1 && idx <= 32 * PT - 2 && cm < M;
+            const long long m = out ? shot_real(cm, T, t0, tn, HW) : 0;
             const bool useL = xs[pt] >= 1, useR = xs[pt] <= W - 2;
             const int c0 = (ng * NT + n) * 32;               // first channel of the tile inside the branch
             float4 v[4];
@@ -607,7 +628,7 @@ __global__ __launch_bounds__(256) void k_shot_conv_x3(const ShotX3 A) {
     for (int pt = 0; pt < PT; ++pt) {
         const long long m = mb + 32 * pt + r;
         const bool in = m >= 0 && m < A.M;
-        const long long mm = in ? m : 0, fr = mm / HW;
+        const long long mm = in ? shot_real(m, A.T, A.t0, A.tn, HW) : 0, fr = mm / HW;
         const int rem = (int)(mm - fr * HW), y = rem / A.W, x = rem - y * A.W, t = (int)(fr % A.T);
         unsigned b = 0;
         for (int g = 0; g < 9; ++g) {
@@ -711,7 +732,7 @@ __global__ __launch_bounds__(256) void k_shot_conv_x3(const ShotX3 A) {
 #undef SHOT_MMA
 #undef SHOT_LDB
 #undef SHOT_LDA
-    shot_kw_epilogue<NT, PT, KT, F16>(acc, A.Y3, A.Mp, A.M, A.W, A.F, A.bias, A.relu, br, ng, mb, r, hh, xs);
+    shot_kw_epilogue<NT, PT, KT, F16>(acc, A.Y3, A.Mp, A.M, A.W, A.F, A.bias, A.relu, br, ng, mb, r, hh, xs, A.T, A.t0, A.tn, HW);
 }
 
 // The same cell on v_mfma_f32_16x16x32_bf16 (SVC_SHOT_M16): 16 filters x 16 positions per MFMA, 32 channels deep.  Why a second
@@ -746,7 +767,7 @@ __global__ __launch_bounds__(256) void k_shot_conv_x3m(const ShotX3 A) {
     for (int pt = 0; pt < PT; ++pt) {
         const long long m = mb + 16 * pt + p;
         const bool in = m >= 0 && m < A.M;
-        const long long mm = in ? m : 0, fr = mm / HW;
+        const long long mm = in ? shot_real(m, A.T, A.t0, A.tn, HW) : 0, fr = mm / HW;
         const int rem = (int)(mm - fr * HW), y = rem / A.W, x = rem - y * A.W, t = (int)(fr % A.T);
         unsigned b = 0;
         for (int k = 0; k < 9; ++k) {
@@ -843,9 +864,10 @@ __global__ __launch_bounds__(256) void k_shot_conv_x3m(const ShotX3 A) {
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-            const long long m = mb + 16 * pt + p;
+            const long long cm = mb + 16 * pt + p;
             const int idx = 16 * pt + p;
-            const bool out = idx >= 1 && idx <= 16 * PT - 2 && m < A.M;
+            const bool out = idx >= 1 && idx <= 16 * PT - 2 && cm < A.M;
+            const long long m = out ? shot_real(cm, A.T, A.t0, A.tn, HW) : 0;
             const bool useL = xs[pt] >= 1, useR = xs[pt] <= A.W - 2;
             const int c0 = (ng * NT + n) * 16 + 4 * g;       // the lane's four channels inside the branch
             const float4 b = *(const float4 *)(A.bias + br * A.F + c0);
@@ -1057,7 +1079,7 @@ __global__ __launch_bounds__(256) void k_shot_first_x3(const ShotFirst A) {
                 for (int pt = 0; pt < PT; ++pt)
                     acc[pt][wt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[PW[pr]], a[q][pt][PA[pr]], acc[pt][wt], 0, 0, 0);
         }
-    shot_kw_epilogue<1, PT, KT, true>(acc, A.Y3, A.Mp, A.M, A.W, 16, A.bias, A.relu, br, 0, mb, r, hh, xs);
+    shot_kw_epilogue<1, PT, KT, true>(acc, A.Y3, A.Mp, A.M, A.W, 16, A.bias, A.relu, br, 0, mb, r, hh, xs, A.T, 0, A.T, HW);
     }
 }
 
@@ -1065,15 +1087,16 @@ __global__ __launch_bounds__(256) void k_shot_first_x3(const ShotFirst A) {
 // planes, so the maximum is taken on the sums and split again (the same planes come out).  Yf: the last pool writes fp32
 // [position][C] for Dense(256) instead.
 __global__ __launch_bounds__(256) void k_shot_pool_x3(const uint4 *__restrict__ X3, long long Mp_in, uint4 *__restrict__ Y3, long long Mp_out,
-                                                      float *__restrict__ Yf, size_t total, int H, int W, int Q) {
+                                                      float *__restrict__ Yf, size_t total, int H, int W, int Q, int T, int t0, int tn) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int OH = H / 2, OW = W / 2;
     const int hh = (int)(i & 1);
     size_t u = i >> 1;
-    const size_t Mo = total / ((size_t)2 * Q);
-    const size_t mo = u % Mo;
+    const size_t Mo = total / ((size_t)2 * Q);               // output positions of the frames that are computed (tn of every T)
+    const size_t mc = u % Mo;
     const int q = (int)(u / Mo);
+    const size_t mo = (size_t)shot_real((long long)mc, T, t0, tn, OH * OW);      // ... in the full-length planes
     const int ox = (int)(mo % OW);
     size_t v = mo / OW;
     const int oy = (int)(v % OH);
@@ -1101,8 +1124,8 @@ __global__ __launch_bounds__(256) void k_shot_pool_x3(const uint4 *__restrict__ 
         *(float4 *)(o + 8) = v1;
     } else {
         shot_store_x3(Y3, Mp_out, (long long)mo, hh, q, v0, v1);
-        if (mo < SHOT_PAD) {
-            uint4 *z = Y3 + ((size_t)(q * 3) * Mp_out + mo) * 2 + hh;
+        if (mc < SHOT_PAD) {
+            uint4 *z = Y3 + ((size_t)(q * 3) * Mp_out + mc) * 2 + hh;
             z[0] = z[(size_t)Mp_out * 2] = z[(size_t)Mp_out * 4] = make_uint4(0, 0, 0, 0);
         }
     }
@@ -1152,9 +1175,40 @@ extern "C" int svc_transnet_load(SvcHandle *h, const float *blob_host, size_t n_
 
 extern "C" int svc_transnet_matrix_pipe(const SvcHandle *h) { return h ? (h->shot_mx < 0 ? h->mx : h->shot_mx) : 0; }
 
+// TransNet knobs of a handle as an array {matrix pipe (-1 = the handle's SVC_MX), 16x16x32 tiles, 32x32x16 tiles, XCD order, fp32 form}: what
+// ShotTransNet.clone() copies to the engine of a second network instead of re-reading the environment
+extern "C" int svc_transnet_config_get(const SvcHandle *h, int32_t *cfg5) {
+    if (!h || !cfg5) { svc_set_error("svc_transnet_config_get: invalid argument"); return SVC_E_INVALID; }
+    cfg5[0] = h->shot_mx; cfg5[1] = h->shot_m16; cfg5[2] = h->shot_pt; cfg5[3] = h->shot_xcd; cfg5[4] = h->shot_form;
+    return SVC_OK;
+}
+extern "C" int svc_transnet_config_set(SvcHandle *h, const int32_t *cfg5) {
+    if (!h || !cfg5) { svc_set_error("svc_transnet_config_set: invalid argument"); return SVC_E_INVALID; }
+    const int mx = cfg5[0], m16 = cfg5[1], pt = cfg5[2], form = cfg5[4];
+    if (!(mx == -1 || mx == 0 || mx == 3 || mx == 6) || !(m16 == 0 || (m16 >= 2 && m16 <= 4)) || !(pt == 1 || pt == 2) || form < 0 || form > 2) {
+        svc_set_error("svc_transnet_config_set: {%d, %d, %d, %d, %d} is not a configuration", mx, m16, pt, cfg5[3], form);
+        return SVC_E_INVALID;
+    }
+    h->shot_mx = mx; h->shot_m16 = m16; h->shot_pt = pt; h->shot_xcd = cfg5[3] != 0; h->shot_form = form;
+    return SVC_OK;                                           // (the split weight copies follow at the next predict: shot_w3_mx keys them)
+}
+
+static int transnet_predict_rows(SvcHandle *h, const uint8_t *frames, int n_windows, int frames_per_window, int row0, int row1, float *probs,
+                                 void *stream);
+
 extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_windows, int frames_per_window, float *probs,
                                     void *stream) {
-    if (!h || n_windows < 0 || frames_per_window < 1 || (n_windows > 0 && (!frames || !probs))) {
+    return transnet_predict_rows(h, frames, n_windows, frames_per_window, 0, frames_per_window, probs, stream);
+}
+
+extern "C" int svc_transnet_predict_rows(SvcHandle *h, const uint8_t *frames, int n_windows, int frames_per_window, int row0, int row1,
+                                         float *probs, void *stream) {
+    return transnet_predict_rows(h, frames, n_windows, frames_per_window, row0, row1, probs, stream);
+}
+
+static int transnet_predict_rows(SvcHandle *h, const uint8_t *frames, int n_windows, int frames_per_window, int row0, int row1, float *probs,
+                                 void *stream) {
+    if (!h || n_windows < 0 || frames_per_window < 1 || (n_windows > 0 && (!frames || !probs)) || row0 < 0 || row1 > frames_per_window || row0 >= row1) {
         svc_set_error("svc_transnet_predict: invalid argument");
         return SVC_E_INVALID;
     }
@@ -1169,6 +1223,14 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
     const int T = frames_per_window;
     const int mx = h->shot_mx < 0 ? h->mx : h->shot_mx;      // 0: fp32 MFMA; 6 / 3: split-bf16 planes (SVC_SHOT_MX, default = SVC_MX)
     const int NPL = mx == 3 ? 2 : 3;
+    // frames [ca[i], cb[i]) of every window that cell i computes (shot_real): the last cell the kept rows, every cell in front of
+    // it 8 more on either side (the fp32 pipe computes every frame; so does the first cell)
+    int ca[SHOT_L * SHOT_S], cb[SHOT_L * SHOT_S];
+    ca[SHOT_L * SHOT_S - 1] = mx ? row0 : 0;
+    cb[SHOT_L * SHOT_S - 1] = mx ? row1 : T;
+    for (int i = SHOT_L * SHOT_S - 2; i >= 0; --i) { ca[i] = std::max(0, ca[i + 1] - 8); cb[i] = std::min(T, cb[i + 1] + 8); }
+    ca[0] = 0; cb[0] = T;
+    const int ka = ca[SHOT_L * SHOT_S - 1], kn = cb[SHOT_L * SHOT_S - 1] - ka;        // Dense + head: the kept rows
     // split-bf16 weights of the cells with >= 64 input channels, packed once per load in the kernels' read order
     size_t w3_off[SHOT_L * SHOT_S] = {0};
     if (mx) {
@@ -1247,13 +1309,14 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
                 if (mx && k.cpad >= 64 && h->shot_m16) {
                     ShotX3 X;
                     X.X3 = (const uint4 *)P[cur]; X.W3 = (const uint4 *)h->shot_w3.p + w3_off[b * SHOT_S + c]; X.bias = blob + k.b_off;
-                    X.Y3 = (uint4 *)P[cur ^ 1]; X.M = Mc; X.Mp = Mp; X.T = T; X.H = H; X.W = W; X.C = k.cpad; X.F = k.f; X.Fpad = k.fpad;
+                    X.Y3 = (uint4 *)P[cur ^ 1]; X.Mp = Mp; X.T = T; X.H = H; X.W = W; X.C = k.cpad; X.F = k.f; X.Fpad = k.fpad;
                     X.relu = 1; X.xcd = h->shot_xcd;
+                    X.t0 = ca[b * SHOT_S + c]; X.tn = cb[b * SHOT_S + c] - X.t0; X.M = (long long)nw * X.tn * H * W;
                     // position tiles of 16 per wavefront: shot_m16 with two filter tiles, one more with one (the 16-filter cell: 1 167 us at
                     // three tiles, 1 066 at four; two filter tiles at four tiles leave one wave per SIMD: 465 / 872 -> 592 / 1 028 us)
                     const int NT = std::min(k.f / 16, 2), PT = NT == 1 ? std::min(h->shot_m16 + 1, 4) : h->shot_m16;
                     const int WGS = 4 * (16 * PT - 2);
-                    unsigned gx = (unsigned)((Mc + WGS - 1) / WGS);
+                    unsigned gx = (unsigned)((X.M + WGS - 1) / WGS);
                     if (X.xcd) gx = (gx + 7) / 8 * 8;
                     dim3 grid(gx, (unsigned)(4 * (k.f / (16 * NT))));
                     const size_t lds = (size_t)2 * 3 * NT * NPL * 64 * sizeof(uint4);
@@ -1271,12 +1334,13 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
                 if (mx && k.cpad >= 64) {
                     ShotX3 X;
                     X.X3 = (const uint4 *)P[cur]; X.W3 = (const uint4 *)h->shot_w3.p + w3_off[b * SHOT_S + c]; X.bias = blob + k.b_off;
-                    X.Y3 = (uint4 *)P[cur ^ 1]; X.M = Mc; X.Mp = Mp; X.T = T; X.H = H; X.W = W; X.C = k.cpad; X.F = k.f; X.Fpad = k.fpad;
+                    X.Y3 = (uint4 *)P[cur ^ 1]; X.Mp = Mp; X.T = T; X.H = H; X.W = W; X.C = k.cpad; X.F = k.f; X.Fpad = k.fpad;
                     X.relu = 1; X.xcd = h->shot_xcd;
+                    X.t0 = ca[b * SHOT_S + c]; X.tn = cb[b * SHOT_S + c] - X.t0; X.M = (long long)nw * X.tn * H * W;
                     const int NT = 1, PT = h->shot_pt;
                     const bool f16 = k.f == 16;
                     const int WGS = 4 * (32 * PT - 2);
-                    unsigned gx = (unsigned)((Mc + WGS - 1) / WGS);
+                    unsigned gx = (unsigned)((X.M + WGS - 1) / WGS);
                     if (X.xcd) gx = (gx + 7) / 8 * 8;
                     dim3 grid(gx, (unsigned)(4 * (k.fpad / (32 * NT))));
                     const size_t lds = (size_t)2 * (f16 ? 2 : 3 * NT) * NPL * 64 * sizeof(uint4);
@@ -1297,7 +1361,7 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
                 A.logC = 0;
                 while ((1 << A.logC) < k.cpad) ++A.logC;
                 A.F = k.f; A.Fpad = k.fpad; A.kpad = k.kpad; A.ntaps = 27; A.ldy = 4 * k.f; A.relu = 1;
-                A.ksplit = 1;
+                A.ksplit = 1; A.rT = A.rtn = 1; A.rt0 = 0;
                 dim3 grid((unsigned)((A.M + 127) / 128), (unsigned)(4 * (k.fpad / 32)));
                 const int shot_form = h->shot_form;             // 0: direct operand loads, 1: weights through LDS, 2: both operands (SVC_SHOT_FORM)
                 if (shot_form == 2 && k.cpad >= 64 && k.cpad % 64 == 0) {
@@ -1324,10 +1388,11 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
             const int C = 4 * (SHOT_F << b);
             if (mx) {
                 const long long Mo = (long long)nfr * (H / 2) * (W / 2), Mpo = (Mo + SHOT_PAD + 3) / 4 * 4;
-                const size_t total = (size_t)Mo * (C / 16) * 2;
+                const int pa = ca[b * SHOT_S + SHOT_S - 1], pn = cb[b * SHOT_S + SHOT_S - 1] - pa;    // the frames the block's last cell computed
+                const size_t total = (size_t)nw * pn * (H / 2) * (W / 2) * (C / 16) * 2;
                 const bool last = b == SHOT_L - 1;
                 k_shot_pool_x3<<<(unsigned)((total + 255) / 256), 256, 0, s>>>((const uint4 *)P[cur], Mp, (uint4 *)P[cur ^ 1], Mpo,
-                                                                                last ? P[cur ^ 1] : nullptr, total, H, W, C / 16);
+                                                                                last ? P[cur ^ 1] : nullptr, total, H, W, C / 16, T, pa, pn);
             } else {
                 const size_t total = nfr * (H / 2) * (W / 2) * (C / 4);
                 k_shot_pool<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(P[cur], P[cur ^ 1], total, H, W, C / 4);
@@ -1340,7 +1405,8 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
             ShotConv A;
             const int nflat = H * W * 4 * (SHOT_F << (SHOT_L - 1));
             A.X = P[cur]; A.Wt = blob + d1w; A.bias = blob + d1b; A.Y = P[cur ^ 1];
-            A.M = (long long)nfr; A.T = 1; A.H = 1; A.W = 1; A.C = nflat; A.logC = 0;
+            A.M = (long long)nw * kn; A.rT = T; A.rt0 = ka; A.rtn = kn;      // the kept rows of every window
+            A.T = 1; A.H = 1; A.W = 1; A.C = nflat; A.logC = 0;
             A.F = SHOT_D; A.Fpad = SHOT_D; A.kpad = nflat; A.ntaps = 1; A.ldy = SHOT_D; A.relu = 1;
             // 7 x 8 workgroups of 576 steps leave the chip idle (184 us per 800 frames): K in eight parts, summed by the head
             A.ksplit = nflat % (8 * 8) == 0 ? 8 : 1;
@@ -1348,8 +1414,8 @@ extern "C" int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_w
             k_shot_conv<<<grid, 256, 0, s>>>(A);
             SVC_CHECK_LAUNCH();
             cur ^= 1;
-            k_shot_head<<<(unsigned)nfr, 64, 0, s>>>(P[cur], blob + d2w, blob + d2b, probs + (size_t)w0 * T, (int)nfr,
-                                                     A.ksplit > 1 ? A.ksplit : 0, blob + d1b);
+            k_shot_head<<<(unsigned)(nw * kn), 64, 0, s>>>(P[cur], blob + d2w, blob + d2b, probs + (size_t)w0 * T, (int)nfr,
+                                                           A.ksplit > 1 ? A.ksplit : 0, blob + d1b, T, ka, kn);
             SVC_CHECK_LAUNCH();
         }
     }

@@ -70,10 +70,11 @@ class Engine:
         return out
 
     # -- saliency ------------------------------------------------------------------------
-    def saliency(self, frames, out=None, threshold=0):
+    def saliency(self, frames, out=None, threshold=0, census=None):
         """uint8 [n,h,w,3] RGB at saliency size -> uint8 [n,h,w] maps (frame-major); `out`: write into this tensor.
         threshold > 0: the maps come out thresholded (sc_threshold fused into the network's last kernel: the bytes of
-        saliency() + threshold_(), one launch less)."""
+        saliency() + threshold_(), one launch less).  census (with a threshold): int32 CUDA rows [n,4] to which the pixels
+        of every frame's raw map at t - 1, t, t + 1 are ADDED (svc_saliency_census_u8; the caller zeroes the rows)."""
         _need_cuda(frames, torch.uint8, 'frames')
         n, h, w, c = frames.shape
         assert c == 3
@@ -82,7 +83,11 @@ class Engine:
         else:
             _need_cuda(out, torch.uint8, 'out')
             assert tuple(out.shape) == (n, h, w)
-        if threshold:
+        if census is not None:
+            _need_cuda(census, torch.int32, 'census')
+            assert threshold and tuple(census.shape) == (n, 4)
+            _lib.check(self.lib.svc_saliency_census_u8(self._h, _ptr(frames), n, h, w, _ptr(out), int(threshold), _ptr(census), _stream()))
+        elif threshold:
             _lib.check(self.lib.svc_saliency_thresholded_u8(self._h, _ptr(frames), n, h, w, _ptr(out), int(threshold), _stream()))
         else:
             _lib.check(self.lib.svc_saliency_u8(self._h, _ptr(frames), n, h, w, _ptr(out), _stream()))

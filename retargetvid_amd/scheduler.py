@@ -22,6 +22,12 @@ One feeder thread drives all lanes round-robin (a lane takes the next video from
 the low-occupancy tail of one lane overlaps the full-chip network of the others, as bench.py's batches do.  Every video's
 result equals smartVidCrop.smart_vid_crop_ratios on that video alone (tests/test_gpu_scheduler.py).
 
+Videos given as CALLABLES are built on demand.  Without shot_net the feeder thread calls them, one at a time, when a lane takes
+the video.  With shot_net= the PLANNER threads call them (shot detection runs ahead of the lanes): up to JobScheduler.PLANNERS
+callables run concurrently, on non-feeder threads and with a planner's HIP stream current -- they must be thread-safe -- and
+at most `plan_ahead` videos (default: lanes + 2 per planner) are materialised beyond the one the feeder took last, so a job of
+thousands of on-demand videos holds a bounded number of them in memory.
+
 Host logic + torch plumbing only; device work goes through ops.Engine (the C ABI)."""
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -62,7 +68,7 @@ def lane_rows_for(videos, CP, lanes, cap=4096):
 
 
 class _Video:
-    __slots__ = ('idx', 'video', 'plan', 'lane', 'row0', 'xy', 'remaining', 'maps', 'pos', 'done', 'sink', 'ready')
+    __slots__ = ('idx', 'video', 'plan', 'lane', 'row0', 'xy', 'remaining', 'maps', 'pos', 'done', 'sink', 'ready', 'census')
 
     def __init__(self, idx, video, plan, sink):
         self.idx, self.video, self.plan = idx, video, plan
@@ -100,6 +106,10 @@ class _Lane:
             self.small = torch.empty((rows, sal_h, sal_w, 3), dtype=torch.uint8, device=dev)     # network input frames, in order
             self.maps = torch.zeros((rows, sal_h, sal_w), dtype=torch.uint8, device=dev)         # stream rows (zero rows stay zero)
             self.tmp = torch.empty((sc.chunk, sal_h, sal_w), dtype=torch.uint8, device=dev)
+            # threshold census (the regime diagnostic, per video): pixels of a row's raw map at t - 1, t, t + 1, added by the network's
+            # last kernel (svc_saliency_census_u8); rows without a network pass stay 0
+            self.census = torch.zeros((rows, 4), dtype=torch.int32, device=dev)
+            self.census_tmp = torch.zeros((sc.chunk, 4), dtype=torch.int32, device=dev)
         self.cap = rows
         self.row_of_frame = np.empty(rows, np.int64)
         self.flags = np.zeros(rows, np.uint8)
@@ -119,7 +129,6 @@ class _Lane:
             self.drain()
             self._alloc(geom[0], geom[1], plan['n_sel'])
         v.lane, v.row0 = self, self.rows_in
-        self.sched.lane_of[v.idx] = self.k
         v.maps = self.maps[v.row0:v.row0 + plan['n_sel']]         # a VIEW of the lane's storage until the video's last centre has arrived (_dispatch clones it then)
         slot = self.next_slot
         self.next_slot += 1
@@ -203,15 +212,22 @@ class _Lane:
             if k:
                 rows = self.row_of_frame[f0:f0 + k]
                 r0 = int(rows[0])
+                cen = 1 <= int(sc.CP['t_threshold']) <= 254
                 if int(rows[-1]) - r0 + 1 == k:                       # no zero row inside: the network writes in place
-                    self.eng.saliency(self.small[f0:f0 + k], out=self.maps[r0:r0 + k], threshold=sc.CP['t_threshold'])
+                    self.eng.saliency(self.small[f0:f0 + k], out=self.maps[r0:r0 + k], threshold=sc.CP['t_threshold'],
+                                      census=self.census[r0:r0 + k] if cen else None)
                 else:
-                    self.eng.saliency(self.small[f0:f0 + k], out=self.tmp[:k], threshold=sc.CP['t_threshold'])
+                    if cen:
+                        self.census_tmp[:k].zero_()
+                    self.eng.saliency(self.small[f0:f0 + k], out=self.tmp[:k], threshold=sc.CP['t_threshold'],
+                                      census=self.census_tmp[:k] if cen else None)
                     brk = np.flatnonzero(np.diff(rows) != 1) + 1
                     a = 0
                     for b in list(brk) + [k]:                         # runs of consecutive rows
                         ra = int(rows[a])
                         self.maps[ra:ra + (b - a)].copy_(self.tmp[a:b])
+                        if cen:
+                            self.census[ra:ra + (b - a)].copy_(self.census_tmp[a:b])
                         a = int(b)
         t1 = time.perf_counter()
         self.pipe.submit_rows(n_rows, self.flags[self.rows_called:R])
@@ -256,7 +272,7 @@ class JobScheduler:
     """crop_videos' engine room.  ``videos``: sequence of ingest_pickle dicts or zero-argument callables producing them."""
 
     def __init__(self, CP, ratios=None, lanes=4, chunk=32, state_dict=None, seed=0, engines=None, shot_net=None,
-                 host_threads=3, depth=2, lane_rows=4096, piece_frames=256, piece_bytes=256 << 20):
+                 host_threads=3, depth=2, lane_rows=4096, piece_frames=256, piece_bytes=256 << 20, plan_ahead=None):
         import torch
         from . import ops as _ops
         if CP['exit_on_spread_sal'] or CP['exit_on_low_cvrg'] or CP['t_border'] != -1:
@@ -267,6 +283,7 @@ class JobScheduler:
         self.chunk, self.depth, self.lane_rows = int(chunk), int(depth), int(lane_rows)
         self.piece_frames, self.piece_bytes = int(piece_frames), int(piece_bytes)
         self.shot_net = shot_net
+        self.plan_ahead = None if plan_ahead is None else max(1, int(plan_ahead))    # None: lanes + 2 per planner (set in _start_planner)
         self._plan_ready = self._planned = self._plan_err = None
         self._plan_nets = []                                  # the planner threads' networks: shot_net and its clones (made by the first job)
         self.dev = torch.device('cuda', torch.cuda.current_device())
@@ -282,8 +299,9 @@ class JobScheduler:
 
     def close(self):
         self.pool.shutdown(wait=True)
-        for n in self._plan_nets[1:]:                          # the clones are the scheduler's; shot_net itself is the caller's
-            n.close()
+        for n in self._plan_nets:                              # the clones are the scheduler's; shot_net itself is the caller's
+            if n is not self.shot_net:
+                n.close()
         self._plan_nets = []
         if self.own_engines:
             for e in self.engines:
@@ -302,13 +320,10 @@ class JobScheduler:
         self.out = [None] * len(self.videos)
         self.next_idx = 0
         self.futures = []
-        self.lane_of = {}                                     # video -> lane (for the per-lane threshold census below)
         self.n_chunks = self.n_net_frames = 0
         self.host_s = dict(plan=0.0, intake=0.0, enqueue_net=0.0, enqueue_tail=0.0, wait=0.0, dispatch=0.0)
         t0 = time.perf_counter()
         lanes = [_Lane(self, e, s, k) for k, (e, s) in enumerate(zip(self.engines, self.streams))]
-        for e in self.engines:
-            e.threshold_census(reset=True)
         t0 = time.perf_counter()
         planner = self._start_planner()
         try:
@@ -347,17 +362,12 @@ class JobScheduler:
         missing = [i for i, o in enumerate(self.out) if o is None]
         if missing:
             raise RuntimeError('JobScheduler: videos %r were never completed' % (missing[:8],))
-        # the regime diagnostic (smartVidCrop.after_ingest): the threshold is fused into the network here, so the figure is the
-        # lane engine's census over this job -- every video of a lane reports that lane's mean
-        ppl = [e.threshold_census(reset=True)['pixels_per_grey_level'] for e in self.engines]
-        for i, o in enumerate(self.out):
-            v = ppl[self.lane_of[i]] if i in self.lane_of else None
-            for ratio in o:
-                o[ratio][1]['pixels_per_grey_level_at_threshold'] = None if v is None else round(float(v), 2)
         self.stats = dict(videos=len(self.videos), chunks=self.n_chunks, network_frames=self.n_net_frames,
                           mean_chunk_fill=self.n_net_frames / max(1, self.n_chunks) / self.chunk,
                           seconds_device_side=t1 - t0, seconds_host_stage_drain=t2 - t1, lanes=len(lanes),
                           feeder_seconds={k: round(v, 4) for k, v in self.host_s.items()})
+        if planner:                                           # shot detection ahead of the lanes: how far ahead it was allowed / ever got
+            self.stats.update(planners=len(planner), plan_ahead=self.plan_ahead, plan_high_water=self.plan_high_water)
         return self.out
 
     # ---- feeder-side helpers ------------------------------------------------------------------------------------------
@@ -366,14 +376,18 @@ class JobScheduler:
         if self.next_idx >= len(self.videos):
             return None
         i = self.next_idx
-        self.next_idx += 1
         shots = None
         if self._plan_ready is not None:                      # shot detection ran (or is running) in the planner thread
+            with self._plan_cv:                               # the planners may now materialise video i + plan_ahead
+                self.next_idx += 1
+                self._plan_cv.notify_all()
             self._plan_ready[i].wait()
             if self._plan_err is not None:
                 raise self._plan_err
             v, shots = self._planned[i]
             self._planned[i] = None
+        else:
+            self.next_idx += 1
         with torch.cuda.stream(lane.stream):
             if self._plan_ready is None:
                 v = self.videos[i]() if callable(self.videos[i]) else self.videos[i]
@@ -397,8 +411,16 @@ class JobScheduler:
             return None
         self._plan_ready = [threading.Event() for _ in self.videos]
         self._planned = [None] * len(self.videos)
+        self._plan_cv = threading.Condition()
+        self.plan_high_water = 0                              # most videos ever planned beyond the feeder's (stats; the bound is plan_ahead)
         while len(self._plan_nets) < min(self.PLANNERS, len(self.videos)):
-            self._plan_nets.append(self.shot_net if not self._plan_nets else self.shot_net.clone())
+            # planner 0 runs the caller's network only when that network owns its engine: a network built on an engine the
+            # caller also uses elsewhere (a lane's, get_engine()'s) must not be driven from a second thread -- a handle's
+            # workspace serves one call at a time -- so it is cloned for planner 0 as well
+            own = bool(getattr(self.shot_net, '_own', False))
+            self._plan_nets.append(self.shot_net if (not self._plan_nets and own) else self.shot_net.clone())
+        if self.plan_ahead is None:
+            self.plan_ahead = len(self.engines) + 2 * len(self._plan_nets)
         ths = [threading.Thread(target=self._plan_ahead, args=(k, len(self._plan_nets)), name='svc-shot-planner-%d' % k, daemon=True)
                for k in range(len(self._plan_nets))]
         for th in ths:
@@ -413,6 +435,14 @@ class JobScheduler:
                 st = torch.cuda.Stream(device=self.dev)
                 with torch.cuda.stream(st):
                     for i in range(k, len(self.videos), stride):
+                        # back-pressure: video i is materialised only when the feeder is within plan_ahead videos of it (the
+                        # planners take ~3 ms per video, the lanes ~11: unbounded, a job of on-demand callables would be built
+                        # whole long before the lanes reach it).  The feeder only ever waits for video next_idx - 1, which this
+                        # condition always admits: no deadlock.
+                        with self._plan_cv:
+                            while not (self._plan_stop or self._plan_err is not None or i < self.next_idx + self.plan_ahead):
+                                self._plan_cv.wait(0.5)
+                            self.plan_high_water = max(self.plan_high_water, i - self.next_idx + 1)
                         if self._plan_stop or self._plan_err is not None:
                             break
                         v = self.videos[i]() if callable(self.videos[i]) else self.videos[i]
@@ -434,7 +464,9 @@ class JobScheduler:
 
     def _stop_planner(self, ths):
         if ths:
-            self._plan_stop = True
+            with self._plan_cv:
+                self._plan_stop = True
+                self._plan_cv.notify_all()
             for th in ths:
                 th.join()
 
@@ -458,6 +490,8 @@ class JobScheduler:
                 # (and whatever storage drain() has replaced since) alive, and results of different videos do not alias
                 with torch.cuda.stream(lane.stream):
                     v.maps = v.maps.clone()
+                    n_sel = v.plan['n_sel']
+                    v.census = lane.census[v.row0:v.row0 + n_sel].sum(0)      # the video's own rows (read on the host by _finish_video)
                     v.ready = torch.cuda.Event()
                     v.ready.record(lane.stream)               # _finish_video waits for the copy before anything reads it
                 self.futures.append(self.pool.submit(self._finish_video, v))
@@ -468,6 +502,12 @@ class JobScheduler:
         S.sc_init_time()
         v.ready.synchronize()              # the video's own copy of its maps is complete (made on the lane's stream; read on any)
         VD = S._LazySmaps(S._ingest_dict(v.plan, v.maps, xy_stream=v.xy))
+        # the regime diagnostic of THIS video (smartVidCrop.after_ingest reports it): its maps' pixels at t - 1, t, t + 1 per map and level
+        n_net = int((~v.plan['zero_map']).sum())
+        tt = int(self.CP['t_threshold'])
+        if n_net and 1 <= tt <= 254:
+            c = v.census.cpu().numpy()
+            VD['pixels_per_grey_level_at_threshold'] = float(c[0] + c[1] + c[2]) / (3.0 * n_net)
         out = {}
         base = None
         for ratio in self.ratios:

@@ -668,13 +668,14 @@ def after_ingest(VD, CP, engine, verbose=False):
     maps = VD['smaps_dev']
     t = time.perf_counter()
     ppl = VD.get('pixels_per_grey_level_at_threshold')
+    near = None
     if 'xy_stream' not in VD:
-        # the regime diagnostic (include/svc.h: svc_threshold_census): pixels of the raw maps at t - 1, t, t + 1 per map and level
+        # the regime diagnostic (include/svc.h: svc_threshold_census): pixels of the raw maps at t - 1, t, t + 1 per map and level.
+        # (maps - (t - 1)) wraps in uint8, so the three levels are exactly the values 0..2: one temporary, no synchronisation here --
+        # the count travels to the host with the centres below
         tt = int(CP['t_threshold'])
         if maps.numel() and 1 <= tt <= 254:
-            near = ((maps >= tt - 1) & (maps <= tt + 1)).sum()
-            n_net = max(1, int(VD.get('n_net_maps', VD['fc_sel'])))
-            ppl = float(near.item()) / (3.0 * n_net)
+            near = (maps - (tt - 1)).le_(2).sum()
         engine.threshold_(maps, CP['t_threshold'])
     sc_register_time(t, '_thresh')                     # (enqueue time; the stream is synchronised by the D2H below)
 
@@ -683,7 +684,14 @@ def after_ingest(VD, CP, engine, verbose=False):
         xy = VD['xy_stream']
     else:
         flags = blend_flags(VD['fc_sel'], VD['segmentation_sel']) if CP['clust_filt'] else None
-        xy = engine.cluster_center_(maps, flags, CP).cpu().numpy()       # one D2H of n x 2 doubles
+        xy_dev = engine.cluster_center_(maps, flags, CP)
+        if near is not None:                           # one D2H: n x 2 doubles + the census count
+            import torch
+            both = torch.cat([xy_dev.reshape(-1), near.to(torch.float64).reshape(1)]).cpu().numpy()
+            xy = both[:-1].reshape(-1, 2)
+            ppl = float(both[-1]) / (3.0 * max(1, int(VD.get('n_net_maps', VD['fc_sel']))))
+        else:
+            xy = xy_dev.cpu().numpy()                  # one D2H of n x 2 doubles
     results['cuts_clust'] = 0
     sc_register_time(t, '_clustering')
 
@@ -734,7 +742,7 @@ def after_ingest(VD, CP, engine, verbose=False):
     # t_threshold (mean per map).  Two correct fp32 implementations of the network differ by one grey level on ~0.3 % of the
     # pixels; ~7 - 45 pixels per level keep the crop windows identical to the reference CPU path's, ~500 (a checkpoint whose
     # maps are flat around the threshold) make a fifth of them differ by more than a pixel.  The multi-video
-    # job reports the figure of the lane's engine over the job so far (the threshold is fused into the network there).
+    # job reports the same per-video figure (counted by the network's last kernel: svc_saliency_census_u8).
     results['pixels_per_grey_level_at_threshold'] = None if ppl is None else round(float(ppl), 2)
     results['params'] = ''.join(' %-18s : %s\n' % (k, str(v)) for k, v in CP.items())
     results['mean_sal_score'] = VD['mean_sal_score']

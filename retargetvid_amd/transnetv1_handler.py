@@ -48,19 +48,25 @@ class ShotTransNet:
         self._blob = blob
         _lib.check(self.eng.lib.svc_transnet_load(self.eng._h, blob.ctypes.data_as(ctypes.c_void_p), blob.size))
 
+    def config(self):
+        """The engine's TransNet knobs (svc_transnet_config_get): [matrix pipe (-1 = the engine's SVC_MX), 16x16x32 tiles, 32x32x16
+        tiles, XCD order, fp32 form]."""
+        cfg = (ctypes.c_int32 * 5)()
+        _lib.check(self.eng.lib.svc_transnet_config_get(self.eng._h, cfg))
+        return list(cfg)
+
     def clone(self):
-        """A second network with the same weights and matrix pipe on an engine of its own (a handle's workspace serves one call
-        at a time): what the job scheduler's second planner thread runs."""
-        import os
-        old = os.environ.get('SVC_SHOT_MX')
-        os.environ['SVC_SHOT_MX'] = self.matrix_pipe()               # read when the engine is created
-        try:
-            return ShotTransNet(self.params, windows_per_call=self.windows_per_call, _blob=self._blob)
-        finally:
-            if old is None:
-                os.environ.pop('SVC_SHOT_MX', None)
-            else:
-                os.environ['SVC_SHOT_MX'] = old
+        """A second network with the same weights, matrix pipe and kernel knobs on an engine of its own (a handle's workspace
+        serves one call at a time): what the job scheduler's planner threads run.  The knobs are copied handle to handle
+        (svc_transnet_config_get / _set), not through the process environment.  Memory: the copy owns an engine (the saliency
+        network's weights, ~15 MB; its workspace is only allocated by a saliency call) and, after its first prediction, a TransNet
+        workspace of up to 1.6 GB (two activation buffers for windows_per_call windows)."""
+        cfg = self.config()
+        if cfg[0] < 0:                                        # "follow SVC_MX": pin what THIS engine resolved it to
+            cfg[0] = int(self.eng.lib.svc_transnet_matrix_pipe(self.eng._h))
+        net = ShotTransNet(self.params, windows_per_call=self.windows_per_call, _blob=self._blob)
+        _lib.check(net.eng.lib.svc_transnet_config_set(net.eng._h, (ctypes.c_int32 * 5)(*cfg)))
+        return net
 
     def matrix_pipe(self):
         """'f32', 'bf16x6' or 'bf16x3': what the convolution cells run on (svc_transnet_matrix_pipe; environment SVC_SHOT_MX
@@ -73,13 +79,21 @@ class ShotTransNet:
         self.eng = None
 
     # -- the reference's methods --------------------------------------------------------------------------------
-    def predict_raw_device(self, frames):
-        """CUDA uint8 [batch, frames, 27, 48, 3] -> CUDA float32 [batch, frames]."""
+    def predict_raw_device(self, frames, rows=None):
+        """CUDA uint8 [batch, frames, 27, 48, 3] -> CUDA float32 [batch, frames].  rows=(a, b): only columns a .. b - 1 of the
+        result are wanted (svc_transnet_predict_rows: the layers are computed on the frames those depend on and nothing else;
+        the kept columns are bit for bit those of the full pass, the others are unspecified)."""
         if not (torch.is_tensor(frames) and frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous()):
             raise TypeError('frames must be a contiguous CUDA uint8 tensor')
         assert frames.dim() == 5 and tuple(frames.shape[2:]) == (self.params.INPUT_HEIGHT, self.params.INPUT_WIDTH, 3), \
             ' [ShotTransNet] Input shape must be [batch, frames, height, width, 3].'
         nb, nt = int(frames.shape[0]), int(frames.shape[1])
+        if rows is not None and (int(rows[0]), int(rows[1])) != (0, nt):
+            out = torch.zeros((nb, nt), dtype=torch.float32, device=frames.device)
+            _lib.check(self.eng.lib.svc_transnet_predict_rows(self.eng._h, ctypes.c_void_p(frames.data_ptr()), nb, nt, int(rows[0]), int(rows[1]),
+                                                              ctypes.c_void_p(out.data_ptr()),
+                                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            return out
         out = torch.empty((nb, nt), dtype=torch.float32, device=frames.device)
         _lib.check(self.eng.lib.svc_transnet_predict(self.eng._h, ctypes.c_void_p(frames.data_ptr()), nb, nt,
                                                      ctypes.c_void_p(out.data_ptr()),
@@ -115,7 +129,7 @@ class ShotTransNet:
         out = torch.zeros(len(wi_all) * 50, dtype=torch.float32, device=dev)
         for i in range(0, len(wi), self.windows_per_call):
             win = t[wi[i:i + self.windows_per_call].reshape(-1)].reshape(-1, 100, *t.shape[1:]).contiguous()
-            res = self.predict_raw_device(win)[:, 25:75].reshape(-1)
+            res = self.predict_raw_device(win, rows=(25, 75))[:, 25:75].reshape(-1)       # the reference keeps the middle 50 (:117-121)
             out[50 * (k0 + i):50 * (k0 + i) + res.numel()] = res
         return out[:n].cpu().numpy()
 

@@ -348,7 +348,8 @@ def test_threshold_regime_diagnostic(engine, tmp_path):
     """Round-4 verdict, "Next round" 6: the user can tell which regime a checkpoint lives in.  svc_threshold_census counts the
     pixels of the UN-thresholded maps at t - 1 / t / t + 1 inside the fused threshold entry; smart_crop_results carries the
     mean per map and level (`pixels_per_grey_level_at_threshold`), the single-video path from the raw maps, the packed job
-    from its lane engines' census; write_results puts it into <vid>_info.txt (a line without '%': the evaluator skips it)."""
+    from the per-frame rows the network's last kernel counts (svc_saliency_census_u8: the VIDEO's own figure, whatever shares
+    its lane); write_results puts it into <vid>_info.txt (a line without '%': the evaluator skips it)."""
     fr = torch.from_numpy(synth.blob_frames(9, 140, 250, seed=5)).cuda()
     raw = engine.saliency(fr).cpu().numpy().astype(int)
     engine.threshold_census(reset=True)
@@ -365,8 +366,18 @@ def test_threshold_regime_diagnostic(engine, tmp_path):
     VD, res = S.smart_vid_crop(video, dict(CP, out_ratio='1:3'), save_vid=False, engine=engine)
     ppl = res['pixels_per_grey_level_at_threshold']
     assert ppl is not None and 0 < ppl < 2000
-    job = S.crop_videos([video], CP, ('1:3',), workers=1)
-    assert abs(job[0]['1:3'][1]['pixels_per_grey_level_at_threshold'] - ppl) <= 0.011     # one video on one lane: the same maps
+    # per-frame rows: what the caller's rows receive is the census of each frame's raw map (added: the caller zeroes)
+    rows = torch.zeros((9, 4), dtype=torch.int32, device='cuda')
+    engine.saliency(fr, threshold=120, census=rows)
+    engine.saliency(fr[:4], threshold=120, census=rows[:4])
+    want = np.stack([[(m == 119).sum(), (m == 120).sum(), (m == 121).sum(), 0] for m in raw])
+    want[:4] *= 2
+    assert np.array_equal(rows.cpu().numpy(), want)
+    other = _video(45, 12, [0, 45])                                 # a second video sharing the lane: each reports ITS OWN figure
+    ppl2 = S.smart_vid_crop(other, dict(CP, out_ratio='1:3'), save_vid=False, engine=engine)[1]['pixels_per_grey_level_at_threshold']
+    job = S.crop_videos([video, other], CP, ('1:3',), workers=1)
+    assert job[0]['1:3'][1]['pixels_per_grey_level_at_threshold'] == ppl
+    assert job[1]['1:3'][1]['pixels_per_grey_level_at_threshold'] == ppl2 != ppl
     fn = S.write_results(str(tmp_path), 'v', '1:3', VD, res)
     info = open(fn.replace('.txt', '_info.txt')).read()
     assert 'pixels_per_grey_level_at_threshold:%s' % ppl in info

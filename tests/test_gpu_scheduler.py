@@ -22,6 +22,8 @@ def _same(a, b, ratios=('1:3', '3:1'), maps=True):
         assert va['dx'] == vb['dx'] and va['dy'] == vb['dy']
         assert va['dxs_smooth'] == vb['dxs_smooth'] and va['dxi'] == vb['dxi']
         assert a[r][1]['info'] == b[r][1]['info'] and a[r][1]['params'] == b[r][1]['params']
+        # the regime diagnostic is the VIDEO's own in the packed job too (round-5 advisor: it was the lane's job-wide mean)
+        assert a[r][1]['pixels_per_grey_level_at_threshold'] == b[r][1]['pixels_per_grey_level_at_threshold']
     if maps:
         assert torch.equal(a[ratios[0]][0]['smaps_dev'], b[ratios[0]][0]['smaps_dev'])
         assert np.array_equal(a[ratios[0]][0]['smaps'], b[ratios[0]][0]['smaps'])

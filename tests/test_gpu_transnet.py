@@ -121,6 +121,125 @@ def test_more_windows_than_one_pass_holds(net):
     assert np.abs(whole[[0, 16]] - R.forward(sd, fr[[0, 16]])).max() <= TOL
 
 
+def test_kept_rows_only_every_layer_on_the_frames_they_depend_on(net):
+    """svc_transnet_predict_rows: the caller keeps rows a .. b - 1 of every window (predict_video: the middle 50 of 100,
+    transnetv1_handler.py:117-121); a cell reaches 8 frames to either side, so the last four cells run on 50 / 66 / 82 / 98 of the
+    100 frames.  The kept rows are BIT FOR BIT those of the full pass -- on both MFMA shapes, both split-bf16 pipes, any row range,
+    window lengths other than 100, more windows than one pass holds -- and predict_video is unchanged against the oracle."""
+    import os
+    n, sd = net
+    fr = torch.from_numpy(np.stack([_frames(100, 300 + k, smooth=(k % 2 == 0)) for k in range(3)])).cuda()
+    for knobs in ({}, {'SVC_SHOT_M16': '0'}, {'SVC_SHOT_M16': '0', 'SVC_SHOT_PT': '1'}, {'SVC_SHOT_MX': 'bf16x3'}, {'SVC_SHOT_MX': 'f32'}):
+        old = {k: os.environ.get(k) for k in knobs}
+        os.environ.update(knobs)
+        try:
+            other = Hd.ShotTransNet(Hd.ShotTransNetParams(), weights=sd)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        try:
+            full = other.predict_raw_device(fr)
+            for a, b in ((25, 75), (0, 100), (0, 1), (99, 100), (3, 12), (40, 97), (10, 11)):
+                part = other.predict_raw_device(fr, rows=(a, b))
+                assert torch.equal(part[:, a:b], full[:, a:b]), (knobs, a, b)
+            short = fr[:, :37].contiguous()                              # another window length: 37 frames
+            assert torch.equal(other.predict_raw_device(short, rows=(5, 30))[:, 5:30], other.predict_raw_device(short)[:, 5:30])
+        finally:
+            other.close()
+    many = torch.from_numpy(np.stack([_frames(100, 400 + k) for k in range(17)])).cuda()      # two passes of the workspace
+    assert torch.equal(n.predict_raw_device(many, rows=(25, 75))[:, 25:75], n.predict_raw_device(many)[:, 25:75])
+    import ctypes
+    out = torch.empty((3, 100), dtype=torch.float32, device='cuda')
+    for a, b in ((-1, 50), (50, 50), (60, 40), (0, 101)):
+        assert n.eng.lib.svc_transnet_predict_rows(n.eng._h, ctypes.c_void_p(fr.data_ptr()), 3, 100, a, b, ctypes.c_void_p(out.data_ptr()), None) < 0
+
+
+def test_clone_copies_the_knobs_handle_to_handle_and_unknown_pipes_are_rejected(net):
+    """ShotTransNet.clone(): same weights, matrix pipe and kernel knobs on an engine of its own, copied with svc_transnet_config_get /
+    _set -- the process environment is neither read nor written; svc_create rejects a misspelt SVC_MX / SVC_SHOT_MX (it used to select
+    the fp32 pipe silently) and svc_transnet_config_set a configuration that does not exist."""
+    import ctypes, os
+    n, sd = net
+    env = {k: os.environ.get(k) for k in ('SVC_SHOT_MX', 'SVC_SHOT_M16', 'SVC_SHOT_PT', 'SVC_SHOT_FORM')}
+    os.environ.update(SVC_SHOT_MX='bf16x3', SVC_SHOT_M16='4', SVC_SHOT_PT='1')
+    try:
+        a = Hd.ShotTransNet(Hd.ShotTransNetParams(), weights=sd)
+    finally:
+        for k, v in env.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    try:
+        assert a.config() == [3, 4, 1, 1, 2] and a.matrix_pipe() == 'bf16x3'
+        before = dict(os.environ)
+        c = a.clone()                                                  # the environment now says "defaults": the clone must not follow it
+        try:
+            assert dict(os.environ) == before
+            assert c.config() == a.config() and c.matrix_pipe() == 'bf16x3' and c.eng is not a.eng
+            fr = np.stack([_frames(100, 501)])
+            assert np.array_equal(c.predict_raw(fr), a.predict_raw(fr))
+        finally:
+            c.close()
+        d = n.clone()                                                  # "follow SVC_MX" is pinned to what the original resolved it to
+        try:
+            assert d.config()[0] == 6 and d.config()[1:] == n.config()[1:]
+        finally:
+            d.close()
+        bad = (ctypes.c_int32 * 5)(5, 3, 2, 1, 2)
+        assert a.eng.lib.svc_transnet_config_set(a.eng._h, bad) < 0 and a.config() == [3, 4, 1, 1, 2]
+    finally:
+        a.close()
+    for var, val in (('SVC_MX', 'bf16'), ('SVC_MX', 'bf16x9'), ('SVC_SHOT_MX', '1'), ('SVC_SHOT_MX', 'fp32')):
+        old = os.environ.get(var)
+        os.environ[var] = val
+        try:
+            with pytest.raises(Exception, match=var):
+                ops.Engine(seed=0)
+        finally:
+            os.environ.pop(var, None) if old is None else os.environ.__setitem__(var, old)
+
+
+def test_the_planners_stay_a_bounded_number_of_videos_ahead_of_the_lanes(net):
+    """Back-pressure (round-5 advisor): with shot_net= the planner threads build the on-demand videos and run shot detection AHEAD of
+    the lanes; they are three to four times faster than the lanes, so unbounded they would materialise the whole job.  A video is
+    built only when the feeder is within plan_ahead videos of it; a shot network on a SHARED engine is cloned for every planner."""
+    from retargetvid_amd import smartVidCrop as S, synth, scheduler
+    n, sd = net
+    usd = weights.make_synthetic_state_dict(0)
+    CP = dict(S.sc_init_crop_params(), read_batch=64, hdbscan_min=5)
+    base = []
+    for k in range(3):
+        frames = synth.blob_frames(50 + 10 * k, 90, 160, seed=60 + k)
+        frames[30:] = frames[30:][:, ::-1]
+        base.append(dict(fr=25.0, frame_count=len(frames), w=160, h=90, frames=frames))
+    js = scheduler.JobScheduler(CP, ('1:3',), lanes=1, state_dict=usd, shot_net=n, plan_ahead=2)
+    ahead = []
+
+    def make(i):
+        def f():
+            ahead.append(i - js.next_idx + 1)                           # videos built beyond the feeder's, this one included
+            return base[i % 3]
+        return f
+    try:
+        out = js.run([make(i) for i in range(24)])
+        assert len(out) == 24 and len(ahead) == 24 and max(ahead) <= 2, ahead
+        assert js.stats['plan_ahead'] == 2 and 1 <= js.stats['plan_high_water'] <= 2 and js.stats['planners'] == 3
+        for i in range(3, 24):
+            assert out[i]['1:3'][0]['bbs'] == out[i % 3]['1:3'][0]['bbs']
+        assert js._plan_nets[0] is n                                    # n owns its engine: planner 0 runs it, the others run clones
+    finally:
+        js.close()
+    shared = Hd.ShotTransNet(Hd.ShotTransNetParams(), weights=sd, engine=n.eng)      # a network on somebody else's engine
+    js = scheduler.JobScheduler(CP, ('1:3',), lanes=2, state_dict=usd, shot_net=shared)
+    try:
+        ref = js.run(base)
+        assert len(js._plan_nets) == 3 and all(p is not shared and p.eng is not n.eng for p in js._plan_nets)
+        assert js.plan_ahead == 2 + 2 * 3                               # the default: lanes + 2 per planner
+        for a, b in zip(ref, out[:3]):
+            assert a['1:3'][0]['bbs'] == b['1:3'][0]['bbs']
+    finally:
+        js.close()
+        shared.close()
+
+
 def test_errors():
     eng = ops.Engine(seed=0)
     try:

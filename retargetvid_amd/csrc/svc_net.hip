@@ -685,7 +685,7 @@ struct UpsAdd {
 // TR = true: the MFMA operands are swapped (weights as A, activations as B), so a lane ends up with ONE pixel and
 // 16 output channels in runs of four -- the epilogue then moves float4 (4 stores per tile instead of 16).
 template <int TN, int PF, bool TR = false>
-__global__ __launch_bounds__(256) void k_pw(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
+__global__ __launch_bounds__(256) SVC_NO_PK void k_pw(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
                                             const float *__restrict__ bias, const float *__restrict__ R, int ldr,
                                             float *__restrict__ Y, int ldy, int M, int N, int Npad, int K,
                                             int relu6, UpsAdd ups) {
@@ -1366,7 +1366,7 @@ __global__ __launch_bounds__(256) void k_gauss_fill(const float *__restrict__ G,
 }
 
 // bilinear x2 (align_corners=False): X[n][H][W][C] -> Y[n][2H][2W][ldy] channels 0..C-1
-__global__ __launch_bounds__(256) void k_upsample2x(const float *__restrict__ X, float *__restrict__ Y, int n,
+__global__ __launch_bounds__(256) SVC_NO_PK void k_upsample2x(const float *__restrict__ X, float *__restrict__ Y, int n,
                                                     int H, int W, int C, int ldy, FDiv dC4, FDiv dOW, FDiv dOH) {
     const int C4 = C >> 2, OH = 2 * H, OW = 2 * W;
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
@@ -1480,7 +1480,7 @@ extern "C" int svc_debug_sd_log(unsigned *count4, float *rec64x16) {
     return 0;
 }
 #endif
-__global__ __launch_bounds__(256) void k_smooth_down_mfma(const float *__restrict__ logit, const float *__restrict__ phase,
+__global__ __launch_bounds__(256) SVC_NO_PK void k_smooth_down_mfma(const float *__restrict__ logit, const float *__restrict__ phase,
                                                           float *__restrict__ pre, unsigned *__restrict__ fmax, int LH,
                                                           int LW, int NH, int NW, int h, int w, int rows_per_block,
                                                           int tile_cap, FDiv dw) {
@@ -1590,7 +1590,7 @@ __global__ __launch_bounds__(256) void k_smooth_down_mfma(const float *__restric
     if (tid == 0) atomicMax(fmax + f, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
 }
 
-__global__ __launch_bounds__(256) void k_smooth_down(const float *__restrict__ logit, const float *__restrict__ phase,
+__global__ __launch_bounds__(256) SVC_NO_PK void k_smooth_down(const float *__restrict__ logit, const float *__restrict__ phase,
                                                      float *__restrict__ pre, unsigned *__restrict__ fmax, int LH,
                                                      int LW, int NH, int NW, int h, int w, int rows_per_block,
                                                      int tile_cap, FDiv dNW, FDiv dw) {

@@ -52,3 +52,24 @@ def test_path_hierarchy_equals_the_oracles_labels():
         left, right, weight, csize = H.single_linkage(u, v, w, order)
         ref = H.select_and_label(H.condense_tree(left, right, weight, csize, mcs), n)
         assert TP.same_partition(ref, TP.labels_path(u, v, w, order, mcs))
+
+
+def test_no_half_swapping_packed_f32_instruction_in_the_library():
+    """Build check (hipcc -S on this box, ~35 s): round 5 found a product LOST in a `v_pk_mul_f32 x2 ; v_pk_add_f32 op_sel:[0,1]
+    op_sel_hi:[1,0]` sequence of the smoothing kernel when bf16-MFMA workgroups shared its CU (profiles/r05_mx_reproducibility.txt).
+    The trigger is not fully understood, so the form is kept out of the library: no kernel may contain a packed f32 instruction that
+    routes the halves of an operand crosswise, and the two smoothing kernels none at all (tools/packed_f32_census.py; kernels whose C
+    code the compiler packs that way carry SVC_NO_PK).  The detector itself is checked on a two-line kernel that compiles to the form."""
+    import subprocess
+    import tempfile
+    tool = os.path.join(ROOT, 'tools', 'packed_f32_census.py')
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'svc_net.hip' in r.stdout and 'svc_shot.hip' in r.stdout and 'FAIL' not in r.stdout
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, 'swap.hip')
+        with open(src, 'w') as f:
+            f.write('#include <hip/hip_runtime.h>\n__global__ void k(const float2* a, const float2* b, float2* c) { int i = threadIdx.x; '
+                    'float2 x = a[i], y = b[i], z; z.x = x.x * y.x + x.y; z.y = x.y * y.y + x.x; c[i] = z; }\n')
+        r = subprocess.run([sys.executable, tool, src], capture_output=True, text=True)
+        assert r.returncode == 1 and 'half-swapping' in r.stdout, r.stdout + r.stderr

@@ -1,13 +1,16 @@
 """Run-to-run reproducibility of the NETWORK with several passes sharing the chip: N engines on N streams push the same 32 frames
 ITERS times; every pass's maps (and, on a mismatch, the taps of the differing frame) are compared with a single-stream reference.
-python tools/soak_network_concurrent.py [N] [ITERS]    (GPU box; SVC_MX / SVC_MX_MASK select the matrix pipe)"""
+python tools/soak_network_concurrent.py [N] [ITERS]    (GPU box; SVC_MX / SVC_MX_MASK select the matrix pipe)
+GEOM=HxW: maps of another geometry (187x250 = 4:3 sources, 250x140 = portrait; default 140x250) -- the taps of a differing frame are
+then not printed (their shapes belong to the 16:9 network input), the count of differing passes is."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from retargetvid_amd import ops, synth, scheduler
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-fr = torch.from_numpy(synth.blob_frames(32, 140, 250, seed=0)).cuda()
+GH, GW = [int(v) for v in os.environ.get('GEOM', '140x250').split('x')]
+fr = torch.from_numpy(synth.blob_frames(32, GH, GW, seed=0)).cuda()
 TAPS = [('feat4x', ops.TAP_FEAT4X, (32, 52, 64)), ('feat2x', ops.TAP_FEAT2X, (16, 26, 160)), ('feat1x', ops.TAP_FEAT1X, (8, 13, 1296)),
         ('postcnn', ops.TAP_POSTCNN, (8, 13, 256)), ('dec', ops.TAP_DEC, (32, 52, 64)), ('pre', ops.TAP_PRE, (140, 250))]
 engs = [ops.Engine(seed=0) for _ in range(N)]
@@ -21,7 +24,7 @@ if BURN:
     bstreams = [torch.cuda.Stream() for _ in range(2)]
 sts = scheduler.lane_streams(torch.device('cuda', 0), N)
 ref = engs[0].saliency(fr).clone()
-reft = {f: [engs[0].tap(w, f, sh) for _, w, sh in TAPS] for f in range(32)}
+reft = {f: [engs[0].tap(w, f, sh) for _, w, sh in TAPS] for f in range(32)} if (GH, GW) == (140, 250) else None
 outs = [torch.empty_like(ref) for _ in range(N)]
 # VICTIM=k: beside every pass, k launches of a stand-in for the smoothing kernel (tools/micro/victim.hip: pure function of block and
 # thread) on a stream of its own; the words that differ from its lone reference run are counted
@@ -65,6 +68,9 @@ for it in range(ITERS):
     for i in range(N):
         if not torch.equal(outs[i], ref):
             bad += 1
+            if reft is None:
+                print('iter %d engine %d: %d pixels differ' % (it, i, int((outs[i] != ref).sum())), flush=True)
+                continue
             d = (outs[i] != ref)
             frames = torch.nonzero(d.flatten(1).any(1)).flatten().tolist()
             msg = []

@@ -40,6 +40,8 @@ Rank 0 prints ONE JSON line.  `roofline` describes the kernel class that takes t
                            traffic_source; not re-measured by this run)
 `cpu_baseline` is the oracle (CPU restatement of the same path) timed on this node's host cores on a bounded
 sample of the same workload.
+`cpu_baseline.network_under_pytorch_rocm` (BENCH_TORCH_BASELINE=0 skips it): the NETWORK alone the way the reference runs it -- eager
+PyTorch modules, here under PyTorch-ROCm (MIOpen / rocBLAS) -- on this GPU, forward only: a second reported baseline, same rules.
 `config.config3` (BENCH_CONFIG3=0 skips it) is BASELINE.json's configs[2] run ONCE MORE OUTSIDE the timed region through the
 product's job code: the 200-video RetargetVid-shaped synthetic set (real frame counts, 1:3 and 3:1), videos sharded over the
 ranks (dist.crop_job), every rank's share through the job-level scheduler (retargetvid_amd/scheduler.py: frames of
@@ -172,6 +174,42 @@ def cpu_baseline(sd, frames_u8, CP, flags):
     host_boxes([(np.nan, np.nan) if x is None else (x, y) for x, y in zip(dx, dy)])
     dt = time.perf_counter() - t0
     return n / dt, dt
+
+
+def reference_formulation_on_gpu(sd, dev, batch, iters=10):
+    """Part of the baseline leg: the NETWORK the way the reference runs it -- eager PyTorch modules (train.py:778-859, model.py:411-506;
+    cuDNN on its hardware, MIOpen / rocBLAS under PyTorch-ROCm) -- on THIS GPU: oracle/unisal_ref.forward_logits (F.conv2d / F.batch_norm /
+    F.interpolate, BatchNorm not folded, NCHW fp32) on `batch` frames of 256 x 416, forward only (no LANCZOS, no quantisation, no tail:
+    those run on the CPU in the reference).  A reported baseline beside cpu_baseline, never the thing shipped; tools/torch_rocm_baseline.py
+    is the stand-alone form."""
+    from oracle import unisal_ref as U
+    sd_dev = {k: (v if torch.is_tensor(v) else torch.as_tensor(v)).to(dev) for k, v in sd.items()}
+    orig = U.gaussian_maps
+    U.gaussian_maps = lambda g, h, w, scaling=6.0: orig(g.cpu(), h, w, scaling).to(dev)
+    try:
+        x = torch.randn(batch, 3, 256, 416, device=dev)
+        t = time.perf_counter()
+        U.forward_logits(sd_dev, x, (140, 250))
+        torch.cuda.synchronize()
+        first = time.perf_counter() - t
+        for _ in range(2):
+            U.forward_logits(sd_dev, x, (140, 250))
+        ts = []
+        for _ in range(iters):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            U.forward_logits(sd_dev, x, (140, 250))
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t)
+        ts.sort()
+        med = ts[len(ts) // 2]
+        return dict(value=round(batch / med, 1), unit='frames/s', ms_per_pass=round(med * 1e3, 3), first_pass_s=round(first, 2),
+                    what='the reference\'s formulation of the network (eager PyTorch-ROCm: MIOpen / rocBLAS, fp32 NCHW, BatchNorm not folded), '
+                         'forward only, batch %d x 256 x 416, one pass alone on this GPU; compare with config.one_batch_in_flight and '
+                         'batch_phase_ms_in_the_pipeline.network (which include LANCZOS and the u8 quantisation)' % batch,
+                    torch=torch.__version__)
+    finally:
+        U.gaussian_maps = orig
 
 
 def config3_job(world, rank, dist_on, dev, sd, lanes, rccl_init_s, mode='resident', shot_mx=None):
@@ -720,6 +758,11 @@ def main():
             cpu = dict(value=round(nfr / secs, 3), unit='frames/s', cores=torch.get_num_threads(), host_cpu_count=os.cpu_count(), kind='port',
                        sample='%d steps of the same workload (%d frames), oracle/ (PyTorch-CPU fp32 forward at batch 1, '
                               'NumPy tail), %.1f s' % (nb, nfr, secs))
+            if os.environ.get('BENCH_TORCH_BASELINE', '1') != '0':  # the reference's own way of running the network, on this GPU
+                try:
+                    cpu['network_under_pytorch_rocm'] = reference_formulation_on_gpu(sd, dev, B)
+                except Exception as e:                              # (MIOpen needs a writable cache directory: a baseline must not fail the bench)
+                    cpu['network_under_pytorch_rocm'] = dict(error='%s: %s' % (type(e).__name__, str(e)[:200]))
         value = world * B * args.steps / dt
         tail_classes = {k: round(per_class[k][0], 4) for k in ('compact', 'core', 'prim', 'finish')}
         roof['tail'] = dict(total_ms=round(sum(tail_classes.values()), 4), prim_ms=tail_classes['prim'], finish_ms=tail_classes['finish'], core_ms=tail_classes['core'],

@@ -805,6 +805,10 @@ def crop_videos(videos, CP, ratios=None, workers=12, state_dict=None, seed=0, st
     retargetvid_amd/scheduler.py -- ``workers`` lanes (engine + HIP stream), the selected frames of consecutive videos
     packed into full network chunks across video boundaries, one tail round per chunk, host stages on a thread pool;
     ``stats`` (a dict) receives the run's counters.  packed=False: the round-3 form described next.
+    ``videos`` may be zero-argument CALLABLES (videos built on demand).  Without ``shot_net`` the feeder thread calls them one at a
+    time as lanes take them; WITH ``shot_net`` the scheduler's planner threads call them -- up to three concurrently, on threads of
+    their own, with a planner's HIP stream current: such callables must be thread-safe -- and at most ``lanes + 2 per planner``
+    videos are materialised ahead of the lanes (scheduler.JobScheduler(plan_ahead=)), however long the job is.
 
     ``workers`` videos in flight, one per worker thread: every worker thread owns an engine
     (weights + workspace) and a HIP stream and runs smart_vid_crop_ratios on its share, so the

@@ -247,13 +247,12 @@ int svc_transnet_predict(SvcHandle *h, const uint8_t *frames, int n_windows, int
  * 0 <= row0 < row1 <= frames_per_window. */
 int svc_transnet_predict_rows(SvcHandle *h, const uint8_t *frames, int n_windows, int frames_per_window, int row0, int row1,
                               float *probs, void *stream);
-/* The handle's TransNet knobs as five int32: {matrix pipe: -1 = the handle's SVC_MX | 0 fp32 | 6 bf16x6 | 3 bf16x3, 16-position
- * tiles per wavefront of the 16x16x32 kernel (0 = the 32x32x16 kernel), 32-position tiles of that kernel (1 | 2), XCD-aware tile
- * order (0 | 1), fp32 form (0..2)} -- read from SVC_SHOT_* when the handle is created; ShotTransNet.clone() copies them to the
- * engine of the copy with these two calls instead of going through the process environment.  _set rejects values that are not
- * a configuration with SVC_E_INVALID. */
-int svc_transnet_config_get(const SvcHandle *h, int32_t *cfg5);
-int svc_transnet_config_set(SvcHandle *h, const int32_t *cfg5);
+/* The handle's TransNet knobs as three int32: {matrix pipe: -1 = the handle's SVC_MX | 0 fp32 | 6 bf16x6 | 3 bf16x3, 16-position
+ * tiles per wavefront of the split-bf16 cell kernel (2..4), XCD-aware tile order (0 | 1)} -- read from SVC_SHOT_MX / SVC_SHOT_M16 /
+ * SVC_SHOT_XCD when the handle is created; ShotTransNet.clone() copies them to the engine of the copy with these two calls instead of
+ * going through the process environment.  _set rejects values that are not a configuration with SVC_E_INVALID. */
+int svc_transnet_config_get(const SvcHandle *h, int32_t *cfg3);
+int svc_transnet_config_set(SvcHandle *h, const int32_t *cfg3);
 
 /* Test/diagnostic door: copy an intermediate activation of the LAST svc_saliency_u8
  * call (NHWC fp32, frame 0..n-1) to a HOST buffer.  `which` is one of the SVC_TAP_*

@@ -133,7 +133,6 @@ struct SvcHandle {
     std::map<std::tuple<const void *, int, int, int>, DevBuf> lane_w;   // split-K layers' weights in lane order (svc_net.hip: lane_weights), keyed by (matrix, row stride, K, padded N)
     std::map<std::tuple<const void *, int, int, int>, DevBuf> x3_w;     // split-bf16 copies of weight matrices (svc_net.hip: x3_weights), keyed by (matrix, row stride, K, 2 * padded N + order)
     int mx = 6;                        // matrix pipe of the 1x1-convolution GEMMs: 6 = split-bf16 operands, six plane pairs on v_mfma_f32_32x32x16_bf16 (round 5, the default: a pass 1.42 -> 1.24 ms alone, 1.01 -> 0.87 ms with four passes sharing the chip, every parity gate unchanged); 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, rounds 1-4: SVC_MX=f32).  The one kernel found to miscompute beside bf16 workgroups, the smoothing kernel, lost a product in a packed-instruction sequence of its bilinear stage: written with scalar instructions since (sd_bilinear)
-    int sd_excl = 0;                   // 1: k_smooth_down_mfma alone on its CU (an LDS request nothing fits beside): the containment used before sd_bilinear, kept for A/B runs (SVC_SD_EXCL)
     unsigned irb_mx = 0x1b;            // ... which of k_irb's five fixed-shape instances take that form for their expand GEMM (bit = block 2, 3, 4, 5-6, 7; SVC_IRB_MX).  Measured per instance against the fp32 form, us per pass alone / shared: -17 / -11, -12 / -7, +11 / +11 (block 4: Cin = 24 pads its second step, two halo tiles per wave: 36 spilled registers), -11 / -4, -10 / -6: block 4 stays fp32
     unsigned mx_mask = 0xff;           // ... and which kernel families: bit 0 k_pwr, 1 k_irb, 2 k_dwpw, 3 k_pw_sk, 4 k_pwpw (SVC_MX_MASK; for A/B timing)
     bool sk_lane = true;               // k_pw_sk reads its weights from the lane-order copy: a wave's load is 1 KB contiguous instead of 32 rows x 32 B (SVC_SK_LANE=0: from the [N][K] matrix)
@@ -155,7 +154,6 @@ struct SvcHandle {
     bool irb_fixed = true;             // fused blocks of the six MobileNetV2 shapes run compile-time-shaped instances (SVC_IRB_FIXED=0: generic)
     DevBuf stem_wt;                    // stem weights transposed to [32 out][32 taps, 27 used] for the MFMA stem
     int smooth_mfma = 1;               // 41x41 smoothing phases as a GEMM on the matrix cores (SVC_SMOOTH_MFMA=0: the FMA kernel)
-    int stem_mfma = 1;                 // features.0 as MFMA im2col tiles (SVC_STEM_MFMA=0: the FMA kernel k_stem)
     bool front = true;                 // LANCZOS + features.0 + features.1 as one kernel, k_front (SVC_FRONT=0: three kernels)
     bool keep_input = false;           // ... which then also writes the normalised network input for svc_debug_tap(SVC_TAP_INPUT) (SVC_KEEP_INPUT=1)
     bool dwpw = true;                  // depthwise 3x3 fused into the following 1x1 project (SVC_DWPW=0: two kernels)
@@ -166,7 +164,6 @@ struct SvcHandle {
     int dwpw_min_px = 400;             // ... on levels with at least this many pixels per frame (SVC_DWPW_MIN_PX); svc_create sets 100 with the split-bf16 pipe (the fused kernel then wins on the 8x13 level too: -18 us per shared pass), 400 is the fp32 pipe's optimum
     int dw_tile = 42;                  // stride-1 depthwise: outputs per thread as TX*10+TY (SVC_DW_TILE: 21, 22, 41, 42, 44; 0 = one output per thread)
     int prim_pt = 2;                   // legacy Prim (k_prim_pt): smallest points-per-thread variant (SVC_PRIM_PT: 2, 4, 8, 16)
-    int tail_prio = 0;                 // SVC_TAIL_PRIO=1: s_setprio 3 in k_tail_front / k_tail_back (measured: no effect on the pipelined bench or config 3)
     int tail_merge = 1;                // a round's kernels as two fused launches, k_tail_front / k_tail_back (SVC_TAIL_MERGE=0: one launch per stage, for per-kernel profiles)
     int tree_par = 1;                  // data-parallel hierarchy k_tree_par for maps of up to 4352 points (SVC_TREE_PAR=0: the serial builder k_tree)
     int prim_lvl = 1;                  // level-bucketed Prim k_prim_lvl for maps of up to 8192 points (SVC_PRIM_LVL=0: one node per step)
@@ -174,11 +171,9 @@ struct SvcHandle {
     DevBuf shot_blob, shot_ws, shot_w3;   // shot_w3: split-bf16 copies of the cells' weights (svc_shot.hip), valid for shot_w3_mx
     int shot_w3_mx = 0;
     int shot_mx = -1;                  // TransNet cells' matrix pipe: -1 = follow mx, 0 = fp32, 6 = bf16x6, 3 = bf16x3 (SVC_SHOT_MX)
-    int shot_pt = 2;                   // 32-position tiles per wavefront of k_shot_conv_x3 (SVC_SHOT_PT: 1 | 2)
-    int shot_m16 = 3;                  // > 0: the cells with >= 64 input channels on v_mfma_f32_16x16x32_bf16 (k_shot_conv_x3m), value = 16-position tiles per wavefront (2, 3, 4); 0: on 32x32x16 (k_shot_conv_x3) (SVC_SHOT_M16)
-    int shot_xcd = 1;                  // XCD-aware tile order of k_shot_conv_x3 (SVC_SHOT_XCD)
+    int shot_m16 = 3;                  // 16-position tiles per wavefront of the split-bf16 cell kernel k_shot_conv_x3m (SVC_SHOT_M16: 2, 3, 4; one more where a wave holds one filter tile)
+    int shot_xcd = 1;                  // XCD-aware tile order of k_shot_conv_x3m / k_shot_first_x3 (SVC_SHOT_XCD)
     bool shot_loaded = false;
-    int shot_form = 2;                 // TransNet convolution cells: 0 = operands straight from global memory (k_shot_conv), 1 = weights through LDS, 2 = both operands through LDS with whole-line loads (SVC_SHOT_FORM)
     // per-kernel-class event log (svc_profile_*)
     int prof_class = -1;
     hipStream_t prof_cal_stream = nullptr;      // a stream of the handle's own for the empty-event-pair calibration of svc_profile_read

@@ -264,53 +264,6 @@ static void lanczos_tab(int in_size, int out_size, std::vector<int> &bounds, std
     }
 }
 
-// --------------------------------------------------------------------------------------
-// stem: 3x3 stride 2 pad 1, 3 -> 32, +bias, ReLU6.  One thread = one pixel x 4 channels.
-// w layout [ky][kx][ci][co]
-// --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stem(const float *__restrict__ X, const float *__restrict__ Wt,
-                                              const float *__restrict__ bias, float *__restrict__ Y, int n,
-                                              int H, int W, int OH, int OW, FDiv dOW, FDiv dOH) {
-    __shared__ float ws[27 * 32 + 32];
-    for (int i = threadIdx.x; i < 27 * 32; i += 256) ws[i] = Wt[i];
-    if (threadIdx.x < 32) ws[27 * 32 + threadIdx.x] = bias[threadIdx.x];
-    __syncthreads();
-    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    size_t total = (size_t)n * OH * OW * 8;
-    if (gid >= total) return;
-    int c4 = gid & 7;
-    uint32_t ox, oy;
-    const uint32_t f = fdivmod(fdivmod((uint32_t)(gid >> 3), dOW, ox), dOH, oy);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float *xf = X + (size_t)f * H * W * 3;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        int iy = 2 * oy - 1 + ky;
-        if (iy < 0 || iy >= H) continue;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            int ix = 2 * ox - 1 + kx;
-            if (ix < 0 || ix >= W) continue;
-            const float *px = xf + ((size_t)iy * W + ix) * 3;
-#pragma unroll
-            for (int ci = 0; ci < 3; ++ci) {
-                float v = px[ci];
-                const float *wp = ws + ((ky * 3 + kx) * 3 + ci) * 32 + c4 * 4;
-                acc.x = fmaf(v, wp[0], acc.x);
-                acc.y = fmaf(v, wp[1], acc.y);
-                acc.z = fmaf(v, wp[2], acc.z);
-                acc.w = fmaf(v, wp[3], acc.w);
-            }
-        }
-    }
-    const float *b = ws + 27 * 32 + c4 * 4;
-    acc.x = fminf(fmaxf(acc.x + b[0], 0.f), 6.f);
-    acc.y = fminf(fmaxf(acc.y + b[1], 0.f), 6.f);
-    acc.z = fminf(fmaxf(acc.z + b[2], 0.f), 6.f);
-    acc.w = fminf(fmaxf(acc.w + b[3], 0.f), 6.f);
-    *(float4 *)(Y + gid * 4) = acc;
-}
-
 // features.0 on the matrix cores: one workgroup = 8 x 16 output pixels.  The 17 x 33 x 3 input patch is read once
 // (whole rows, coalesced) into LDS; every lane owns one output pixel and gathers its 27 taps (K padded to 32) from
 // the patch as the B operand of sixteen 32x32x2 MFMAs against the transposed weights (A operand, four float4 per
@@ -3079,7 +3032,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     float *IN = p->buf(B_IN), *P[2] = {p->buf(B_P0), p->buf(B_P1)}, *E0 = p->buf(B_E0), *E1 = p->buf(B_E1);
     // the front of the network (LANCZOS, features.0, features.1) as one kernel where a tile's resampling arrays fit in LDS
     const int fr_lds = front_lds_bytes();
-    const bool front = h->front && h->stem_mfma && h->fuse_max >= 1 && p->fr_ok;
+    const bool front = h->front && h->fuse_max >= 1 && p->fr_ok;
     p->last_front = front;
     h->seg_cur = 0;
     auto seg_on = [&]() { return !(h->seg_off >> h->seg_cur & 1u); };   // SVC_SEG_OFF (measurement aid): see svc_internal.h
@@ -3097,14 +3050,9 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     const SvcLayer &Lstem = next();
     if (!front && seg_on()) {
         ProfScope ps(h, SVC_K_STEM, s);
-        if (h->stem_mfma) {
-            const int tx = ceil_div(W, STEM_TW), ty = ceil_div(H, STEM_TH);
-            k_stem_mfma<<<dim3((unsigned)(n * tx * ty)), 256, 0, s>>>(IN, (const float *)h->stem_wt.p, Lstem.b.dev, P[0], NH, NW,
-                                                                     H, W, tx, ty);
-        } else {
-            k_stem<<<blocks256((size_t)n * H * W * 8), 256, 0, s>>>(IN, Lstem.w.dev, Lstem.b.dev, P[0], n, NH, NW, H, W,
-                                                                    make_fdiv(W), make_fdiv(H));
-        }
+        const int tx = ceil_div(W, STEM_TW), ty = ceil_div(H, STEM_TH);
+        k_stem_mfma<<<dim3((unsigned)(n * tx * ty)), 256, 0, s>>>(IN, (const float *)h->stem_wt.p, Lstem.b.dev, P[0], NH, NW,
+                                                                 H, W, tx, ty);
         SVC_CHECK_LAUNCH();
     }
     int cur = 0;
@@ -3280,15 +3228,7 @@ static int forward_chunk(SvcHandle *h, const uint8_t *frames, int n, uint8_t *ma
     {
         dim3 grid(ceil_div(p->h, p->sd_rows), n);
         if (h->smooth_mfma && NW % 8 == 0 && NW == 8 * W3 && NH == 8 * H3) {
-            size_t lds = ((size_t)H3 * W3 + 64 * SD_KP + (size_t)p->sd_tile_cap * NW) * sizeof(float);
-            // SVC_SD_EXCL=1: the kernel alone on its CU (an LDS request nothing fits beside).  That was the containment of the lost
-            // product in its bilinear stage before the stage was rewritten with scalar instructions (sd_bilinear above); off by
-            // default since -- the soaks are clean without it -- and kept as a knob for A/B runs with the -DSD_PACKED build.
-            if (h->sd_excl > 0) {
-                lds = std::max(lds, (size_t)150 * 1024);
-                if (h->lds_attr_done.insert((const void *)k_smooth_down_mfma).second)
-                    SVC_HIP(hipFuncSetAttribute((const void *)k_smooth_down_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-            }
+            const size_t lds = ((size_t)H3 * W3 + 64 * SD_KP + (size_t)p->sd_tile_cap * NW) * sizeof(float);
             if (seg_on()) k_smooth_down_mfma<<<grid, 256, lds, s>>>(p->buf(B_LOGIT), Ls.w.dev, p->buf(B_PRE), (unsigned *)p->fmax.p, H3, W3,
                                                       NH, NW, p->h, p->w, p->sd_rows, p->sd_tile_cap, make_fdiv(p->w));
         } else {
@@ -3481,8 +3421,6 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->irb_fixed = atoi(env) != 0;
     env = getenv("SVC_SMOOTH_MFMA");
     if (env) h->smooth_mfma = atoi(env);
-    env = getenv("SVC_STEM_MFMA");
-    if (env) h->stem_mfma = atoi(env);
     env = getenv("SVC_FRONT");
     if (env) h->front = atoi(env) != 0;
     env = getenv("SVC_KEEP_INPUT");
@@ -3498,8 +3436,6 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
         else { svc_set_error("svc_create: SVC_MX=%s (expected f32 or bf16x6)", env); delete h; return SVC_E_INVALID; }
     }
     if (h->mx && !getenv("SVC_DWPW_MIN_PX")) h->dwpw_min_px = 100;
-    env = getenv("SVC_SD_EXCL");
-    if (env) h->sd_excl = atoi(env);
     env = getenv("SVC_IRB_MX");
     if (env) h->irb_mx = (unsigned)strtoul(env, nullptr, 0);
     env = getenv("SVC_MX_MASK");
@@ -3514,8 +3450,6 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
     if (env) h->dwpw_max_nt = atoi(env);
     env = getenv("SVC_DW_TILE");
     if (env) h->dw_tile = atoi(env);
-    env = getenv("SVC_SHOT_FORM");
-    if (env) h->shot_form = atoi(env);
     env = getenv("SVC_SHOT_MX");
     if (env) {
         if (!strcmp(env, "bf16x6") || !strcmp(env, "6")) h->shot_mx = 6;
@@ -3523,16 +3457,12 @@ extern "C" int svc_create(const void *blob_host, size_t n_bytes, int device, Svc
         else if (!strcmp(env, "f32") || !strcmp(env, "0")) h->shot_mx = 0;
         else { svc_set_error("svc_create: SVC_SHOT_MX=%s (expected f32, bf16x6 or bf16x3)", env); delete h; return SVC_E_INVALID; }
     }
-    env = getenv("SVC_SHOT_PT");
-    if (env) h->shot_pt = atoi(env) == 1 ? 1 : 2;
     env = getenv("SVC_SHOT_M16");
-    if (env) { const int v = atoi(env); h->shot_m16 = v >= 2 && v <= 4 ? v : 0; }
+    if (env) { const int v = atoi(env); if (v >= 2 && v <= 4) h->shot_m16 = v; }
     env = getenv("SVC_SHOT_XCD");
     if (env) h->shot_xcd = atoi(env) != 0;
     env = getenv("SVC_PRIM_PT");
     if (env && atoi(env) > 0) h->prim_pt = atoi(env);
-    env = getenv("SVC_TAIL_PRIO");
-    if (env) h->tail_prio = atoi(env);
     env = getenv("SVC_TAIL_MERGE");
     if (env) h->tail_merge = atoi(env);
     env = getenv("SVC_TREE_PAR");

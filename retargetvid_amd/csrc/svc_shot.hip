@@ -14,8 +14,11 @@
 //
 // Default since round 5 (SVC_SHOT_MX = SVC_MX = bf16x6): the cells run on v_mfma_f32_32x32x16_bf16 with every f32 operand as
 // three bf16 planes (svc_x3.h) and the activations kept split and planar between the cells -- "split-bf16 activations" below:
-// k_shot_in_x3 -> k_shot_first_x3 -> k_shot_conv_x3 ... k_shot_pool_x3 -> Dense -> k_shot_head.  The fp32 kernels above
-// (k_shot_conv, k_shot_conv_lds, k_shot_conv_lds2*) are SVC_SHOT_MX=f32.
+// k_shot_in_x3 -> k_shot_first_x3 -> k_shot_conv_x3m ... k_shot_pool_x3 -> Dense -> k_shot_head.  The fp32 kernels
+// (k_shot_conv for the first cell and Dense, k_shot_conv_lds2* for the cells) are SVC_SHOT_MX=f32.
+// Round 6 removed the measured losers: the fp32 forms with operands straight from global memory / weights only through LDS
+// (SVC_SHOT_FORM 0 / 1: 19.5 / 17.0 ms per 8 windows against 10.9) and the split-bf16 cells on the 32x32x16 shape (k_shot_conv_x3,
+// SVC_SHOT_M16=0: 89.4 k against 94.1 k video frames/s); DESIGN_HISTORY.md keeps their measurements.
 #include <algorithm>
 
 #include "svc_internal.h"
@@ -117,44 +120,6 @@ __global__ __launch_bounds__(256) void k_shot_conv(const ShotConv A) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
         }
-    } else if (A.C >= 8) {
-        // 27 taps x C / 8 steps.  Measured first: with the operand loads taken out the loop runs at 102 TFLOP/s, with a load
-        // guarded by the tap's bounds test in front of every step's MFMAs at 57 -- the wave waits for each load.  So a tap's
-        // source row is decoded once, the loads are unconditional (an out-of-range tap reads a valid dummy address and is
-        // zeroed by a select: SAME padding), and the next step's operands are requested before this step's MFMAs.
-        const int spt = A.C >> 3;
-        auto tap_ptr = [&](int tap, bool &ok) -> const float * {
-            const int kt = tap / 9, kh = (tap - 9 * kt) / 3, kw = tap - 9 * kt - 3 * kh;
-            const int tt = t + (kt - 1) * d, yy = y + kh - 1, xx = x + kw - 1;
-            ok = (unsigned)tt < (unsigned)A.T && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W;
-            return ok ? A.X + ((((size_t)(frame0 + tt)) * A.H + yy) * A.W + xx) * A.C + 4 * hh : A.X + 4 * hh;
-        };
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool okc, okn = false;
-        const float *pc = tap_ptr(0, okc), *pn = pc;
-        float4 an = *(const float4 *)pc, bn = *(const float4 *)wrow;
-        if (!okc) an = z4;
-        int kk = 0;
-        for (int tap = 0; tap < 27; ++tap) {
-            if (tap + 1 < 27) pn = tap_ptr(tap + 1, okn);
-            for (int st = 0; st < spt; ++st) {
-                const float4 a = an, b = bn;
-                if (st + 1 < spt) {
-                    an = *(const float4 *)(pc + 8 * (st + 1));
-                    if (!okc) an = z4;
-                } else if (tap + 1 < 27) {
-                    an = *(const float4 *)pn;
-                    if (!okn) an = z4;
-                }
-                kk += 8;
-                if (kk < A.kpad) bn = *(const float4 *)(wrow + kk);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
-            }
-            pc = pn; okc = okn;
-        }
     } else {
         for (int kk = 0; kk < A.kpad; kk += 8) {
             const int k0 = kk + 4 * hh, tap = k0 >> A.logC, c0 = k0 & (A.C - 1);
@@ -177,96 +142,6 @@ __global__ __launch_bounds__(256) void k_shot_conv(const ShotConv A) {
         for (int g = 0; g < 4; ++g)
             *(float4 *)(yp + nt * 32 + 8 * g + 4 * hh) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
         return;
-    }
-    if ((long long)blockIdx.x * 128 + wave * 32 + r >= A.M) return;
-    float *yp = A.Y + (size_t)m * A.ldy + br * A.F;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int col = nt * 32 + 8 * g + 4 * hh;
-        if (col >= A.F) continue;
-        const float4 b = *(const float4 *)(A.bias + br * A.F + col);
-        float4 v = make_float4(acc[4 * g] + b.x, acc[4 * g + 1] + b.y, acc[4 * g + 2] + b.z, acc[4 * g + 3] + b.w);
-        if (A.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *(float4 *)(yp + col) = v;
-    }
-}
-
-// The 27-tap cells with C >= 64 input channels: the tap's [32 output channels x C] slice of the weights goes through LDS
-// (double-buffered, fetched with whole-line loads by all four waves, one barrier per tap) instead of every wave reading
-// its 32 weight rows 16 bytes at a time: k_shot_conv's loads, not its MFMAs, set its pace (with the operand loads taken
-// out it runs at 102 TFLOP/s, with them at 57: a wave-wide float4 load of 32 different rows is 32 L1 transactions), and
-// the weight operand is the half of them that the four waves of a workgroup share.
-__global__ __launch_bounds__(256) void k_shot_conv_lds(const ShotConv A) {
-    extern __shared__ float sm_shot[];                       // [2][32][C + 4]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-    const long long m = std::min((long long)blockIdx.x * 128 + wave * 32 + r, A.M - 1);
-    const int tiles = A.Fpad >> 5, br = blockIdx.y / tiles, nt = blockIdx.y - br * tiles;
-    const int d = 1 << br;
-    const int x = (int)(m % A.W);
-    long long q = m / A.W;
-    const int y = (int)(q % A.H);
-    q /= A.H;
-    const int t = (int)(q % A.T);
-    const long long frame0 = q - t;
-    const int C = A.C, WS = C + 4, spt = C >> 3, c4n = C >> 2;
-    const int per_thread = (32 * c4n) >> 8;                  // float4 of a weight slice per thread: 2 (C = 64), 4, 8
-    const float *wbase = A.Wt + ((size_t)br * A.Fpad + nt * 32) * A.kpad;
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    auto tap_ptr = [&](int tap, bool &ok) -> const float * {
-        const int kt = tap / 9, kh = (tap - 9 * kt) / 3, kw = tap - 9 * kt - 3 * kh;
-        const int tt = t + (kt - 1) * d, yy = y + kh - 1, xx = x + kw - 1;
-        ok = (unsigned)tt < (unsigned)A.T && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W;
-        return ok ? A.X + ((((size_t)(frame0 + tt)) * A.H + yy) * A.W + xx) * C + 4 * hh : A.X + 4 * hh;
-    };
-    typedef float shot_f4 __attribute__((ext_vector_type(4)));
-    shot_f4 wreg[8];                                         // (an ext_vector type: a float4 struct array indexed under a run-time bound became a 144-byte private segment)
-    auto fetch_w = [&](int tap) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < per_thread) {
-                const int idx = tid + 256 * i, row = idx / c4n, c4 = idx - row * c4n;
-                wreg[i] = *(const shot_f4 *)(wbase + (size_t)row * A.kpad + tap * C + c4 * 4);
-            }
-    };
-    auto store_w = [&](float *dst) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < per_thread) {
-                const int idx = tid + 256 * i, row = idx / c4n, c4 = idx - row * c4n;
-                *(shot_f4 *)(dst + row * WS + c4 * 4) = wreg[i];
-            }
-    };
-    fetch_w(0);
-    store_w(sm_shot);
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool okc, okn = false;
-    const float *pc = tap_ptr(0, okc), *pn = pc;
-    float4 an = *(const float4 *)pc;
-    if (!okc) an = z4;
-    for (int tap = 0; tap < 27; ++tap) {
-        float *Bs = sm_shot + (tap & 1) * 32 * WS;
-        __syncthreads();                                     // this tap's slice is in LDS; the other buffer's readers are done
-        if (tap + 1 < 27) { fetch_w(tap + 1); pn = tap_ptr(tap + 1, okn); }
-        const float *bp = Bs + r * WS + 4 * hh;
-        for (int st = 0; st < spt; ++st) {
-            const float4 a = an;
-            const float4 b = *(const float4 *)(bp + 8 * st);
-            if (st + 1 < spt) {
-                an = *(const float4 *)(pc + 8 * (st + 1));
-                if (!okc) an = z4;
-            } else if (tap + 1 < 27) {
-                an = *(const float4 *)pn;
-                if (!okn) an = z4;
-            }
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
-        }
-        if (tap + 1 < 27) store_w(sm_shot + ((tap + 1) & 1) * 32 * WS);
-        pc = pn; okc = okn;
     }
     if ((long long)blockIdx.x * 128 + wave * 32 + r >= A.M) return;
     float *yp = A.Y + (size_t)m * A.ldy + br * A.F;
@@ -510,7 +385,7 @@ __global__ __launch_bounds__(64) void k_shot_head(const float *__restrict__ X, c
 
 struct ShotX3 {
     const uint4 *X3;        // input planes [C / 16][3][Mp][2]
-    const uint4 *W3;        // [branch][filter group][iteration = (q, kt, kh)][kw][NT tiles][NPL planes][64 lanes] uint4 (k_shot_x3_weights)
+    const uint4 *W3;        // [branch][filter group][iteration = (q, kt, kh)][kw][NT tiles][NPL planes][64 lanes] uint4 (k_shot_x3m_weights)
     const float *bias;      // [branches * F]
     uint4 *Y3;              // output planes [4 F / 16][3][Mp][2]: branch br writes channels br * F ..
     long long M, Mp;        // positions the launch computes = B * tn * H * W (compact, see shot_real); plane stride
@@ -582,166 +457,28 @@ __device__ __forceinline__ void shot_kw_epilogue(const f32x16 (&acc)[PT][KT], ui
     }
 }
 
-// A DDCNN cell on split-bf16 operands: implicit GEMM [positions x 27 C] . [27 C x filters] on v_mfma_f32_32x32x16_bf16, NP = 6
-// plane pairs per 16-deep step (svc_x3.h; NP = 3: hi.hi + hi.mid + mid.hi only, SVC_SHOT_MX=bf16x3).
+// A DDCNN cell on split-bf16 operands: implicit GEMM [positions x 27 C] . [27 C x filters] on v_mfma_f32_16x16x32_bf16 (16 filters x
+// 16 positions per MFMA, 32 channels deep), NP = 6 plane pairs per step (svc_x3.h; NP = 3: hi.hi + hi.mid + mid.hi only, SVC_SHOT_MX=bf16x3).
 //
-// What bounds this kernel is the delivery of the position operand (measured with one load per tap: 21 TB/s from L2 to the
-// CUs' L1s in the 32-filter cells, the MFMAs at half their rate), so the three kw taps of a (kt, kh) share ONE load:
+// What bounds this kernel is the delivery of the position operand (measured with one load per tap: 21 TB/s from L2 to the CUs' L1s in
+// the 32-filter cells, the MFMAs at half their rate), so the three kw taps of a (kt, kh) share ONE load:
 //   y[m] = sum_kw W_kw . x[m + kw - 1]  =  P_0[m - 1] + P_1[m] + P_2[m + 1],   P_kw[m'] = W_kw . x[m']  (un-shifted),
-// i.e. a wavefront keeps one accumulator tile PER kw over the whole K loop, all three fed by the same position registers,
-// and the shift by one position happens ONCE, on the accumulators, in the epilogue (ds_bpermute; the frame's left / right
-// border masks the P_0 / P_2 term there; the (kt, kh) border is a property of m' and masks the load as before).  A wave
-// computes 32 PT consecutive positions and emits the inner 32 PT - 2 (the two ends only serve their neighbours): 3 % more
-// MFMAs for a third of the operand traffic.  The 16-filter cell packs kw = 0 | kw = 1 into ONE 32-row weight tile and
-// kw = 2 into half of a second (F16: 2 tiles instead of 3 half-empty ones).
-// K order: the 16-channel group q OUTERMOST, then (kt, kh) = one iteration -- what the workgroups of an XCD have in flight
-// is one group's planes of a band of frames (a few MB: it stays in the XCD's L2 while the taps re-read it; with the taps
-// outermost the 128-channel cell took 2.29 ms, with q outermost 1.00).
-// Positions: straight from the planes into the MFMA registers (see above), requested one iteration ahead.  Weights: the
-// iteration's [tile][plane][64 lanes] block is contiguous in W3 in exactly the order the lanes read it -- copied to LDS by
-// all four waves one iteration ahead (double buffer, ONE barrier per iteration), read back lane-contiguous (conflict-free)
-// one tile ahead.
-// NT (filter tiles per wavefront) is 1 in every launch: the 64-filter cells run their two filter groups as separate workgroups
-// (two tiles per wave -- six accumulator tiles per position tile, one wave per SIMD -- took 580 / 1033 us against 451 / 863).
-template <int NT, int PT, int NP, bool F16>
-__global__ __launch_bounds__(256) void k_shot_conv_x3(const ShotX3 A) {
-    extern __shared__ uint4 sm_w3[];
-    constexpr int NPL = NP == 3 ? 2 : 3;                     // planes an operand needs
-    constexpr int KT = F16 ? 2 : 3 * NT;                     // weight tiles per iteration: (kw, n), or kw0|kw1 and kw2|0
-    constexpr int WCH = KT * NPL * 64;                       // uint4 per iteration
-    constexpr int WPT = (WCH + 255) / 256;                   // per thread
-    constexpr int WS = 32 * PT - 2, WGS = 4 * WS;            // positions a wave / a workgroup emits
-    static_assert(!F16 || NT == 1, "the 16-filter packing is one tile wide");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-    const int groups = A.Fpad / (32 * NT), br = blockIdx.y / groups, ng = blockIdx.y - br * groups;
-    const int d = 1 << br, HW = A.H * A.W, niter = 9 * (A.C >> 4);
-    // XCD-aware tile order: workgroup ids go round the eight XCDs, so XCD x takes the x-th eighth of the positions and its
-    // L2 holds one band of frames (the taps of neighbouring tiles re-read the same lines)
-    long long tile = blockIdx.x;
-    if (A.xcd) tile = (long long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    if (blockIdx.x == 0) shot_zero_pads(A.Y3, A.Mp, (br * A.F + ng * 32 * NT) >> 4, std::min(32 * NT, A.F - ng * 32 * NT) >> 4, tid);
-    if (tile * WGS >= A.M) return;
-    const long long mb = tile * WGS + wave * WS - 1;         // first position this wave computes (its first output is mb + 1)
-    unsigned vo[PT], okb[PT];
-    int xs[PT];
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-        const long long m = mb + 32 * pt + r;
-        const bool in = m >= 0 && m < A.M;
-        const long long mm = in ? shot_real(m, A.T, A.t0, A.tn, HW) : 0, fr = mm / HW;
-        const int rem = (int)(mm - fr * HW), y = rem / A.W, x = rem - y * A.W, t = (int)(fr % A.T);
-        unsigned b = 0;
-        for (int g = 0; g < 9; ++g) {
-            const int kt = g / 3, kh = g - 3 * kt;
-            const bool ok = in && (unsigned)(t + (kt - 1) * d) < (unsigned)A.T && (unsigned)(y + kh - 1) < (unsigned)A.H;
-            b |= (unsigned)ok << g;
-        }
-        okb[pt] = b;
-        xs[pt] = x;
-        vo[pt] = (unsigned)(((SHOT_PAD + mm) * 2 + hh) * 16);
-    }
-    // buffer loads: the descriptor covers the input planes, a lane's byte offset is 32 bits, the (q, plane) offset is a scalar
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)A.X3, 0, (int)((size_t)(A.C >> 4) * 3 * A.Mp * 32), 0x00020000);
-    const unsigned planeB = (unsigned)(A.Mp * 32);
-    const uint4 *wsrc = A.W3 + (size_t)(br * groups + ng) * niter * WCH + tid;
-    bf16x8 a[2][PT][NPL], bw[2][NPL];
-    // positions of iteration it_ = (q, kt, kh) into register set set_: the tap's byte shift is a scalar, its mask one bit per tile
-#define SHOT_LDA(set_, it_)                                                                                          \
-    {                                                                                                                \
-        const int q_ = (it_) / 9, g_ = (it_) - 9 * q_, kt_ = g_ / 3, kh_ = g_ - 3 * kt_;                             \
-        const int sh_ = (((kt_ - 1) * d * HW) + (kh_ - 1) * A.W) * 32;                                               \
-        _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) {                                                          \
-            const unsigned v_ = ((it_) < niter && ((okb[pt] >> g_) & 1)) ? vo[pt] + sh_ : (unsigned)(hh * 16);      \
-            _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                                     \
-                X3Q t_;                                                                                              \
-                const auto ld_ = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)v_, (int)((unsigned)(q_ * 3 + pl) * planeB), 0); \
-                t_.u[0] = ld_[0]; t_.u[1] = ld_[1]; t_.u[2] = ld_[2]; t_.u[3] = ld_[3];                              \
-                a[set_][pt][pl] = t_.v;                                                                              \
-            }                                                                                                        \
-        }                                                                                                            \
-    }
-#define SHOT_LDB(set_, buf_, wt_)                                                                                    \
-    _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                                             \
-        X3Q t_;                                                                                                      \
-        t_.q = sm_w3[(buf_) * WCH + ((wt_) * NPL + pl) * 64 + lane];                                                 \
-        bw[set_][pl] = t_.v;                                                                                         \
-    }
-    // one weight tile against the iteration's positions: the plane pairs in svc_x3.h's order (small pairs first), the
-    // position tiles innermost (independent chains)
-#define SHOT_MMA(aset_, bset_, wt_)                                                                                  \
-    {                                                                                                                \
-        constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};                                        \
-        _Pragma("unroll") for (int pr = (NP == 3 ? 3 : 0); pr < 6; ++pr)                                             \
-            _Pragma("unroll") for (int pt = 0; pt < PT; ++pt)                                                        \
-                acc[pt][wt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[bset_][PW[pr]], a[aset_][pt][PA[pr]], acc[pt][wt_], 0, 0, 0); \
-    }
-    f32x16 acc[PT][KT];
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-        for (int k = 0; k < KT; ++k)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[pt][k][i] = 0.f;
-    // (the weight blocks as clang vectors and copied unconditionally: a uint4 array copied from memory becomes a memcpy and
-    // stays in a private segment, as shot_fetch found; the last iteration re-reads its own block)
-    typedef unsigned shot_u4 __attribute__((ext_vector_type(4)));
-    // prologue: weights of iteration 0 into buffer 0, its positions requested, its first weight tile read
-#pragma unroll
-    for (int k = 0; k < WPT; ++k)
-        if (tid + 256 * k < WCH) ((shot_u4 *)sm_w3)[tid + 256 * k] = ((const shot_u4 *)wsrc)[256 * k];
-    SHOT_LDA(0, 0);
-    __syncthreads();
-    SHOT_LDB(0, 0, 0);
-    // one iteration: the tiles wt = 0 .. KT - 1 against position set sa_; the weight fragments alternate between two register
-    // sets starting with b0_ (KT may be odd: the loop body is two iterations, so every index is static)
-#define SHOT_ITER(it_, sa_, b0_)                                                                                     \
-    {                                                                                                                \
-        const int cb_ = (it_) & 1;                                                                                   \
-        shot_u4 wreg[WPT];                                                                                           \
-        {                                                                                                            \
-            const shot_u4 *wp = (const shot_u4 *)(wsrc + (size_t)((it_) + 1 < niter ? (it_) + 1 : (it_)) * WCH);     \
-            _Pragma("unroll") for (int k = 0; k < WPT; ++k) wreg[k] = wp[tid + 256 * k < WCH ? 256 * k : 0];         \
-        }                                                                                                            \
-        SHOT_LDA((sa_) ^ 1, (it_) + 1);                                                                              \
-        _Pragma("unroll") for (int wt = 0; wt < KT; ++wt) {                                                          \
-            if (wt + 1 < KT) {                                                                                       \
-                SHOT_LDB(((b0_) + wt + 1) & 1, cb_, wt + 1);                                                         \
-            } else {                                                                                                 \
-                /* the next iteration's weights: the other buffer's readers finished before the previous barrier; */ \
-                /* this iteration's last read (the fragments of tile KT - 1) is complete when the barrier is passed */ \
-                shot_u4 *wn = (shot_u4 *)(sm_w3 + (cb_ ^ 1) * WCH + tid);                                            \
-                _Pragma("unroll") for (int k = 0; k < WPT; ++k)                                                      \
-                    if (tid + 256 * k < WCH) wn[256 * k] = wreg[k];                                                  \
-                __syncthreads();                                                                                     \
-                SHOT_LDB(((b0_) + wt + 1) & 1, cb_ ^ 1, 0);                                                          \
-            }                                                                                                        \
-            SHOT_MMA(sa_, ((b0_) + wt) & 1, wt);                                                                     \
-            /* issue order: the weight reads and this tile's share of the position loads between the MFMAs */       \
-            _Pragma("unroll") for (int i_ = 0; i_ < NPL; ++i_) {                                                     \
-                __builtin_amdgcn_sched_group_barrier(0x008, NP * PT / NPL, 0);                                      \
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                   \
-                if (wt * NPL + i_ < PT * NPL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     \
-            }                                                                                                        \
-        }                                                                                                            \
-    }
-    for (int it = 0; it < niter; it += 2) {                  // niter = 9 C / 16 is even (C = 64, 128, 256)
-        SHOT_ITER(it, 0, 0);
-        SHOT_ITER(it + 1, 1, KT & 1);
-    }
-#undef SHOT_ITER
-#undef SHOT_MMA
-#undef SHOT_LDB
-#undef SHOT_LDA
-    shot_kw_epilogue<NT, PT, KT, F16>(acc, A.Y3, A.Mp, A.M, A.W, A.F, A.bias, A.relu, br, ng, mb, r, hh, xs, A.T, A.t0, A.tn, HW);
-}
-
-// The same cell on v_mfma_f32_16x16x32_bf16 (SVC_SHOT_M16): 16 filters x 16 positions per MFMA, 32 channels deep.  Why a second
-// shape: the 16-filter cell fills its weight tiles (3 kw tiles of 16 filters instead of two 32-row tiles of which one is half
-// empty: a quarter fewer MFMAs), and under the chip's clock management the 16x16x32 shape sustains more FLOP/s than 32x32x16
-// (MI355X_MICROARCH.md, DVFS).  Lane (p, g) = (lane & 15, lane >> 4) holds the eight channels of k group g of one position /
-// filter; group g is the uint4 (q = 2 s + (g >> 1), hh = g & 1) of the planar layout, so the position operand is still a plain
-// load (two runs of 512 bytes per instruction) and the kw taps stay in the accumulators (f32x4 per tile).  A lane ends with
-// filters 4 g .. 4 g + 3 of one position: half a uint4 per plane (8-byte stores).  Iteration = (32-channel group s, kt, kh).
+// i.e. a wavefront keeps one accumulator tile PER kw over the whole K loop, all three fed by the same position registers, and the
+// shift by one position happens ONCE, on the accumulators, in the epilogue (ds_bpermute; the frame's left / right border masks the
+// P_0 / P_2 term there; the (kt, kh) border is a property of m' and masks the load).  A wave computes 16 PT consecutive positions and
+// emits the inner 16 PT - 2 (the two ends only serve their neighbours): 3 % more MFMAs for a third of the operand traffic.
+// K order: the 32-channel group s OUTERMOST, then (kt, kh) = one iteration -- what the workgroups of an XCD have in flight is one
+// group's planes of a band of frames (a few MB: it stays in the XCD's L2 while the taps re-read it; with the taps outermost the
+// 128-channel cell took 2.29 ms, with the group outermost 1.00).
+// Positions: straight from the planes into the MFMA registers, requested one iteration ahead.  Lane (p, g) = (lane & 15, lane >> 4)
+// holds the eight channels of k group g of one position / filter; group g is the uint4 (q = 2 s + (g >> 1), hh = g & 1) of the planar
+// layout, so the position operand is a plain load (two runs of 512 bytes per instruction).  Weights: the iteration's [tile][plane][64
+// lanes] block is contiguous in W3 in exactly the order the lanes read it -- copied to LDS by all four waves one iteration ahead (double
+// buffer, ONE barrier per iteration), read back lane-contiguous (conflict-free) one tile ahead.  A lane ends with filters 4 g .. 4 g + 3
+// of one position: half a uint4 per plane (8-byte stores).
+// Why this MFMA shape: 16-filter weight tiles fit the 16-filter cell exactly (three kw tiles; on 32x32x16 two 32-row tiles, one half
+// empty: a quarter more MFMAs), and three 16-position tiles per wavefront keep two waves per SIMD with two filter tiles.
+// NT (filter tiles per wavefront) = min(F / 16, 2): the 64-filter cells run their filter groups as separate workgroups.
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 template <int NT, int PT, int NP>
 __global__ __launch_bounds__(256) void k_shot_conv_x3m(const ShotX3 A) {
@@ -916,47 +653,13 @@ __global__ __launch_bounds__(256) void k_shot_x3m_weights(const float *__restric
         if (pl < NPL) o[pl * 64] = P[pl].q;
 }
 
-// The weights of a cell in the order k_shot_conv_x3 reads them: round-to-nearest bf16 planes (svc_x3.h) of
-// Wt [branch][Fpad][kpad] (k = tap * C + channel), one thread per (branch, group, iteration = (q, kt, kh), weight tile, lane).
-// A weight tile is (kw, n): rows = filters (ng NT + n) 32 ..; f16 (the 16-filter cell): tile 0 = kw 0's filters | kw 1's,
-// tile 1 = kw 2's | zeros.
-__global__ __launch_bounds__(256) void k_shot_x3_weights(const float *__restrict__ Wt, int Fpad, int kpad, int C, int NT, int NPL, int f16,
-                                                         uint4 *__restrict__ out, size_t total) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int KT = f16 ? 2 : 3 * NT;
-    const int lane = (int)(i & 63), r = lane & 31, hh = lane >> 5;
-    size_t u = i >> 6;
-    const int wt = (int)(u % KT); u /= KT;
-    const int niter = 9 * (C >> 4), groups = Fpad / (32 * NT);
-    const int it = (int)(u % niter); u /= niter;
-    const int ng = (int)(u % groups), br = (int)(u / groups);
-    const int q = it / 9, g = it - 9 * q;
-    int kw, row;
-    bool zero = false;
-    if (f16) { kw = 2 * wt + (r >> 4); row = r & 15; zero = kw > 2; }
-    else { kw = wt / NT; row = (ng * NT + wt % NT) * 32 + r; }
-    X3 s;
-    if (zero) {
-        s = x3_split<true>(make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f));
-    } else {
-        const float *w = Wt + ((size_t)br * Fpad + row) * kpad + (g * 3 + kw) * C + 16 * q + 4 * hh;
-        s = x3_split<true>(*(const float4 *)w, *(const float4 *)(w + 8));
-    }
-    X3Q P[3];
-    P[0].v = s.h; P[1].v = s.m; P[2].v = s.l;
-    uint4 *o = out + ((((size_t)(br * groups + ng) * niter + it) * KT + wt) * NPL) * 64 + lane;
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-        if (pl < NPL) o[pl * 64] = P[pl].q;
-}
-
 // ---- the first cell (3 input channels) on the same pipe --------------------------------------------------------------------
 // Its input is the frames themselves: k_shot_in_x3 writes v / 255 as three bf16 planes [3][Mp][4 channels] (8 bytes per
 // position and plane, channel 3 = 0, SHOT_PAD zero positions in front).  K = 27 taps x 3 channels is far too short per tap for
 // a 16-deep step, so a step packs FOUR (kt, kh) pairs x 4 channels: pair pi = 4 q + 2 (j >> 2) + hh for element j of lane
 // (r, hh) (9 pairs in 3 steps, the last three empty), the kw taps stay in the accumulators and the 16 filters pack as in
-// k_shot_conv_x3's F16 form: 3 steps x 2 tiles x NP MFMAs per 32 positions and dilation (fp32 form: 54 x 64-cycle MFMAs).
+// a 16-filter packing -- tile 0 = kw 0's filters (rows 0..15) | kw 1's (rows 16..31), tile 1 = kw 2's | zeros: 3 steps x 2 tiles x NP
+// MFMAs per 32 positions and dilation (fp32 form: 54 x 64-cycle MFMAs).
 struct ShotFirst {
     const uint2 *X3;        // [3 planes][Mp][4 bf16]
     const uint4 *W3;        // [branch][3 steps][2 tiles][NPL planes][64 lanes] (k_shot_first_weights)
@@ -1175,21 +878,21 @@ extern "C" int svc_transnet_load(SvcHandle *h, const float *blob_host, size_t n_
 
 extern "C" int svc_transnet_matrix_pipe(const SvcHandle *h) { return h ? (h->shot_mx < 0 ? h->mx : h->shot_mx) : 0; }
 
-// TransNet knobs of a handle as an array {matrix pipe (-1 = the handle's SVC_MX), 16x16x32 tiles, 32x32x16 tiles, XCD order, fp32 form}: what
-// ShotTransNet.clone() copies to the engine of a second network instead of re-reading the environment
-extern "C" int svc_transnet_config_get(const SvcHandle *h, int32_t *cfg5) {
-    if (!h || !cfg5) { svc_set_error("svc_transnet_config_get: invalid argument"); return SVC_E_INVALID; }
-    cfg5[0] = h->shot_mx; cfg5[1] = h->shot_m16; cfg5[2] = h->shot_pt; cfg5[3] = h->shot_xcd; cfg5[4] = h->shot_form;
+// TransNet knobs of a handle as an array {matrix pipe (-1 = the handle's SVC_MX), 16-position tiles per wavefront, XCD-aware tile order}:
+// what ShotTransNet.clone() copies to the engine of a second network instead of re-reading the environment
+extern "C" int svc_transnet_config_get(const SvcHandle *h, int32_t *cfg3) {
+    if (!h || !cfg3) { svc_set_error("svc_transnet_config_get: invalid argument"); return SVC_E_INVALID; }
+    cfg3[0] = h->shot_mx; cfg3[1] = h->shot_m16; cfg3[2] = h->shot_xcd;
     return SVC_OK;
 }
-extern "C" int svc_transnet_config_set(SvcHandle *h, const int32_t *cfg5) {
-    if (!h || !cfg5) { svc_set_error("svc_transnet_config_set: invalid argument"); return SVC_E_INVALID; }
-    const int mx = cfg5[0], m16 = cfg5[1], pt = cfg5[2], form = cfg5[4];
-    if (!(mx == -1 || mx == 0 || mx == 3 || mx == 6) || !(m16 == 0 || (m16 >= 2 && m16 <= 4)) || !(pt == 1 || pt == 2) || form < 0 || form > 2) {
-        svc_set_error("svc_transnet_config_set: {%d, %d, %d, %d, %d} is not a configuration", mx, m16, pt, cfg5[3], form);
+extern "C" int svc_transnet_config_set(SvcHandle *h, const int32_t *cfg3) {
+    if (!h || !cfg3) { svc_set_error("svc_transnet_config_set: invalid argument"); return SVC_E_INVALID; }
+    const int mx = cfg3[0], m16 = cfg3[1];
+    if (!(mx == -1 || mx == 0 || mx == 3 || mx == 6) || m16 < 2 || m16 > 4) {
+        svc_set_error("svc_transnet_config_set: {%d, %d, %d} is not a configuration", mx, m16, cfg3[2]);
         return SVC_E_INVALID;
     }
-    h->shot_mx = mx; h->shot_m16 = m16; h->shot_pt = pt; h->shot_xcd = cfg5[3] != 0; h->shot_form = form;
+    h->shot_mx = mx; h->shot_m16 = m16; h->shot_xcd = cfg3[2] != 0;
     return SVC_OK;                                           // (the split weight copies follow at the next predict: shot_w3_mx keys them)
 }
 
@@ -1235,9 +938,8 @@ static int transnet_predict_rows(SvcHandle *h, const uint8_t *frames, int n_wind
     size_t w3_off[SHOT_L * SHOT_S] = {0};
     if (mx) {
         size_t tot = 0;
-        // uint4 per cell: branches x groups x iterations x weight tiles x planes x 64 lanes
-        auto w3_tiles = [&](const ShotCell &k) { return k.f == 16 ? (size_t)2 : (size_t)3 * (k.fpad / 32); };
-        for (int i = 1; i < SHOT_L * SHOT_S; ++i) { w3_off[i] = tot; tot += (size_t)4 * 9 * (cells[i].cpad / 16) * w3_tiles(cells[i]) * NPL * 64; }
+        // uint4 per cell: (4 branches) x (F / 16 filter tiles) x 3 kw x 9 (kt, kh) x (C / 32 groups) x planes x 64 lanes
+        for (int i = 1; i < SHOT_L * SHOT_S; ++i) { w3_off[i] = tot; tot += (size_t)4 * (cells[i].f / 16) * 3 * 9 * (cells[i].cpad / 32) * NPL * 64; }
         const size_t w3_first = tot;                          // the first cell's block behind the others
         tot += (size_t)4 * 3 * 2 * NPL * 64;
         w3_off[0] = w3_first;
@@ -1249,17 +951,9 @@ static int transnet_predict_rows(SvcHandle *h, const uint8_t *frames, int n_wind
             SVC_CHECK_LAUNCH();
             for (int i = 1; i < SHOT_L * SHOT_S; ++i) {
                 const ShotCell &k = cells[i];
-                if (h->shot_m16) {                            // 16-filter tiles, 32-deep iterations: (4 br) x (F / 16 tiles) x 3 kw x 9 (kt, kh) x C / 32 x 64 lanes
-                    const size_t total = (size_t)4 * (k.f / 16) * 3 * 9 * (k.cpad / 32) * 64;
-                    k_shot_x3m_weights<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(blob + k.w_off, k.fpad, k.kpad, k.cpad, k.f, std::min(k.f / 16, 2), NPL,
-                                                                                      (uint4 *)h->shot_w3.p + w3_off[i], total);
-                    SVC_CHECK_LAUNCH();
-                    continue;
-                }
-                const int NT = 1;
-                const size_t total = (size_t)4 * 9 * (k.cpad / 16) * w3_tiles(k) * 64;         // threads: one per (tile, lane)
-                k_shot_x3_weights<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(blob + k.w_off, k.fpad, k.kpad, k.cpad, NT, NPL, k.f == 16,
-                                                                                 (uint4 *)h->shot_w3.p + w3_off[i], total);
+                const size_t total = (size_t)4 * (k.f / 16) * 3 * 9 * (k.cpad / 32) * 64;        // threads: one per (tile, lane)
+                k_shot_x3m_weights<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(blob + k.w_off, k.fpad, k.kpad, k.cpad, k.f, std::min(k.f / 16, 2), NPL,
+                                                                                  (uint4 *)h->shot_w3.p + w3_off[i], total);
                 SVC_CHECK_LAUNCH();
             }
             h->shot_w3_mx = mx * 2 + h->shot_m16;
@@ -1296,17 +990,17 @@ static int transnet_predict_rows(SvcHandle *h, const uint8_t *frames, int n_wind
                     ShotFirst X;
                     X.X3 = (const uint2 *)P[cur]; X.W3 = (const uint4 *)h->shot_w3.p + w3_off[0]; X.bias = blob + k.b_off; X.Y3 = (uint4 *)P[cur ^ 1];
                     X.M = Mc; X.Mp = Mp; X.T = T; X.H = H; X.W = W; X.relu = 1; X.xcd = h->shot_xcd;
-                    const int PT = h->shot_pt, WGS = 4 * (32 * PT - 2) * SHOT_FIRST_REP;
+                    const int PT = 2, WGS = 4 * (32 * PT - 2) * SHOT_FIRST_REP;      // two 32-position tiles per wavefront (one: measured slower)
                     unsigned gx = (unsigned)((Mc + WGS - 1) / WGS);
                     if (X.xcd) gx = (gx + 7) / 8 * 8;
                     dim3 grid(gx, 4);
-                    if (mx == 3) { if (PT == 2) k_shot_first_x3<2, 3><<<grid, 256, 0, s>>>(X); else k_shot_first_x3<1, 3><<<grid, 256, 0, s>>>(X); }
-                    else { if (PT == 2) k_shot_first_x3<2, 6><<<grid, 256, 0, s>>>(X); else k_shot_first_x3<1, 6><<<grid, 256, 0, s>>>(X); }
+                    if (mx == 3) k_shot_first_x3<2, 3><<<grid, 256, 0, s>>>(X);
+                    else k_shot_first_x3<2, 6><<<grid, 256, 0, s>>>(X);
                     SVC_CHECK_LAUNCH();
                     cur ^= 1;
                     continue;
                 }
-                if (mx && k.cpad >= 64 && h->shot_m16) {
+                if (mx && k.cpad >= 64) {
                     ShotX3 X;
                     X.X3 = (const uint4 *)P[cur]; X.W3 = (const uint4 *)h->shot_w3.p + w3_off[b * SHOT_S + c]; X.bias = blob + k.b_off;
                     X.Y3 = (uint4 *)P[cur ^ 1]; X.Mp = Mp; X.T = T; X.H = H; X.W = W; X.C = k.cpad; X.F = k.f; X.Fpad = k.fpad;
@@ -1331,30 +1025,6 @@ static int transnet_predict_rows(SvcHandle *h, const uint8_t *frames, int n_wind
                     cur ^= 1;
                     continue;
                 }
-                if (mx && k.cpad >= 64) {
-                    ShotX3 X;
-                    X.X3 = (const uint4 *)P[cur]; X.W3 = (const uint4 *)h->shot_w3.p + w3_off[b * SHOT_S + c]; X.bias = blob + k.b_off;
-                    X.Y3 = (uint4 *)P[cur ^ 1]; X.Mp = Mp; X.T = T; X.H = H; X.W = W; X.C = k.cpad; X.F = k.f; X.Fpad = k.fpad;
-                    X.relu = 1; X.xcd = h->shot_xcd;
-                    X.t0 = ca[b * SHOT_S + c]; X.tn = cb[b * SHOT_S + c] - X.t0; X.M = (long long)nw * X.tn * H * W;
-                    const int NT = 1, PT = h->shot_pt;
-                    const bool f16 = k.f == 16;
-                    const int WGS = 4 * (32 * PT - 2);
-                    unsigned gx = (unsigned)((X.M + WGS - 1) / WGS);
-                    if (X.xcd) gx = (gx + 7) / 8 * 8;
-                    dim3 grid(gx, (unsigned)(4 * (k.fpad / (32 * NT))));
-                    const size_t lds = (size_t)2 * (f16 ? 2 : 3 * NT) * NPL * 64 * sizeof(uint4);
-#define SHOT_X3(NT_, PT_, NP_, F16_) k_shot_conv_x3<NT_, PT_, NP_, F16_><<<grid, 256, lds, s>>>(X)
-#define SHOT_X3_NP(NP_)                                                                                              \
-                    if (f16) { if (PT == 2) SHOT_X3(1, 2, NP_, true); else SHOT_X3(1, 1, NP_, true); }               \
-                    else { if (PT == 2) SHOT_X3(1, 2, NP_, false); else SHOT_X3(1, 1, NP_, false); }
-                    if (mx == 3) { SHOT_X3_NP(3) } else { SHOT_X3_NP(6) }
-#undef SHOT_X3_NP
-#undef SHOT_X3
-                    SVC_CHECK_LAUNCH();
-                    cur ^= 1;
-                    continue;
-                }
                 ShotConv A;
                 A.X = P[cur]; A.Wt = blob + k.w_off; A.bias = blob + k.b_off; A.Y = P[cur ^ 1];
                 A.M = (long long)nfr * H * W; A.T = T; A.H = H; A.W = W; A.C = k.cpad;
@@ -1363,8 +1033,7 @@ static int transnet_predict_rows(SvcHandle *h, const uint8_t *frames, int n_wind
                 A.F = k.f; A.Fpad = k.fpad; A.kpad = k.kpad; A.ntaps = 27; A.ldy = 4 * k.f; A.relu = 1;
                 A.ksplit = 1; A.rT = A.rtn = 1; A.rt0 = 0;
                 dim3 grid((unsigned)((A.M + 127) / 128), (unsigned)(4 * (k.fpad / 32)));
-                const int shot_form = h->shot_form;             // 0: direct operand loads, 1: weights through LDS, 2: both operands (SVC_SHOT_FORM)
-                if (shot_form == 2 && k.cpad >= 64 && k.cpad % 64 == 0) {
+                if (k.cpad >= 64 && k.cpad % 64 == 0) {            // the cells: both operands through LDS
                     if (k.f == 16) {
                         dim3 g16(grid.x, 4);
                         k_shot_conv_lds2_n16<<<g16, 256, (128 + 16) * 68 * sizeof(float), s>>>(A);
@@ -1374,12 +1043,7 @@ static int transnet_predict_rows(SvcHandle *h, const uint8_t *frames, int n_wind
                     } else {
                         k_shot_conv_lds2<1><<<grid, 256, (128 + 32) * 68 * sizeof(float), s>>>(A);
                     }
-                } else if (shot_form >= 1 && k.cpad >= 64 && k.cpad <= 256) {
-                    const size_t lds = (size_t)2 * 32 * (k.cpad + 4) * sizeof(float);
-                    if (lds > 64 * 1024 && h->lds_attr_done.insert((const void *)k_shot_conv_lds).second)
-                        SVC_HIP(hipFuncSetAttribute((const void *)k_shot_conv_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-                    k_shot_conv_lds<<<grid, 256, lds, s>>>(A);
-                } else {
+                } else {                                           // the first cell (3 input channels padded to 4)
                     k_shot_conv<<<grid, 256, 0, s>>>(A);
                 }
                 SVC_CHECK_LAUNCH();

@@ -96,7 +96,6 @@ struct TailArgs {
     int n_ring, n_ring1;    // all offsets within RING_R / the prefix within RING_R1
     const uint16_t *ring_cnt;   // [RING_R^2 + 1]: offsets with d2 <= index
     int prim_lvl;           // 1: k_prim_lvl for maps of up to LVL_CAP points (SVC_PRIM_LVL)
-    int tail_prio;          // 1: the fused tail kernels raise their wavefronts' issue priority (SVC_TAIL_PRIO)
     double *xy;
     int32_t *stats;
     FrameWS L;
@@ -2905,10 +2904,9 @@ __global__ __launch_bounds__(TB) void k_finish(TailArgs A) { finish_body(A); }
 // take (more than 8 192 points, cluster tables full) are left to the stand-alone kernels launched behind.
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TB) void k_tail_front(TailArgs A) {           // k_compact -> k_core -> k_prim_lvl
-    // SVC_TAIL_PRIO=1: highest issue priority for the tail's wavefronts (a chain of dependent steps that shares its SIMDs with
-    // other streams' network wavefronts in the pipeline).  Measured: no difference (1.2315 / 1.2354 ms per pipelined step,
-    // config 3 1.93 / 1.95 s) -- the chain waits for its own latencies, not for issue slots.  Off by default.
-    if (A.tail_prio) __builtin_amdgcn_s_setprio(3);
+    // (s_setprio 3 for the tail's wavefronts -- a chain of dependent steps sharing its SIMDs with other streams' network wavefronts --
+    // was measured in round 4: no difference, 1.2315 / 1.2354 ms per pipelined step; the chain waits for its own latencies, not for
+    // issue slots.  The knob is gone.)
     compact_body(A);
     __syncthreads();
     core_body(A);
@@ -2918,7 +2916,6 @@ __global__ __launch_bounds__(TB) void k_tail_front(TailArgs A) {           // k_
 
 __global__ __launch_bounds__(TB) void k_tail_back(TailArgs A, int cap_clusters, int cap_clusters_huge) {   // k_sort -> k_tree_par -> k_finish
     int32_t *hdr = (int32_t *)(A.ws + (size_t)(A.slot0 + (int)blockIdx.x) * A.ws_stride + A.L.hdr);
-    if (A.tail_prio) __builtin_amdgcn_s_setprio(3);
     sort_body(A);
     __syncthreads();
     tree_par_body(A, cap_clusters, cap_clusters_huge);
@@ -3183,7 +3180,7 @@ static int cluster_center_impl(SvcHandle *h, uint8_t *maps, int n, int height, i
     RC_TAIL(ensure_ring_delta(h, width, &ring_delta));
     A.ring = (const uint32_t *)h->tail_offsets.p; A.n_ring = h->tail_n_offsets; A.n_ring1 = h->tail_n_offsets1;
     A.ring_delta = ring_delta;
-    A.ring_cnt = (const uint16_t *)h->tail_ring_cnt.p; A.prim_lvl = h->prim_lvl; A.tail_prio = h->tail_prio;
+    A.ring_cnt = (const uint16_t *)h->tail_ring_cnt.p; A.prim_lvl = h->prim_lvl;
     A.xy = xy; A.stats = stats; A.L = L;
     const int hw = height * width;
     const size_t lds_core = (size_t)(hw + 15) / 16 * 16 + (size_t)h->tail_n_offsets * 4 + (size_t)h->tail_n_offsets1 * 4;

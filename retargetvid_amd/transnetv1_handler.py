@@ -49,9 +49,9 @@ class ShotTransNet:
         _lib.check(self.eng.lib.svc_transnet_load(self.eng._h, blob.ctypes.data_as(ctypes.c_void_p), blob.size))
 
     def config(self):
-        """The engine's TransNet knobs (svc_transnet_config_get): [matrix pipe (-1 = the engine's SVC_MX), 16x16x32 tiles, 32x32x16
-        tiles, XCD order, fp32 form]."""
-        cfg = (ctypes.c_int32 * 5)()
+        """The engine's TransNet knobs (svc_transnet_config_get): [matrix pipe (-1 = the engine's SVC_MX), 16-position tiles per
+        wavefront, XCD-aware tile order]."""
+        cfg = (ctypes.c_int32 * 3)()
         _lib.check(self.eng.lib.svc_transnet_config_get(self.eng._h, cfg))
         return list(cfg)
 
@@ -65,7 +65,7 @@ class ShotTransNet:
         if cfg[0] < 0:                                        # "follow SVC_MX": pin what THIS engine resolved it to
             cfg[0] = int(self.eng.lib.svc_transnet_matrix_pipe(self.eng._h))
         net = ShotTransNet(self.params, windows_per_call=self.windows_per_call, _blob=self._blob)
-        _lib.check(net.eng.lib.svc_transnet_config_set(net.eng._h, (ctypes.c_int32 * 5)(*cfg)))
+        _lib.check(net.eng.lib.svc_transnet_config_set(net.eng._h, (ctypes.c_int32 * 3)(*cfg)))
         return net
 
     def matrix_pipe(self):

@@ -119,7 +119,7 @@ def test_saliency_batch_and_chunk_independence(engine, shape):
     {'SVC_FUSE_MAX': '13'},                                 # every block that can be fused is
     {'SVC_SPLIT_UP': '0'},                                  # decoder: up-sample + concatenate + one GEMM (the reference's order)
     {'SVC_IRB_FIXED': '0'},                                 # generic (run-time shaped) fused block instead of the fixed-shape instances
-    {'SVC_STEM_MFMA': '0', 'SVC_SMOOTH_MFMA': '0'},          # features.0 and the 41x41 smoothing as FMA kernels
+    {'SVC_SMOOTH_MFMA': '0'},                               # the 41x41 smoothing as the FMA kernel (the fall-back for geometries whose maps are not 8 x the low-resolution grid)
     {'SVC_FRONT': '0'},                                     # LANCZOS, features.0 and features.1 as three kernels instead of k_front
     {'SVC_CHUNK': '5'},                                     # ragged chunks of the batch
     {'SVC_SK_LANE': '0'},                                   # split-K layers read the [N][K] weight matrix instead of its lane-order copy

@@ -57,6 +57,11 @@ def load():
     if not os.path.isfile(LIB_PATH):
         raise SvcError('HIP library %s not found: build it with `make -C %s/csrc` '
                        '(there is no CPU fallback)' % (LIB_PATH, _HERE))
+    # PyTorch first: its wheel bundles the HIP runtime (libamdhip64) the process must share -- device memory and streams come from
+    # torch.  Loaded the other way round the library would bind the system's /opt/rocm runtime, and on the GPU boxes of this pool that
+    # second runtime reports "no ROCm-capable device" (seen in round 6 with `python __graft_entry__.py smoke`: build() loaded the
+    # library before anything had imported torch).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     lib.svc_last_error.restype = ctypes.c_char_p

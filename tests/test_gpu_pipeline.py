@@ -381,3 +381,30 @@ def test_threshold_regime_diagnostic(engine, tmp_path):
     fn = S.write_results(str(tmp_path), 'v', '1:3', VD, res)
     info = open(fn.replace('.txt', '_info.txt')).read()
     assert 'pixels_per_grey_level_at_threshold:%s' % ppl in info
+
+
+@pytest.mark.gpu
+def test_a_folder_of_frame_images_through_the_decode_door(engine, tmp_path):
+    """§8 f2: smart_vid_crop(<path>) with a reader installed (set_video_reader) -- here the Pillow reader that runs in this image
+    (retargetvid_amd/ingest.py; the reference decodes with cv2, smartVidCrop.py:299-335) -- gives the windows of the call on the
+    decoded frames; without trans_inds (shots=None) the entry point runs shot detection itself."""
+    from PIL import Image
+    from retargetvid_amd import ingest, transnetv1_handler as TH, weights
+    video = _video(40, 21, [0, 17, 40])
+    d = tmp_path / 'clip_001'
+    d.mkdir()
+    for i, f in enumerate(video['frames']):
+        Image.fromarray(f).save(str(d / ('%05d.png' % i)))
+    CP = dict(S.sc_init_crop_params(), out_ratio='1:3')
+    ref = S.smart_vid_crop(video, CP, save_vid=False, engine=engine)
+    try:
+        S.set_video_reader(lambda path, cp: ingest.read_frames_pillow(path, fr=video['fr'], shot_detector=lambda fr: [17]))
+        VD, res = S.smart_vid_crop(str(d), CP, save_vid=False, engine=engine)
+        assert VD['bbs'] == ref[0]['bbs'] and VD['dx'] == ref[0]['dx'] and res['info'] == ref[1]['info']
+        net = TH.ShotTransNet(TH.ShotTransNetParams(), weights=weights.make_transnet_state_dict(0), engine=engine)
+        S.set_video_reader(lambda path, cp: ingest.read_frames_pillow(path, fr=video['fr'], shots=None))
+        a = S.smart_vid_crop(str(d), CP, save_vid=False, engine=engine, shot_net=net)
+        b = S.smart_vid_crop({k: v for k, v in video.items() if k != 'trans_inds'}, CP, save_vid=False, engine=engine, shot_net=net)
+        assert a[0]['bbs'] == b[0]['bbs'] and np.array_equal(a[0]['segmentation'], b[0]['segmentation'])
+    finally:
+        S.set_video_reader(None)

@@ -350,3 +350,35 @@ def test_lane_rows_follow_the_job():
 def S_init():
     from retargetvid_amd import smartVidCrop as S
     return S.sc_init_crop_params()
+
+
+def test_pillow_reader_decodes_frame_folders_and_multi_frame_files(tmp_path):
+    """The decode door (the reference decodes with cv2, smartVidCrop.py:299-335 -- absent here): the reader that
+    does run in this image.  A folder of frame images and multi-frame files come back as the ingest_pickle dict with the very
+    bytes that were written (lossless formats), RGB, frame rate from the argument or the file, shots from the detector or left
+    to the entry point (shots=None: no trans_inds key)."""
+    from PIL import Image
+    from retargetvid_amd import ingest
+    fr = np.random.RandomState(3).randint(0, 256, (9, 36, 64, 3)).astype(np.uint8)
+    d = tmp_path / 'clip'
+    d.mkdir()
+    for i, f in enumerate(fr):
+        Image.fromarray(f).save(str(d / ('frame_%04d.png' % i)))
+    (d / 'notes.txt').write_text('not a frame')
+    v = ingest.read_frames_pillow(str(d), fr=30.0)
+    assert np.array_equal(v['frames'], fr) and v['frames'].flags['C_CONTIGUOUS']
+    assert (v['fr'], v['frame_count'], v['w'], v['h'], v['trans_inds']) == (30.0, 9, 64, 36, [0, 9])
+    assert ingest.read_frames_pillow(str(d), max_frames=4)['frames'].shape[0] == 4
+    ims = [Image.fromarray(f) for f in fr]
+    ims[0].save(str(tmp_path / 'a.png'), save_all=True, append_images=ims[1:], duration=40)      # APNG, 40 ms per frame
+    v = ingest.read_frames_pillow(str(tmp_path / 'a.png'), shots=None)
+    assert np.array_equal(v['frames'], fr) and v['fr'] == 25.0 and 'trans_inds' not in v
+    ims[0].save(str(tmp_path / 'a.tiff'), save_all=True, append_images=ims[1:])
+    v = ingest.read_frames_pillow(str(tmp_path / 'a.tiff'), fr=24.0, shot_detector=lambda f: [4, 4, 0, 99])
+    assert np.array_equal(v['frames'], fr) and v['trans_inds'] == [0, 4, 9] and v['fr'] == 24.0
+    Image.fromarray(fr[0][:20]).save(str(d / 'frame_9999.png'))                              # a frame of another size
+    with pytest.raises(IOError):
+        ingest.read_frames_pillow(str(d))
+    (tmp_path / 'empty').mkdir()
+    with pytest.raises(IOError):
+        ingest.read_frames_pillow(str(tmp_path / 'empty'))                                   # a folder without frame images

@@ -710,7 +710,7 @@ def main():
                         hbm_note='un-fused layer-wise fp32 traffic of the class (in + out + weights) / class time')
         roof['traffic'] = None
         try:
-            src = next(os.path.join('profiles', f) for f in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json')
+            src = next(os.path.join('profiles', f) for f in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json')
                        if os.path.isfile(os.path.join(ROOT, 'profiles', f)))
             with open(os.path.join(ROOT, src)) as fp:
                 c = json.load(fp)['classes'][dominant]

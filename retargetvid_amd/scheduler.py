@@ -212,7 +212,7 @@ class _Lane:
             if k:
                 rows = self.row_of_frame[f0:f0 + k]
                 r0 = int(rows[0])
-                cen = 1 <= int(sc.CP['t_threshold']) <= 254
+                cen = 2 <= int(sc.CP['t_threshold']) <= 254              # (t = 1: level t - 1 is the value of the rows without a network pass)
                 if int(rows[-1]) - r0 + 1 == k:                       # no zero row inside: the network writes in place
                     self.eng.saliency(self.small[f0:f0 + k], out=self.maps[r0:r0 + k], threshold=sc.CP['t_threshold'],
                                       census=self.census[r0:r0 + k] if cen else None)
@@ -505,7 +505,7 @@ class JobScheduler:
         # the regime diagnostic of THIS video (smartVidCrop.after_ingest reports it): its maps' pixels at t - 1, t, t + 1 per map and level
         n_net = int((~v.plan['zero_map']).sum())
         tt = int(self.CP['t_threshold'])
-        if n_net and 1 <= tt <= 254:
+        if n_net and 2 <= tt <= 254:
             c = v.census.cpu().numpy()
             VD['pixels_per_grey_level_at_threshold'] = float(c[0] + c[1] + c[2]) / (3.0 * n_net)
         out = {}

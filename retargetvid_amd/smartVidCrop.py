@@ -674,7 +674,7 @@ def after_ingest(VD, CP, engine, verbose=False):
         # (maps - (t - 1)) wraps in uint8, so the three levels are exactly the values 0..2: one temporary, no synchronisation here --
         # the count travels to the host with the centres below
         tt = int(CP['t_threshold'])
-        if maps.numel() and 1 <= tt <= 254:
+        if maps.numel() and 2 <= tt <= 254:             # (t = 1: level 0 is also the value of the all-zero rows the off-by-one leaves)
             near = (maps - (tt - 1)).le_(2).sum()
         engine.threshold_(maps, CP['t_threshold'])
     sc_register_time(t, '_thresh')                     # (enqueue time; the stream is synchronised by the D2H below)

@@ -1403,6 +1403,13 @@ __device__ __forceinline__ float dec_f32(unsigned u) {
 // in a kernel of its own beside the same co-runners is NOT hit (tools/micro/pk_opsel_victim.hip), so the trigger needs more of
 // this kernel's context than the three instructions; what is established is where the value is lost and what removes it
 // (profiles/r05_mx_reproducibility.txt, item 7).
+// The smoothing kernels carry SVC_NO_PK (no packed f32 instruction at all) -- except in the diagnostic build that is meant to
+// reproduce the loss (-DSD_PACKED), which needs the compiler's packed form.
+#ifdef SD_PACKED
+#define SD_NO_PK
+#else
+#define SD_NO_PK SVC_NO_PK
+#endif
 __device__ __forceinline__ float sd_bilinear(float lx0, float lx1, float ly0, float ly1, float a00, float a01, float a10, float a11) {
 #ifdef SD_PACKED
     return ly0 * (lx0 * a00 + lx1 * a01) + ly1 * (lx0 * a10 + lx1 * a11);      // the compiler's packed form: reproduces the loss
@@ -1433,7 +1440,7 @@ extern "C" int svc_debug_sd_log(unsigned *count4, float *rec64x16) {
     return 0;
 }
 #endif
-__global__ __launch_bounds__(256) SVC_NO_PK void k_smooth_down_mfma(const float *__restrict__ logit, const float *__restrict__ phase,
+__global__ __launch_bounds__(256) SD_NO_PK void k_smooth_down_mfma(const float *__restrict__ logit, const float *__restrict__ phase,
                                                           float *__restrict__ pre, unsigned *__restrict__ fmax, int LH,
                                                           int LW, int NH, int NW, int h, int w, int rows_per_block,
                                                           int tile_cap, FDiv dw) {
@@ -1543,7 +1550,7 @@ __global__ __launch_bounds__(256) SVC_NO_PK void k_smooth_down_mfma(const float 
     if (tid == 0) atomicMax(fmax + f, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
 }
 
-__global__ __launch_bounds__(256) SVC_NO_PK void k_smooth_down(const float *__restrict__ logit, const float *__restrict__ phase,
+__global__ __launch_bounds__(256) SD_NO_PK void k_smooth_down(const float *__restrict__ logit, const float *__restrict__ phase,
                                                      float *__restrict__ pre, unsigned *__restrict__ fmax, int LH,
                                                      int LW, int NH, int NW, int h, int w, int rows_per_block,
                                                      int tile_cap, FDiv dNW, FDiv dw) {

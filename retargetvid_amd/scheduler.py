@@ -67,6 +67,49 @@ def lane_rows_for(videos, CP, lanes, cap=4096):
     return int(min(cap, max(128, 2 * (sum(n) // max(1, lanes) + 1))))
 
 
+class LookAhead:
+    """Back-pressure between the planner threads (which build on-demand videos and run shot detection AHEAD of the lanes) and the
+    feeder (which takes the videos in order): item i may be produced only while i < taken + limit, `taken` = how many items the
+    consumer has asked for so far.  The consumer only ever waits for item taken - 1, which the condition always admits, so the
+    two sides cannot dead-lock; stop() and fail() release every waiter.  Pure host logic (tests/test_host_logic.py)."""
+
+    def __init__(self, limit):
+        import threading
+        self.limit = max(1, int(limit))
+        self.taken = 0
+        self.stopped = False
+        self.error = None
+        self.high_water = 0                # most items ever admitted beyond the consumer's position (<= limit)
+        self._cv = threading.Condition()
+
+    def admit(self, i, poll=0.5):
+        """Producer side: blocks until item i may be produced.  -> False when the job was stopped or has failed."""
+        with self._cv:
+            while not (self.stopped or self.error is not None or i < self.taken + self.limit):
+                self._cv.wait(poll)
+            if self.stopped or self.error is not None:
+                return False
+            self.high_water = max(self.high_water, i - self.taken + 1)
+            return True
+
+    def take(self):
+        """Consumer side: the next item is being asked for."""
+        with self._cv:
+            self.taken += 1
+            self._cv.notify_all()
+
+    def stop(self):
+        with self._cv:
+            self.stopped = True
+            self._cv.notify_all()
+
+    def fail(self, err):
+        with self._cv:
+            if self.error is None:
+                self.error = err
+            self._cv.notify_all()
+
+
 class _Video:
     __slots__ = ('idx', 'video', 'plan', 'lane', 'row0', 'xy', 'remaining', 'maps', 'pos', 'done', 'sink', 'ready', 'census')
 
@@ -367,7 +410,7 @@ class JobScheduler:
                           seconds_device_side=t1 - t0, seconds_host_stage_drain=t2 - t1, lanes=len(lanes),
                           feeder_seconds={k: round(v, 4) for k, v in self.host_s.items()})
         if planner:                                           # shot detection ahead of the lanes: how far ahead it was allowed / ever got
-            self.stats.update(planners=len(planner), plan_ahead=self.plan_ahead, plan_high_water=self.plan_high_water)
+            self.stats.update(planners=len(planner), plan_ahead=self.plan_ahead, plan_high_water=self._look.high_water)
         return self.out
 
     # ---- feeder-side helpers ------------------------------------------------------------------------------------------
@@ -378,9 +421,8 @@ class JobScheduler:
         i = self.next_idx
         shots = None
         if self._plan_ready is not None:                      # shot detection ran (or is running) in the planner thread
-            with self._plan_cv:                               # the planners may now materialise video i + plan_ahead
-                self.next_idx += 1
-                self._plan_cv.notify_all()
+            self.next_idx += 1
+            self._look.take()                                 # the planners may now materialise video i + plan_ahead
             self._plan_ready[i].wait()
             if self._plan_err is not None:
                 raise self._plan_err
@@ -411,8 +453,6 @@ class JobScheduler:
             return None
         self._plan_ready = [threading.Event() for _ in self.videos]
         self._planned = [None] * len(self.videos)
-        self._plan_cv = threading.Condition()
-        self.plan_high_water = 0                              # most videos ever planned beyond the feeder's (stats; the bound is plan_ahead)
         while len(self._plan_nets) < min(self.PLANNERS, len(self.videos)):
             # planner 0 runs the caller's network only when that network owns its engine: a network built on an engine the
             # caller also uses elsewhere (a lane's, get_engine()'s) must not be driven from a second thread -- a handle's
@@ -421,6 +461,7 @@ class JobScheduler:
             self._plan_nets.append(self.shot_net if (not self._plan_nets and own) else self.shot_net.clone())
         if self.plan_ahead is None:
             self.plan_ahead = len(self.engines) + 2 * len(self._plan_nets)
+        self._look = LookAhead(self.plan_ahead)
         ths = [threading.Thread(target=self._plan_ahead, args=(k, len(self._plan_nets)), name='svc-shot-planner-%d' % k, daemon=True)
                for k in range(len(self._plan_nets))]
         for th in ths:
@@ -439,11 +480,7 @@ class JobScheduler:
                         # planners take ~3 ms per video, the lanes ~11: unbounded, a job of on-demand callables would be built
                         # whole long before the lanes reach it).  The feeder only ever waits for video next_idx - 1, which this
                         # condition always admits: no deadlock.
-                        with self._plan_cv:
-                            while not (self._plan_stop or self._plan_err is not None or i < self.next_idx + self.plan_ahead):
-                                self._plan_cv.wait(0.5)
-                            self.plan_high_water = max(self.plan_high_water, i - self.next_idx + 1)
-                        if self._plan_stop or self._plan_err is not None:
+                        if not self._look.admit(i) or self._plan_stop or self._plan_err is not None:
                             break
                         v = self.videos[i]() if callable(self.videos[i]) else self.videos[i]
                         shots = None
@@ -455,6 +492,7 @@ class JobScheduler:
                         self._plan_ready[i].set()
         except BaseException as e:                            # surfaced by the feeder (_next_video)
             self._plan_err = e
+            self._look.fail(e)
         finally:
             for ev in self._plan_ready[k::stride]:
                 ev.set()
@@ -464,9 +502,8 @@ class JobScheduler:
 
     def _stop_planner(self, ths):
         if ths:
-            with self._plan_cv:
-                self._plan_stop = True
-                self._plan_cv.notify_all()
+            self._plan_stop = True
+            self._look.stop()
             for th in ths:
                 th.join()
 

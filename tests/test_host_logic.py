@@ -382,3 +382,52 @@ def test_pillow_reader_decodes_frame_folders_and_multi_frame_files(tmp_path):
     (tmp_path / 'empty').mkdir()
     with pytest.raises(IOError):
         ingest.read_frames_pillow(str(tmp_path / 'empty'))                                   # a folder without frame images
+
+
+def test_look_ahead_bounds_the_planners_and_cannot_dead_lock():
+    """scheduler.LookAhead (round-5 advisor: the planner threads ran unbounded ahead of the lanes): three producers walk the items
+    round-robin like JobScheduler._plan_ahead, one consumer takes them in order with random pauses like the feeder; no item is ever
+    produced more than `limit` ahead of the consumer, every item arrives (no dead-lock, also with limit = 1), stop() and fail()
+    release producers that wait."""
+    import random
+    import threading
+    import time
+    from retargetvid_amd.scheduler import LookAhead
+    for limit, n, producers in ((1, 30, 3), (2, 40, 3), (5, 40, 2), (50, 20, 3)):
+        look = LookAhead(limit)
+        ready = [threading.Event() for _ in range(n)]
+        ahead, lock = [], threading.Lock()
+
+        def produce(k):
+            for i in range(k, n, producers):
+                if not look.admit(i, poll=0.05):
+                    return
+                with lock:
+                    ahead.append(i - look.taken + 1)
+                time.sleep(random.random() * 1e-3)
+                ready[i].set()
+        ths = [threading.Thread(target=produce, args=(k,), daemon=True) for k in range(producers)]
+        for t in ths:
+            t.start()
+        rng = random.Random(limit)
+        for i in range(n):                                   # the feeder: ask for item i, wait for it
+            look.take()
+            assert ready[i].wait(10.0), 'item %d never arrived (limit %d)' % (i, limit)
+            time.sleep(rng.random() * 2e-3)
+        for t in ths:
+            t.join(10.0)
+            assert not t.is_alive()
+        assert len(ahead) == n and max(ahead) <= limit and look.high_water <= limit
+        if limit < n:
+            assert look.high_water == min(limit, n)            # the producers DID run ahead as far as they were allowed
+    # producers that wait are released by stop() and by fail()
+    for release in ('stop', 'fail'):
+        look = LookAhead(1)
+        res = []
+        t = threading.Thread(target=lambda: res.append(look.admit(5, poll=0.05)), daemon=True)
+        t.start()
+        time.sleep(0.1)
+        assert t.is_alive()                                  # item 5 is not admitted while nothing has been taken
+        look.stop() if release == 'stop' else look.fail(RuntimeError('x'))
+        t.join(5.0)
+        assert not t.is_alive() and res == [False]

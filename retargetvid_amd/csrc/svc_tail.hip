@@ -2388,7 +2388,9 @@ __global__ __launch_bounds__(64) void k_tree(TailArgs A) {
 #ifndef TP_CAP
 #define TP_CAP 4352                     // points per map with everything in LDS
 #endif
+#ifndef TP_CAP_BIG
 #define TP_CAP_BIG 8192                 // ... with the jump buffers, weights and order in the frame's workspace
+#endif
 #define TP_CAP_HUGE 65025               // ... with every per-edge array there (L2-resident); LDS keeps the rank-maxima levels and the cluster tables
 #define TP_NONE 0xFFFFu
 enum { TP_SMALL = 0, TP_BIRTH = 1, TP_SPLIT = 2, TP_ABS_A = 3, TP_ABS_B = 4 };   // ABS_A: the a side is big, the b side falls out
@@ -2413,7 +2415,11 @@ static size_t tp_lds_bytes(int hw, int mcs, int *cap_clusters, int *cap_clusters
 #define TP_LDS_BUDGET (160 * 1024 - 4096)     // LDS a tail workgroup may ask for (experiment builds: 78 KB = two workgroups per CU)
 #endif
     const size_t budget = TP_LDS_BUDGET;
+#ifdef TP_CC_EXACT                                         // (experiment builds with a small budget: every cluster the budget holds, not the next power-of-two fraction)
+    if (per_edge + (size_t)cc * 48 + 512 > budget) cc = std::max(8, (int)((budget > per_edge + 512 ? budget - per_edge - 512 : 0) / 48));
+#else
     while (cc > 8 && per_edge + (size_t)cc * 48 + 512 > budget) cc /= 2;
+#endif
     *cap_clusters = cc;
     const size_t total = per_edge + (size_t)cc * 48 + 512;
     if (cap_clusters_huge) {                               // MODE 2 keeps only the rank-maxima levels in LDS: the rest of the launch's allocation is cluster tables

@@ -35,7 +35,7 @@
 // What the kernels below assume of TB, stated once (round 4's TB = 512 build did not terminate: three block reductions read
 // sixteen per-wavefront slots whatever NW16 was, i.e. the other parity's stale minima): the per-wavefront slots of a block
 // reduction are read back as slot[lane & (NW16 - 1)] and reduced inside a row of 16 lanes, so NW16 must be a power of two of
-// at most 16; k_prim_lvl's rounds run on LVL_WORKERS = 4 wavefronts.  Every launch below uses TB, and the fused kernels
+// at most 16; k_prim_lvl's rounds run on LVL_WORKERS (8, at most NW16) wavefronts.  Every launch below uses TB, and the fused kernels
 // refuse to run under any other block size (tail_block_ok).
 static_assert(TB % 64 == 0 && (NW16 & (NW16 - 1)) == 0 && NW16 >= 4 && NW16 <= 16,
               "the tail kernels need 4, 8 or 16 wavefronts per workgroup");
@@ -794,6 +794,10 @@ static_assert(LVL_CAP % TB == 0, "k_prim_lvl keeps LVL_CAP / TB points per threa
 #define LVL_NB 256                     // batches of tree nodes a map can have pending (then everything is settled at once)
 #define LVL_NEAR 64u                   // a rise whose bound exceeds this is a jump between blobs: the bound is tightened first
 
+#ifndef LVL_WORKERS
+#define LVL_WORKERS 8                   // wavefronts that run the rounds (lane = candidate), each probing its share of the candidates' discs.  Round 6: 8 instead of 4
+#endif                                  // (two per SIMD): a round's probe is one group of LDS gathers instead of two -- the Prim 313 -> 273 us at 1 800 points, 1 036 -> 935 at 10 000; 2: 404
+static_assert(LVL_WORKERS >= 1 && LVL_WORKERS <= NW16 && (LVL_WORKERS & (LVL_WORKERS - 1)) == 0, "LVL_WORKERS: a power of two of at most the workgroup's wavefronts (every worker probes its share of the disc)");
 struct OccW { uint32_t bits, base; };                                  // 32 grid cells: occupancy, points before them
 typedef short lvl_s2 __attribute__((ext_vector_type(2)));
 
@@ -802,7 +806,7 @@ static size_t lvl_lds_bytes(int h, int w, int n_ring) {
     const size_t cells = (size_t)(h + 2 * LVL_PAD) * (w + 2 * LVL_PAD);
     auto up = [](size_t b) { return (b + 15) / 16 * 16; };
     return up((cells + 31) / 32 * sizeof(OccW)) + up(cap * 8) + up(cap * 4) + up((cap + 63) / 64 * 8) +
-           up((size_t)n_ring * 8) + up(cap * 2) + up(64 * 4 * 4) + up(64 * 4 * 8) + up(2 * NW16 * 4) + up(16) +
+           up((size_t)n_ring * 8) + up(cap * 2) + up(64 * LVL_WORKERS * 4) + up(64 * LVL_WORKERS * 8) + up(2 * NW16 * 4) + up(16) +
            up(LVL_NB * 16) + up((cap + 63) / 64 * (LVL_NB / 32) * 4) + up((LVL_RING2 + 1) * 2) + 64;
 }
 
@@ -839,7 +843,6 @@ struct LvlLds {
     int gw;                 // padded grid width
 };
 
-#define LVL_WORKERS 4                   // wavefronts (one per SIMD) that run the rounds; lane = candidate
 
 // The disc d2 <= level around the candidate of every lane (on = the lane has one), the ring cells k = wave, wave +
 // LVL_WORKERS, ... of it (the other workers take the rest).  The ring entries travel through scalar registers; the
@@ -994,8 +997,8 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
         S.F = carve<uint32_t>(p, (size_t)((cap + 63) / 64) * 2);
         S.ring = carve<uint2>(p, A.n_ring);
         S.rc = carve<uint16_t>(p, cap);
-        S.cand = carve<uint32_t>(p, 64 * 4);
-        S.slot = carve<uint2>(p, 64 * 4);
+        S.cand = carve<uint32_t>(p, 64 * LVL_WORKERS);
+        S.slot = carve<uint2>(p, 64 * LVL_WORKERS);
         S.red = carve<uint32_t>(p, 2 * NW16);
         S.ctl = carve<int>(p, 4);
         S.btab = carve<uint4>(p, LVL_NB);
@@ -1346,7 +1349,7 @@ static size_t lvl_big_lds_bytes(int h, int w, int n_ring) {
     const size_t cells = (size_t)(h + 2 * LVL_PAD) * (w + 2 * LVL_PAD);
     const size_t nf = (cap + 63) / 64;
     auto up = [](size_t b) { return (b + 15) / 16 * 16; };
-    return up((cells + 31) / 32 * sizeof(OccW)) + up(nf * 8) + up((size_t)n_ring * 8) + up(64 * 4 * 4) + up(64 * 4 * 8) +
+    return up((cells + 31) / 32 * sizeof(OccW)) + up(nf * 8) + up((size_t)n_ring * 8) + up(64 * LVL_WORKERS * 4) + up(64 * LVL_WORKERS * 8) +
            up(2 * NW16 * 4) + up(16) + up(LVL_NBB * 16) + up((LVL_RING2 + 1) * 2) + up(nf * 8) + up(nf * 4) + up(NW16 * 64 * 8) +
            up(nf * (LVL_NBB / 32) * 4) + 64;
 }
@@ -1421,8 +1424,8 @@ __device__ __forceinline__ void prim_lvl_big_body(const TailArgs &A) {
         S.occ = carve<OccW>(p, nocc);
         S.F = carve<uint32_t>(p, (size_t)capf * 2);
         S.ring = carve<uint2>(p, A.n_ring);
-        S.cand = carve<uint32_t>(p, 64 * 4);
-        S.slot = carve<uint2>(p, 64 * 4);
+        S.cand = carve<uint32_t>(p, 64 * LVL_WORKERS);
+        S.slot = carve<uint2>(p, 64 * LVL_WORKERS);
         S.red = carve<uint32_t>(p, 2 * NW16);
         S.ctl = carve<int>(p, 4);
         S.btab = carve<uint4>(p, LVL_NBB);
@@ -3198,12 +3201,12 @@ static int cluster_center_impl(SvcHandle *h, uint8_t *maps, int n, int height, i
         SVC_HIP(hipFuncSetAttribute((const void *)k_prim_pt<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_prim_pt<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_prim_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-        SVC_HIP(hipFuncSetAttribute((const void *)k_prim_lvl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_prim_lvl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));      // (255 x 255 maps: 162 896 bytes with eight workers; static LDS 136)
         SVC_HIP(hipFuncSetAttribute((const void *)k_prim_lvl_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_tree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_tree_par, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-        SVC_HIP(hipFuncSetAttribute((const void *)k_tail_front, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        SVC_HIP(hipFuncSetAttribute((const void *)k_tail_front, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));      // (255 x 255 maps: 162 896 bytes with eight workers; static LDS 136)
         SVC_HIP(hipFuncSetAttribute((const void *)k_tail_back, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         SVC_HIP(hipFuncSetAttribute((const void *)k_sort, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_BYTES));
     }

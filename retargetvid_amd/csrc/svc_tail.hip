@@ -826,6 +826,101 @@ __device__ __forceinline__ uint32_t wave_prefix_min_u32(uint32_t v) {
     return v;
 }
 
+// inclusive prefix MAXIMUM over the 64 lanes (wave_incl_scan_u32's DPP pattern; identity 0)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v) {
+    const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+    return t > v ? t : v;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_max_u32(uint32_t v) {
+    v = dpp_max_u32<0x111, 0xF>(v);
+    v = dpp_max_u32<0x112, 0xF>(v);
+    v = dpp_max_u32<0x114, 0xF>(v);
+    v = dpp_max_u32<0x118, 0xF>(v);
+    v = dpp_max_u32<0x142, 0xA>(v);
+    v = dpp_max_u32<0x143, 0xC>(v);
+    return v;
+}
+// position of the n-th (0-based) set bit of the 64-bit word hi:lo (n < its population)
+__device__ __forceinline__ int select_bit64(uint32_t lo, uint32_t hi, int n) {
+    const int clo = __popc(lo);
+    uint32_t w = lo;
+    int pos = 0;
+    if (n >= clo) { w = hi; n -= clo; pos = 32; }
+    int c = __popc(w & 0xFFFFu);
+    if (n >= c) { n -= c; pos += 16; w >>= 16; }
+    c = __popc(w & 0xFFu);
+    if (n >= c) { n -= c; pos += 8; w >>= 8; }
+    c = __popc(w & 0xFu);
+    if (n >= c) { n -= c; pos += 4; w >>= 4; }
+    c = __popc(w & 0x3u);
+    if (n >= c) { n -= c; pos += 2; w >>= 2; }
+    if (n >= (int)(w & 1u)) pos += 1;
+    return pos;
+}
+// The first 64 members of the bitmap F (NF64 words of 64 points) in index order -> cw[0 ..]; returns how many (<= 64).  Called by a
+// whole wavefront; `heads` = 64 words of LDS scratch of that wavefront.
+// Round 6: RANK-parallel.  Lane k holds word k and the prefix sum of the populations tells where its members start; every word that
+// has members writes its lane number at the rank of its first one, a running maximum over the ranks gives every rank r its word, and
+// lane r then picks the (r - start)-th set bit of that word (five popcount halvings): no loop over the words.  The loop it replaces
+// took one pass per word that holds members -- the members of a level are a frontier, spread over 20 - 30 words at 1 800 points --:
+// 0.85 us of a 2.3 us round.  (Round 3's other parallel form, every lane writing ITS OWN word's bits one after the other, was the
+// slower one: that is a loop over the bits.)
+__device__ __forceinline__ int lvl_extract(const unsigned long long *F64, int NF64, uint32_t *cw, uint32_t *heads, uint32_t &mycand) {
+    const int lane = threadIdx.x & 63;
+    int ncand = 0;
+#ifdef LVL_EXTRACT_LOOP                                     // rounds 3-5 (A/B builds): one pass per word that holds members, all lanes placing that word's members
+    for (int wb = 0; wb < NF64 && ncand < 64; wb += 64) {
+        const int k = wb + lane;
+        const unsigned long long W = k < NF64 ? F64[k] : 0ull;
+        unsigned long long nz = __ballot(W != 0ull);
+        while (nz && ncand < 64) {
+            const int src = __builtin_ctzll(nz);
+            nz &= nz - 1ull;
+            const unsigned long long Wk = readlane_u64(W, src);
+            if ((Wk >> lane) & 1ull) {
+                const int rank = ncand + __popcll(Wk & ((1ull << lane) - 1ull));
+                if (rank < 64) cw[rank] = (uint32_t)((wb + src) * 64 + lane);
+            }
+            ncand += __popcll(Wk);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    ncand = min(ncand, 64);
+    mycand = lane < ncand ? cw[lane] : LVL_NONE;
+    return ncand;
+#endif
+    for (int wb = 0; wb < NF64 && ncand < 64; wb += 64) {
+        const int k = wb + lane;
+        const unsigned long long W = k < NF64 ? F64[k] : 0ull;
+        const uint32_t pc = (uint32_t)__popcll(W);
+        const uint32_t incl = wave_incl_scan_u32(pc), excl = incl - pc;
+        const int total = __builtin_amdgcn_readlane((int)incl, 63);
+        if (total == 0) continue;
+        heads[lane] = 0u;
+        __builtin_amdgcn_wave_barrier();                    // (a wavefront's LDS accesses are served in program order; the fences are for the compiler)
+        if (pc != 0u && excl < 64u) heads[excl] = (uint32_t)lane + 1u;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t head = wave_incl_scan_max_u32(heads[lane]);
+        const int src = head ? (int)head - 1 : 0;            // the word that holds rank `lane` (of this pass)
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)W);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)(W >> 32));
+        const uint32_t ex = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)excl);
+        const int rank = ncand + lane;
+        const uint32_t cand = (uint32_t)((wb + src) * 64 + select_bit64(lo, hi, lane - (int)ex));
+        if (NF64 <= 64) {                                   // one pass (maps of up to 4 096 points): rank = lane, the candidate stays in its register
+            mycand = lane < total ? cand : LVL_NONE;
+            return min(total, 64);
+        }
+        if (lane < total && rank < 64) cw[rank] = cand;
+        ncand += total;
+    }
+    __builtin_amdgcn_wave_barrier();
+    ncand = min(ncand, 64);
+    mycand = lane < ncand ? cw[lane] : LVL_NONE;
+    return ncand;
+}
+
 struct LvlLds {
     OccW *occ;              // padded grid, 32 cells per word
     uint2 *tnode;           // tree nodes in the order they joined: (row | col << 16, core distance)
@@ -1209,24 +1304,7 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
             // words with many bits each (the other way round -- lane = word, rank from a prefix sum of the populations, every
             // lane writing its own bits -- took 2.7x as long: 88 against 32 us per map at ~780 points)
             uint32_t *cw = S.cand + wave * 64;
-            for (int wb = 0; wb < NF64 && ncand < 64; wb += 64) {
-                const int k = wb + lane;
-                const unsigned long long W = k < NF64 ? ((const unsigned long long *)S.F)[k] : 0ull;
-                unsigned long long nz = __ballot(W != 0ull);
-                while (nz && ncand < 64) {
-                    const int src = __builtin_ctzll(nz);
-                    nz &= nz - 1ull;
-                    const unsigned long long Wk = readlane_u64(W, src);
-                    if ((Wk >> lane) & 1ull) {
-                        const int rank = ncand + __popcll(Wk & ((1ull << lane) - 1ull));
-                        if (rank < 64) cw[rank] = (uint32_t)((wb + src) * 64 + lane);
-                    }
-                    ncand += __popcll(Wk);
-                }
-            }
-            ncand = min(ncand, 64);
-            __builtin_amdgcn_wave_barrier();
-            if (lane < ncand) mycand = cw[lane];
+            ncand = lvl_extract((const unsigned long long *)S.F, NF64, cw, (uint32_t *)(S.slot + wave * 64), mycand);     // (the slot rows are scratch until the probe writes them)
             LVL_PHASE(1);
             if (!slow) {
                 uint32_t dmin, nmin;
@@ -1647,24 +1725,7 @@ __device__ __forceinline__ void prim_lvl_big_body(const TailArgs &A) {
         bool dropped = false;
         if (worker) {
             uint32_t *cw = S.cand + wave * 64;
-            for (int wb = 0; wb < NF64 && ncand < 64; wb += 64) {
-                const int k = wb + lane;
-                const unsigned long long W = k < NF64 ? ((const unsigned long long *)S.F)[k] : 0ull;
-                unsigned long long nz = __ballot(W != 0ull);
-                while (nz && ncand < 64) {
-                    const int src = __builtin_ctzll(nz);
-                    nz &= nz - 1ull;
-                    const unsigned long long Wk = readlane_u64(W, src);
-                    if ((Wk >> lane) & 1ull) {
-                        const int rank = ncand + __popcll(Wk & ((1ull << lane) - 1ull));
-                        if (rank < 64) cw[rank] = (uint32_t)((wb + src) * 64 + lane);
-                    }
-                    ncand += __popcll(Wk);
-                }
-            }
-            ncand = min(ncand, 64);
-            __builtin_amdgcn_wave_barrier();
-            if (lane < ncand) mycand = cw[lane];
+            ncand = lvl_extract((const unsigned long long *)S.F, NF64, cw, (uint32_t *)(S.slot + wave * 64), mycand);     // (the slot rows are scratch until the probe writes them)
             if (!slow) {
                 uint32_t dmin, nmin;
                 lvl_walk<false>(S, wave, nk, m, lane < ncand, mycand, gw, dmin, nmin, entmask);

@@ -866,7 +866,8 @@ __device__ __forceinline__ int select_bit64(uint32_t lo, uint32_t hi, int n) {
 // took one pass per word that holds members -- the members of a level are a frontier, spread over 20 - 30 words at 1 800 points --:
 // 0.85 us of a 2.3 us round.  (Round 3's other parallel form, every lane writing ITS OWN word's bits one after the other, was the
 // slower one: that is a loop over the bits.)
-__device__ __forceinline__ int lvl_extract(const unsigned long long *F64, int NF64, uint32_t *cw, uint32_t *heads, uint32_t &mycand) {
+__device__ __forceinline__ int lvl_extract(const unsigned long long *F64, int NF64, uint32_t *cw, uint32_t *heads, uint32_t &mycand,
+                                           bool have_w0 = false, unsigned long long w0 = 0ull) {
     const int lane = threadIdx.x & 63;
     int ncand = 0;
 #ifdef LVL_EXTRACT_LOOP                                     // rounds 3-5 (A/B builds): one pass per word that holds members, all lanes placing that word's members
@@ -892,7 +893,7 @@ __device__ __forceinline__ int lvl_extract(const unsigned long long *F64, int NF
 #endif
     for (int wb = 0; wb < NF64 && ncand < 64; wb += 64) {
         const int k = wb + lane;
-        const unsigned long long W = k < NF64 ? F64[k] : 0ull;
+        const unsigned long long W = (have_w0 && wb == 0) ? w0 : (k < NF64 ? F64[k] : 0ull);      // have_w0: word `lane` of F as the caller read it (nothing has written F since)
         const uint32_t pc = (uint32_t)__popcll(W);
         const uint32_t incl = wave_incl_scan_u32(pc), excl = incl - pc;
         const int total = __builtin_amdgcn_readlane((int)incl, 63);
@@ -946,16 +947,22 @@ struct LvlLds {
 //                 entrant), entmask bit it = iteration it found an entrant (iterations < 32).
 //   MARK = true:  F |= the points outside the tree whose mr is exactly `level` (tree members carry the top bit in
 //                 their core distance, so their mr never equals a level).
+//   rcv / corev: the candidate's own row | col << 8 and core distance word as read here (the commit needs them again);
+//   j4: the point indices found in the worker's first four cells (the entrants among them are marked without looking them up again).
 template <bool MARK>
 __device__ __forceinline__ void lvl_walk(const LvlLds &S, int wave, int nk, uint32_t level, bool on, uint32_t cand, int gw,
-                                         uint32_t &dmin, uint32_t &nmin, uint32_t &entmask) {
+                                         uint32_t &dmin, uint32_t &nmin, uint32_t &entmask, uint32_t &rcv, uint32_t &corev, uint32_t (&j4)[4]) {
     const int lane = threadIdx.x & 63;
     dmin = nmin = LVL_NONE;
     entmask = 0;
     const uint32_t c0 = on ? cand : 0u;
     const uint32_t v = S.rc[c0];
     const uint32_t cell0 = on ? ((v & 255) + LVL_PAD) * (uint32_t)gw + (v >> 8) + LVL_PAD : 0u;   // cell 0: in the empty border
-    const uint32_t ci = on ? (S.corei[c0] & ~LVL_TREE) : LVL_NONE;
+    const uint32_t craw = S.corei[c0];
+    const uint32_t ci = on ? (craw & ~LVL_TREE) : LVL_NONE;
+    rcv = v; corev = craw;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) j4[u] = 0u;
     const int nit = (nk - wave + LVL_WORKERS - 1) / LVL_WORKERS;       // this worker's cells
     for (int ib = 0; ib < nit; ib += 64) {
         const int kk = LVL_WORKERS * (ib + lane) + wave;
@@ -979,6 +986,7 @@ __device__ __forceinline__ void lvl_walk(const LvlLds &S, int wave, int nk, uint
                 j[u] = in[u] ? ow[u].base + (uint32_t)__popc(ow[u].bits & ((1u << (cell[u] & 31u)) - 1u)) : 0u;
                 cj[u] = S.corei[j[u]];
                 if (!MARK) fw[u] = S.F[j[u] >> 5];
+                if (!MARK && ib + it0 == 0) j4[u] = j[u];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1148,6 +1156,8 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
     int cnt = 1, done = 0, nb = 0, parity = 0;
     uint32_t m = 0, cur = 0, swept = 0;
     bool need_rise = true;
+    unsigned long long fkeep = 0ull;                                // word `lane` of F as the F-empty test read it (maps of <= 4 096 points)
+    bool fkeep_ok = false;
     int n_rounds = 0, n_rises = 0;
     long long ph[5] = {0, 0, 0, 0, 0}, tp = wall_clock64();        // phase stamps (10 ns units): rise, extract, probe, accept + commit, mark
     const bool stamps = (A.prim_lvl & 2) != 0;                      // SVC_PRIM_LVL=3: phase stamps (each costs a scalar memory round trip)
@@ -1176,6 +1186,7 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
             // ---- rise: the nodes added since the last one become batches; R is caught up block by block (a batch
             // against a chunk) where the block's lower bound allows a value <= the bound; new level, new F
             ++n_rises;
+            fkeep_ok = false;                                        // F is rewritten below
             uint32_t cjq[LVL_PT], rcq[LVL_PT];
             uint4 cbq[LVL_PT];
             uint32_t qmask = 0;
@@ -1297,18 +1308,19 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
         const bool fast = nk <= 32 * LVL_WORKERS;                       // every worker's share of the disc fits a 32-bit entrant mask
         int ncand = 0, a = 1;
         uint32_t mycand = LVL_NONE, m2 = LVL_NONE, entmask = 0;
+        uint32_t rcv = 0, corev = 0, j4[4] = {0u, 0u, 0u, 0u};         // from the probe: the candidate's own row | col << 8 and core word, the points of its first four cells
         bool dropped = false;
         if (worker) {
-            // the first 64 members of F in index order (each worker for itself: no barrier).  A loop over the WORDS that hold
-            // members, all lanes placing one word's members at once: the members of a level are raster neighbours, i.e. few
-            // words with many bits each (the other way round -- lane = word, rank from a prefix sum of the populations, every
-            // lane writing its own bits -- took 2.7x as long: 88 against 32 us per map at ~780 points)
+            // the first 64 members of F in index order (each worker for itself: no barrier; lvl_extract).  Round 6: a dependent LDS round
+            // trip costs this chain 0.2 - 0.4 us, so three of a round's were taken out: F's words come from the registers the F-empty test
+            // of the previous round read them into (fkeep: nothing writes F in between unless the level rose), the commit re-uses what the
+            // probe read of the candidate, and the entrants of the first four cells are marked from the indices the probe found.
             uint32_t *cw = S.cand + wave * 64;
-            ncand = lvl_extract((const unsigned long long *)S.F, NF64, cw, (uint32_t *)(S.slot + wave * 64), mycand);     // (the slot rows are scratch until the probe writes them)
+            ncand = lvl_extract((const unsigned long long *)S.F, NF64, cw, (uint32_t *)(S.slot + wave * 64), mycand, fkeep_ok, fkeep);     // (the slot rows are scratch until the probe writes them)
             LVL_PHASE(1);
             if (!slow) {
                 uint32_t dmin, nmin;
-                lvl_walk<false>(S, wave, nk, m, lane < ncand, mycand, gw, dmin, nmin, entmask);
+                lvl_walk<false>(S, wave, nk, m, lane < ncand, mycand, gw, dmin, nmin, entmask, rcv, corev, j4);
                 S.slot[wave * 64 + lane] = make_uint2(dmin, nmin);
             }
         }
@@ -1340,17 +1352,21 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
             if (wave == 0 && lane < a) {
                 const uint32_t from = lane == 0 ? cur : prevc;
                 mst[cnt - 1 + lane] = hdb::Edge{(uint16_t)from, (uint16_t)mycand, m};
-                const uint32_t v = S.rc[mycand];
-                const uint32_t cj = S.corei[mycand];
+                const uint32_t v = slow ? (uint32_t)S.rc[mycand] : rcv;           // (a slow round has no probe)
+                const uint32_t cj = slow ? S.corei[mycand] : corev;
                 S.tnode[cnt + lane] = make_uint2((v & 255) | ((v >> 8) << 16), cj);
                 S.corei[mycand] = cj | LVL_TREE;
                 if (!dropped) atomicAnd(&S.F[mycand >> 5], ~(1u << (mycand & 31u)));
             }
             if (!slow && !dropped && fast && lane < a && entmask) {
-                // entrants of the accepted candidates, from the cells the probe remembered
-                const uint32_t v = S.rc[mycand];
+                // entrants of the accepted candidates: those of the first four cells from the indices the probe kept, the others from the
+                // cells it remembered
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if ((entmask >> u) & 1u) atomicOr(&S.F[j4[u] >> 5], 1u << (j4[u] & 31u));
+                const uint32_t v = rcv;
                 const uint32_t cell0 = ((v & 255) + LVL_PAD) * (uint32_t)gw + (v >> 8) + LVL_PAD;
-                uint32_t em = entmask;
+                uint32_t em = entmask & ~15u;
                 while (em) {
                     const int it = __builtin_ctz(em);
                     em &= em - 1u;
@@ -1387,18 +1403,26 @@ __device__ __forceinline__ void prim_lvl_body(const TailArgs &A) {
             if (worker) {
                 const bool on = dropped ? lane == a - 1 : lane < a;
                 uint32_t d_, n_, e_;
-                lvl_walk<true>(S, wave, (int)S.rcnt[mnew], mnew, on, mycand, gw, d_, n_, e_);
+                uint32_t r_, c_, j_[4];
+                lvl_walk<true>(S, wave, (int)S.rcnt[mnew], mnew, on, mycand, gw, d_, n_, e_, r_, c_, j_);
             }
             m = mnew;
             __syncthreads();
             LVL_PHASE(4);
         }
-        // F empty -> the level rises (every wavefront reads the same words)
+        // F empty -> the level rises (every wavefront reads the same words).  Maps of up to 4 096 points: the words stay in registers for the
+        // next round's extraction (no write to F lies between this read and that one unless the level rises, which clears fkeep_ok).
         {
             bool any = false;
-            for (int wb = 0; wb < NF64; wb += 64) {
-                const int k = wb + lane;
-                any = any || (__ballot(k < NF64 && ((const unsigned long long *)S.F)[k] != 0ull) != 0ull);
+            if (NF64 <= 64) {
+                fkeep = lane < NF64 ? ((const unsigned long long *)S.F)[lane] : 0ull;
+                any = __ballot(fkeep != 0ull) != 0ull;
+                fkeep_ok = true;
+            } else {
+                for (int wb = 0; wb < NF64; wb += 64) {
+                    const int k = wb + lane;
+                    any = any || (__ballot(k < NF64 && ((const unsigned long long *)S.F)[k] != 0ull) != 0ull);
+                }
             }
             need_rise = !any;
         }
@@ -1728,7 +1752,8 @@ __device__ __forceinline__ void prim_lvl_big_body(const TailArgs &A) {
             ncand = lvl_extract((const unsigned long long *)S.F, NF64, cw, (uint32_t *)(S.slot + wave * 64), mycand);     // (the slot rows are scratch until the probe writes them)
             if (!slow) {
                 uint32_t dmin, nmin;
-                lvl_walk<false>(S, wave, nk, m, lane < ncand, mycand, gw, dmin, nmin, entmask);
+                uint32_t r_, c_, j_[4];
+                lvl_walk<false>(S, wave, nk, m, lane < ncand, mycand, gw, dmin, nmin, entmask, r_, c_, j_);
                 S.slot[wave * 64 + lane] = make_uint2(dmin, nmin);
             }
         }
@@ -1797,7 +1822,8 @@ __device__ __forceinline__ void prim_lvl_big_body(const TailArgs &A) {
             if (worker) {
                 const bool on = dropped ? lane == a - 1 : lane < a;
                 uint32_t d_, n_, e_;
-                lvl_walk<true>(S, wave, (int)S.rcnt[mnew], mnew, on, mycand, gw, d_, n_, e_);
+                uint32_t r_, c_, j_[4];
+                lvl_walk<true>(S, wave, (int)S.rcnt[mnew], mnew, on, mycand, gw, d_, n_, e_, r_, c_, j_);
             }
             m = mnew;
             __syncthreads();

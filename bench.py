@@ -302,7 +302,8 @@ def config3_job(world, rank, dist_on, dev, sd, lanes, rccl_init_s, mode='residen
         shot_net.close()
     if mode == 'shot_net':
         n_sel_mine = int(stats[-1]['network_frames'])
-    n_sel = torch.tensor([n_sel_mine], dtype=torch.int64, device=dev)
+    n_sel = torch.tensor([n_sel_mine], dtype=torch.int64,
+                         device=dev if not dist_on or torch.distributed.get_backend() == 'nccl' else torch.device('cpu'))
     if dist_on:
         torch.distributed.all_reduce(n_sel)
     if rank != 0:
@@ -344,7 +345,11 @@ def main():
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d: launch with `python bench.py --gpus N` (self-launching) or '
                          '`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`' % (args.gpus, world))
-    if args.gpus > torch.cuda.device_count():
+    # BENCH_SHARE_GPU=1 (test aid, never a measurement): the ranks share the visible GPUs (rank -> cuda:LOCAL_RANK % count) and
+    # talk over gloo (RCCL refuses two ranks on one device), so that `bench.py --gpus 2` -- the self-launch, the sharding by
+    # rank, the barriers, the MAX over ranks and the box gather -- runs on a one-GPU box (tests/test_gpu_dist_rccl.py)
+    share_gpu = os.environ.get('BENCH_SHARE_GPU', '0') == '1'
+    if args.gpus > torch.cuda.device_count() and not share_gpu:
         raise SystemExit('bench.py: --gpus %d but only %d GPU(s) visible' % (args.gpus, torch.cuda.device_count()))
     # BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, barrier, MAX all-reduce, box gather) with any
     # world size, including 1 under torch.distributed.run -- a way to exercise it on a single-GPU box
@@ -352,14 +357,20 @@ def main():
     rccl_init_s = None
     if dist_on:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if share_gpu:
+            local %= torch.cuda.device_count()
         torch.cuda.set_device(local)
         t_init = time.perf_counter()
-        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if share_gpu:
+            torch.distributed.init_process_group('gloo')
+        else:
+            torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
         torch.distributed.barrier()                     # the communicator is built by the first collective
         rccl_init_s = time.perf_counter() - t_init
     else:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', torch.cuda.current_device())
+    coll_dev = torch.device('cpu') if share_gpu else dev      # where the (tiny) collective payloads live: the device under RCCL
 
     B = args.batch
     P = max(1, args.pipeline)
@@ -581,12 +592,12 @@ def main():
     rank_fps = [B * args.steps / dt_local]
     seen_world = 1
     if dist_on:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
         seen_world = torch.distributed.get_world_size()
-        tl = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(seen_world)]
-        torch.distributed.all_gather(tl, torch.tensor([dt_local], dtype=torch.float64, device=dev))
+        tl = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(seen_world)]
+        torch.distributed.all_gather(tl, torch.tensor([dt_local], dtype=torch.float64, device=coll_dev))
         rank_fps = [B * args.steps / float(t.item()) for t in tl]
 
     # rounds 1-4 fed ONE batch to every slot (every map of a step then held the same number of points): the same timed region that
@@ -787,6 +798,8 @@ def main():
                                distinct_batches='every slot steps through its own batch of 32 frames (same generator, seeds 100 + 1000 k); rounds 1-4 fed one batch to every slot',
                                parallelism='frames sharded, dp%d' % world,
                                world_size_seen_by_rccl=seen_world if dist_on else None,
+                               ranks_share_gpus=('BENCH_SHARE_GPU=1: %d ranks on %d visible GPU(s) over gloo -- a functional run of the multi-rank '
+                                                 'path, NOT a measurement' % (world, torch.cuda.device_count())) if share_gpu else None,
                                per_rank_frames_per_s=[round(v, 1) for v in rank_fps],
                                points_per_map=dict(min=int(npts.min()), mean=round(float(npts.mean()), 1), max=int(npts.max())),
                                repeats=dict(regions=len(regions), ms_per_step=[round(r[0] / max(args.steps, 1) * 1e3, 4) for r in regions],

@@ -45,3 +45,33 @@ def test_bench_under_torchrun_takes_the_rccl_path_at_world_1():
     boxes = {r: {i: np.asarray(res[i][r][0]['bbs_np'], np.int32) for i in range(len(vids))} for r in ('1:3', '3:1')}
     assert synth.windows_crc32(boxes, ('1:3', '3:1'), len(vids)) == c3['windows_crc32']
     assert sum(len(b) for b in boxes['1:3'].values()) == c3['video_frames'] == 122684
+
+
+def test_bench_self_launch_at_world_2_with_the_ranks_sharing_the_gpu():
+    """`python bench.py --gpus 2` as a user types it: the self-launch (a child torch.distributed.run, nothing exec'ed), two ranks,
+    the sharding of the batches and of the 200-video job by rank, the barriers, the MAX over ranks, the gather of the boxes.  A test
+    box has ONE GPU and RCCL refuses two ranks on one device, so BENCH_SHARE_GPU=1 puts both ranks on it and the (<= 16 B per
+    frame) exchange on gloo: the numbers mean nothing, the path is the one `--gpus N` takes on a multi-GPU node, and the gathered
+    windows of the job must be those of one process."""
+    env = dict(os.environ, BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0', BENCH_VARIANT='0', BENCH_TORCH_BASELINE='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--cpu-sample', '0',
+           '--repeats', '1', '--iso-steps', '1']
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1                                   # rank 0 prints, rank 1 does not
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['steps'] == 4
+    cfg = d['config']
+    assert cfg['world_size_seen_by_rccl'] == 2 and len(cfg['per_rank_frames_per_s']) == 2 and cfg['ranks_share_gpus']
+    assert cfg['parallelism'].endswith('dp2')
+    # value = the frames of BOTH ranks over the slowest rank's time
+    assert abs(d['value'] - 2 * 32 * 4 / (d['ms_per_step'] * 4e-3)) < 1e-3 * d['value']
+    c3 = cfg['config3']
+    assert c3['videos'] == 200 and c3['n_gpus'] == 2 and c3['video_frames'] == 122684
+    # the windows two ranks computed and gathered are those of one process (the checksum the world-1 test above derives in-process
+    # from crop_videos; the frames, cuts and weights are functions of the seeds only)
+    assert c3['windows_crc32'] == 508678473
+    assert cfg['config3_host_fed'] is None and cfg['config3_shot_net'] is None      # N = 1 only

@@ -408,3 +408,16 @@ def test_a_folder_of_frame_images_through_the_decode_door(engine, tmp_path):
         assert a[0]['bbs'] == b[0]['bbs'] and np.array_equal(a[0]['segmentation'], b[0]['segmentation'])
     finally:
         S.set_video_reader(None)
+
+
+def test_random_videos_and_parameters_every_difference_explained(engine, synthetic_sd):
+    """tools/soak_e2e.py on a few videos (the soak proper: profiles/r06_job_x_soak_e2e_explained.txt, 140 videos): random frame
+    shapes, cuts, frame rates, skip / read_batch / threshold / target ratio, both parameter sets.  The windows must be within
+    north_star's +-1 px of the oracle pipeline's, selection and scenes equal; a video whose centres differ AT ALL is accepted only if
+    the raw maps of the two implementations differ by at most one grey level with a pixel on either side of the threshold AND the
+    oracle's tail fed the GPU's maps reproduces the GPU's centres and windows exactly."""
+    from tools import soak_e2e
+    lines = []
+    r = soak_e2e.soak(10, 21, engine, synthetic_sd, say=lines.append)
+    assert r['mismatches'] == 0 and r['beyond_1px'] == 0, '\n'.join(lines)
+    assert r['videos'] == 10 and r['frames'] > 0

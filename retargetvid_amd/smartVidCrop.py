@@ -359,6 +359,14 @@ def plan_video(video, crop_params, engine=None, shot_net=None, shots=None):
         if not scenes:
             raise ValueError('trans_inds %r yields no scenes; pass at least [0, frame_count]' % (trans_inds,))
         seg = np.array(scenes, dtype=np.int32)
+    if int(seg[0][0]) != 0:
+        # predictions_to_scenes (:211-228) opens the first scene where the transition probability first DROPS below the threshold, so a
+        # video that begins inside a transition (a fade-in; a shot network that reports "transition" on the opening frames) leaves its
+        # first frames in no scene, and so does a trans_inds list that does not begin with 0.  The reference has no check for it (:799-815)
+        # and fails later, in the per-shot interpolation; here it is an error before any device work.
+        raise ValueError('the first scene starts at frame %d, not 0: frames 0..%d belong to no scene (%s)' % (
+            int(seg[0][0]), int(seg[0][0]) - 1,
+            'the transition probability is above the threshold from the first frame on' if trans_probs is not None else 'trans_inds must begin with 0'))
     seg_sel = np.array([[map2orig[v] for v in row] for row in seg], dtype=np.int32)
     n_sel = len(true_inds)
     # the reference's sanity checks (:799-825), as exceptions

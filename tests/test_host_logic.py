@@ -308,6 +308,31 @@ def test_plan_video_bookkeeping_for_the_scheduler():
         S.plan_video(dict(video, trans_inds=[7]), CP)
     with pytest.raises(ValueError):
         S.plan_video(dict(video, trans_inds=None), CP)              # no shots and no shot network
+    # A video that BEGINS inside a transition: predictions_to_scenes (smartVidCrop.py:211-228) opens the first scene where the
+    # probability first drops below the threshold, so the opening frames are in no scene.  The reference has no check for it and
+    # fails in the per-shot interpolation (so does the oracle's restatement: found by tools/soak_video_path.py); here it is a
+    # ValueError from the host bookkeeping, before any device work -- and the same for a trans_inds list that does not begin with 0.
+    from retargetvid_amd import transnetv1_handler as T
+    probs = np.zeros(n, np.float32)
+    probs[:100] = 0.6
+    probs[177] = probs[179] = 0.5
+    seg = np.array(T.predictions_to_scenes(probs, threshold=0.1), dtype=np.int32)
+    for i in range(len(seg) - 1):
+        seg[i][1] = seg[i + 1][0] - 1
+    seg[-1][1] = n - 1
+    assert seg[0][0] == 100
+    shots = dict(trans_probs=probs, segmentation=seg, trans_inds=T.shots_to_trans_inds(seg, n))
+    with pytest.raises(ValueError, match='first scene starts at frame 100'):
+        S.plan_video(dict(video, trans_inds=None), CP, shots=shots)
+    with pytest.raises(ValueError, match='trans_inds must begin with 0'):
+        S.plan_video(dict(video, trans_inds=[5, 100, n]), CP)
+    from oracle import temporal_ref as TR
+    ti, m2o, _ = P.select_frames_video(n, n, probs, 0.1, CP['skip'], CP['read_batch'])
+    oseg = P.scenes_from_probs(probs, 0.1)
+    osel = np.array([[m2o[v] for v in row] for row in oseg], dtype=np.int32)
+    with pytest.raises((IndexError, ValueError)):                     # the reference's arithmetic on that input
+        dxi, dyi = TR.interpolate_centres(list(np.linspace(20, 100, len(ti))), list(np.linspace(30, 60, len(ti))), oseg, osel, ti)
+        TR.smoothing(dxi, dyi, oseg, 25.0, dict(P.init_crop_params(), read_batch=150))
 
 
 def test_lazy_result_dict_reports_lazy_keys_without_building_them():
